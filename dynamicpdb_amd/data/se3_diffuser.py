@@ -1,0 +1,135 @@
+"""SE(3) diffuser = IGSO(3) x VP-SDE.  API mirror of the reference's
+src/data/se3_diffuser.py (SE3Diffuser :31-280): forward_marginal, reverse,
+sample_ref, calc_rot_score, calc_trans_score, score_scaling keep their names,
+arguments, return dict keys and ValueErrors.  The two score heads evaluated
+inside the network forward run as HIP kernels on device tensors."""
+import logging
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as _SciRot
+
+from ..rigid import Rigid, Rotation
+from . import r3_diffuser, so3_diffuser
+
+
+def _extract_trans_rots(rigid: Rigid):
+    rot = rigid.get_rots().get_rot_mats().detach().cpu().numpy()
+    shp = rot.shape[:-2]
+    rotvec = _SciRot.from_matrix(rot.reshape(-1, 3, 3)).as_rotvec().reshape(shp + (3,))
+    return rigid.get_trans().detach().cpu().numpy(), rotvec
+
+
+def _assemble_rigid(rotvec, trans, device=torch.device('cpu')):
+    shp = rotvec.shape[:-1]
+    rotmat = _SciRot.from_rotvec(rotvec.reshape(-1, 3)).as_matrix().reshape(shp + (3, 3))
+    return Rigid(Rotation(rot_mats=torch.Tensor(rotmat).to(device)), torch.tensor(trans).to(device))
+
+
+class SE3Diffuser:
+    def __init__(self, se3_conf):
+        self._log = logging.getLogger(__name__)
+        self._se3_conf = se3_conf
+        self._diffuse_rot = se3_conf.diffuse_rot
+        self._so3_diffuser = so3_diffuser.SO3Diffuser(se3_conf.so3)
+        self._diffuse_trans = se3_conf.diffuse_trans
+        self._r3_diffuser = r3_diffuser.R3Diffuser(se3_conf.r3)
+
+    @staticmethod
+    def _apply_mask(x_diff, x_fixed, diff_mask):
+        return diff_mask * x_diff + (1 - diff_mask) * x_fixed
+
+    def forward_marginal(self, rigids_0: Rigid, t: float, diffuse_mask=None, as_tensor_7=True):
+        trans_0, rot_0 = _extract_trans_rots(rigids_0)
+        if self._diffuse_rot:
+            rot_t, rot_score = self._so3_diffuser.forward_marginal(rot_0, t)
+            rot_score_scaling = self._so3_diffuser.score_scaling(t)
+        else:
+            rot_t, rot_score, rot_score_scaling = rot_0, np.zeros_like(rot_0), np.ones_like(t)
+        if self._diffuse_trans:
+            trans_t, trans_score = self._r3_diffuser.forward_marginal(trans_0, t)
+            trans_score_scaling = self._r3_diffuser.score_scaling(t)
+        else:
+            trans_t, trans_score, trans_score_scaling = trans_0, np.zeros_like(trans_0), np.ones_like(t)
+        if diffuse_mask is not None:
+            m = diffuse_mask[..., None]
+            rot_t = self._apply_mask(rot_t, rot_0, m)
+            trans_t = self._apply_mask(trans_t, trans_0, m)
+            trans_score = self._apply_mask(trans_score, np.zeros_like(trans_score), m)
+            rot_score = self._apply_mask(rot_score, np.zeros_like(rot_score), m)
+        rigids_t = _assemble_rigid(rot_t, trans_t)
+        if as_tensor_7:
+            rigids_t = rigids_t.to_tensor_7()
+        return {'rigids_t': rigids_t, 'trans_score': trans_score, 'rot_score': rot_score,
+                'trans_score_scaling': trans_score_scaling, 'rot_score_scaling': rot_score_scaling}
+
+    def calc_trans_0(self, trans_score, trans_t, t):
+        return self._r3_diffuser.calc_trans_0(trans_score, trans_t, t)
+
+    def calc_trans_score(self, trans_t, trans_0, t, use_torch=False, scale=True):
+        return self._r3_diffuser.score(trans_t, trans_0, t, use_torch=use_torch, scale=scale)
+
+    def calc_rot_score(self, rots_t: Rotation, rots_0: Rotation, t):
+        """score of q_0^{-1} (x) q_t as a rotation vector (reference :119-125)."""
+        quats_t, quats_0 = rots_t.get_quats(), rots_0.get_quats()
+        if quats_t.is_cuda:
+            from .. import ops
+            t_np = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            so3 = self._so3_diffuser
+            sigma = so3.discrete_sigma[so3.t_to_idx(t_np)]
+            return ops.rot_score(quats_t, quats_0, sigma)
+        from .. import host_math
+        return self._so3_diffuser.torch_score(host_math.quat_to_rotvec(
+            host_math.quat_multiply(host_math.invert_quat(quats_0), quats_t)), t)
+
+    def score(self, rigid_0: Rigid, rigid_t: Rigid, t: float):
+        tran_0, rot_0 = _extract_trans_rots(rigid_0)
+        tran_t, rot_t = _extract_trans_rots(rigid_t)
+        rot_score = self._so3_diffuser.score(rot_t, t) if self._diffuse_rot else np.zeros_like(rot_0)
+        trans_score = self._r3_diffuser.score(tran_t, tran_0, t) if self._diffuse_trans else np.zeros_like(tran_0)
+        return trans_score, rot_score
+
+    def score_scaling(self, t):
+        return self._so3_diffuser.score_scaling(t), self._r3_diffuser.score_scaling(t)
+
+    def reverse(self, rigid_t: Rigid, rot_score, trans_score, t, dt, diffuse_mask=None, center=True,
+                noise_scale=1.0, device=torch.device('cpu'), z_rot=None, z_trans=None):
+        """One reverse-SDE step t -> t-dt (reference :160-215).  z_rot / z_trans optionally
+        inject the normal draws (parity tests); default = numpy global RNG as upstream."""
+        trans_t, rot_t = _extract_trans_rots(rigid_t)
+        rot_t_1 = rot_t if not self._diffuse_rot else self._so3_diffuser.reverse(
+            rot_t=rot_t, score_t=rot_score, t=t, dt=dt, noise_scale=noise_scale, z=z_rot)
+        trans_t_1 = trans_t if not self._diffuse_trans else self._r3_diffuser.reverse(
+            x_t=trans_t, score_t=trans_score, t=t, dt=dt, center=center, noise_scale=noise_scale, z=z_trans)
+        if diffuse_mask is not None:
+            trans_t_1 = self._apply_mask(trans_t_1, trans_t, diffuse_mask[..., None])
+            rot_t_1 = self._apply_mask(rot_t_1, rot_t, diffuse_mask[..., None])
+        return _assemble_rigid(rot_t_1, trans_t_1, device)
+
+    def sample_ref(self, n_samples: int, impute: Rigid = None, diffuse_mask=None, as_tensor_7=False):
+        if impute is not None:
+            assert impute.shape[0] == n_samples
+            trans_impute, rot_impute = _extract_trans_rots(impute)
+            trans_impute = self._r3_diffuser._scale(trans_impute.reshape((n_samples, 3)))
+            rot_impute = rot_impute.reshape((n_samples, 3))
+        if diffuse_mask is not None and impute is None:
+            raise ValueError('Must provide imputation values.')
+        if (not self._diffuse_rot) and impute is None:
+            raise ValueError('Must provide imputation values.')
+        if (not self._diffuse_trans) and impute is None:
+            raise ValueError('Must provide imputation values.')
+        rot_ref = self._so3_diffuser.sample_ref(n_samples=n_samples) if self._diffuse_rot else rot_impute
+        trans_ref = self._r3_diffuser.sample_ref(n_samples=n_samples) if self._diffuse_trans else trans_impute
+        if diffuse_mask is not None:
+            rot_ref = self._apply_mask(rot_ref, rot_impute, diffuse_mask[..., None])
+            trans_ref = self._apply_mask(trans_ref, trans_impute, diffuse_mask[..., None])
+        trans_ref = self._r3_diffuser._unscale(trans_ref)
+        if not self._se3_conf.dynamics:
+            rigids_t = _assemble_rigid(rot_ref, trans_ref)
+            if as_tensor_7:
+                rigids_t = rigids_t.to_tensor_7()
+        else:
+            F = self._se3_conf.frame_time
+            rot_ref, trans_ref = rot_ref.reshape(F, -1, 3), trans_ref.reshape(F, -1, 3)
+            rigids_t = torch.stack([_assemble_rigid(rot_ref[i], trans_ref[i]).to_tensor_7() for i in range(F)], dim=0)
+        return {'rigids_t': rigids_t}

@@ -1,0 +1,529 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch functional restatement (plain torch on CPU, dtype-parametric so it
+can also run in float64) of the reference's DFOLDv2 hot path.  It is the checker
+for the HIP path: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  The product path (dynamicpdb_amd/) never does.
+
+Parity status: PINNED against the reference's own code executed in the build
+container -- tests/test_oracle_vs_reference.py compares every function here with
+the reference modules imported from /root/reference (oracle/ref_harness), and
+tests/golden/*.npz hold reference outputs minted by tests/golden/make_golden.py.
+The reference ships no tests / golden vectors of its own.
+
+Every function cites the reference file:line it restates (paths relative to
+/root/reference).  State is a flat dict P of tensors keyed by the reference's
+state_dict names.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# quaternion / rigid algebra  (openfold/utils/rigid_utils.py)
+# ----------------------------------------------------------------------------
+
+
+def quat_to_rotmat(q):
+    """openfold/utils/rigid_utils.py:185-205 (quadratic form, NO normalisation)."""
+    a, b, c, d = q.unbind(-1)
+    rows = [
+        a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c),
+        2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b),
+        2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d,
+    ]
+    return torch.stack(rows, -1).reshape(q.shape[:-1] + (3, 3))
+
+
+def quat_mul(p, q):
+    """Hamilton product, openfold/utils/rigid_utils.py:230-263."""
+    a1, b1, c1, d1 = p.unbind(-1)
+    a2, b2, c2, d2 = q.unbind(-1)
+    return torch.stack([
+        a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2,
+        a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+        a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2,
+        a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2,
+    ], -1)
+
+
+def quat_mul_vec(q, v):
+    """q (x) (0, v): openfold/utils/rigid_utils.py:266-275."""
+    zero = torch.zeros_like(v[..., :1])
+    return quat_mul(q, torch.cat([zero, v], -1))
+
+
+def quat_invert(q):
+    """openfold/utils/rigid_utils.py:282-286."""
+    conj = q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+    return conj / (q * q).sum(-1, keepdim=True)
+
+
+def rot_apply(R, x):
+    """openfold/utils/rigid_utils.py:82-106."""
+    return (R * x[..., None, :]).sum(-1)
+
+
+def rigid_apply(t7, pts):
+    """Rigid.apply with quaternion rotation: rigid_utils.py:1104-1116."""
+    R = quat_to_rotmat(t7[..., :4])
+    return rot_apply(R, pts) + t7[..., 4:]
+
+
+def rigid_invert_apply(t7, pts):
+    """Rigid.invert_apply: rigid_utils.py:1118-1130."""
+    R = quat_to_rotmat(t7[..., :4])
+    return rot_apply(R.transpose(-1, -2), pts - t7[..., 4:])
+
+
+def compose_q_update_vec(t7, upd6, mask):
+    """Rigid.compose_q_update_vec rigid_utils.py:1039-1063 (+ Rotation :587-616,
+    normalisation in Rotation.__init__ :331-332).  mask broadcasts as [...,1]."""
+    q, t = t7[..., :4], t7[..., 4:]
+    dq = quat_mul_vec(q, upd6[..., :3]) * mask
+    qn = q + dq
+    qn = qn / torch.linalg.norm(qn, dim=-1, keepdim=True)
+    dt = rot_apply(quat_to_rotmat(q), upd6[..., 3:]) * mask
+    return torch.cat([qn, t + dt], -1)
+
+
+def quat_to_rotvec(quat, eps=1e-6):
+    """src/data/utils.py:589-606."""
+    flip = (quat[..., :1] < 0).to(quat.dtype)
+    quat = quat * (1 - 2 * flip)
+    angle = 2 * torch.atan2(torch.linalg.norm(quat[..., 1:], dim=-1), quat[..., 0])
+    a2 = angle * angle
+    small = 2 + a2 / 12 + 7 * a2 * a2 / 2880
+    large = angle / torch.sin(angle / 2 + eps)
+    is_small = (angle <= 1e-3).to(quat.dtype)
+    scale = small * is_small + (1 - is_small) * large
+    return scale[..., None] * quat[..., 1:]
+
+
+# ----------------------------------------------------------------------------
+# small layers
+# ----------------------------------------------------------------------------
+
+
+def linear(P, name, x):
+    b = P.get(name + ".bias")
+    return F.linear(x, P[name + ".weight"].to(x.dtype), None if b is None else b.to(x.dtype))
+
+
+def my_layer_norm(x, eps=1e-4):
+    """MyLayerNorm src/model/ipa_pytorch_dynamic.py:709-724: statistics over the
+    WHOLE [F,N,C] tensor, unbiased variance, eps inside the sqrt, no affine."""
+    mean = x.mean()
+    var = x.var(unbiased=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def embedder(P, name, x):
+    """Linear-SiLU-Linear-MyLayerNorm-SiLU, ipa_pytorch_dynamic.py:757-796."""
+    h = F.silu(linear(P, name + ".0", x))
+    h = linear(P, name + ".2", h)
+    return F.silu(my_layer_norm(h))
+
+
+def convnet(P, name, x):
+    """ConvNet ipa_pytorch_dynamic.py:664-706 on x[F,N,C] (channels-last view of
+    the reference's [1,C,F,N]); 4 residual pairs of 5x5 convs, zero pad 2."""
+    h = x.permute(2, 0, 1).unsqueeze(0)
+    for i in (1, 2, 3, 4):
+        w0, b0 = P[f"{name}.conv{i}.0.weight"].to(x.dtype), P[f"{name}.conv{i}.0.bias"].to(x.dtype)
+        w2, b2 = P[f"{name}.conv{i}.2.weight"].to(x.dtype), P[f"{name}.conv{i}.2.bias"].to(x.dtype)
+        y = F.relu(F.conv2d(h, w0, b0, padding=2))
+        y = F.relu(F.conv2d(y, w2, b2, padding=2))
+        h = y + h
+    return h.squeeze(0).permute(1, 2, 0)
+
+
+def angle_resnet(P, name, s, s_initial, eps=1e-12):
+    """AngleResnet openfold/model/structure_module.py:114-158 (2 blocks, 7 angles)."""
+    a = linear(P, name + ".linear_in", F.relu(s)) + linear(P, name + ".linear_initial", F.relu(s_initial))
+    for l in (0, 1):
+        h = linear(P, f"{name}.layers.{l}.linear_1", F.relu(a))
+        h = linear(P, f"{name}.layers.{l}.linear_2", F.relu(h))
+        a = a + h
+    out = linear(P, name + ".linear_out", F.relu(a))
+    out = out.reshape(out.shape[:-1] + (-1, 2))
+    denom = torch.sqrt(torch.clamp((out * out).sum(-1, keepdim=True), min=eps))
+    return out, out / denom
+
+
+# ----------------------------------------------------------------------------
+# Invariant point attention  (src/model/ipa_pytorch_dynamic.py:242-516)
+# ----------------------------------------------------------------------------
+
+IPA_H, IPA_C, IPA_PQ, IPA_PV = 8, 256, 8, 12
+
+
+def ipa(P, name, s, z, t7, mask, inf=1e5, eps=1e-8, return_attn=False):
+    """s[F,N,c_s], z[N,N,c_z] (no frame axis; broadcast), t7[F,N,7], mask[F,N]."""
+    H, C, PQ, PV = IPA_H, IPA_C, IPA_PQ, IPA_PV
+    Fr, N = s.shape[0], s.shape[1]
+    q = linear(P, name + ".linear_q", s).reshape(Fr, N, H, C)                       # :350-354
+    kv = linear(P, name + ".linear_kv", s).reshape(Fr, N, H, 2 * C)                 # :351-360
+    k, v = kv[..., :C], kv[..., C:]
+
+    def points(lin, npts):                                                          # :363-390
+        raw = linear(P, name + lin, s)                     # [F,N,3*H*npts], xyz-major split
+        xyz = torch.stack(torch.chunk(raw, 3, dim=-1), -1)  # [F,N,H*npts,3]
+        glob = rigid_apply(t7[..., None, :], xyz)
+        return glob.reshape(Fr, N, H, npts, 3)
+
+    q_pts = points(".linear_q_points", PQ)
+    kv_pts = points(".linear_kv_points", PQ + PV)
+    k_pts, v_pts = kv_pts[..., :PQ, :], kv_pts[..., PQ:, :]
+
+    b = linear(P, name + ".linear_b", z)                                            # :396  [N,N,H]
+    a = torch.einsum("fihc,fjhc->fhij", q, k) * math.sqrt(1.0 / (3 * C))            # :402-406
+    a = a + math.sqrt(1.0 / 3) * b.permute(2, 0, 1)                                 # :407
+    d2 = ((q_pts[:, :, None] - k_pts[:, None, :]) ** 2).sum(-1)                     # :410-414 [F,i,j,H,PQ]
+    hw = F.softplus(P[name + ".head_weights"].to(s.dtype)) * math.sqrt(1.0 / (3 * (PQ * 9.0 / 2)))  # :415-421
+    pt = (d2 * hw[:, None]).sum(-1) * (-0.5)                                        # :422-424 [F,i,j,H]
+    a = a + pt.permute(0, 3, 1, 2)
+    sq_mask = inf * (mask[:, :, None] * mask[:, None, :] - 1)                       # :426-427
+    a = torch.softmax(a + sq_mask[:, None], dim=-1)                                 # :443-444
+
+    o = torch.einsum("fhij,fjhc->fihc", a, v).reshape(Fr, N, H * C)                 # :452-457
+    o_pt_g = torch.einsum("fhij,fjhpx->fihpx", a, v_pts)                            # :460-469 (global frame)
+    o_pt_l = rigid_invert_apply(t7[:, :, None, None, :], o_pt_g)                    # :481
+    n_l = torch.sqrt((o_pt_l ** 2).sum(-1) + eps).reshape(Fr, N, H * PV)            # :484-486
+    n_g = torch.sqrt((o_pt_g ** 2).sum(-1) + eps).reshape(Fr, N, H * PV)            # :487-488
+    o_pt_l = o_pt_l.reshape(Fr, N, H * PV, 3)
+    o_pt_g = o_pt_g.reshape(Fr, N, H * PV, 3)
+    pair_z = linear(P, name + ".down_z", z)                                         # :498 [N,N,32]
+    o_pair = torch.einsum("fhij,ijc->fihc", a, pair_z).reshape(Fr, N, -1)           # :499-502
+    feats = [o, o_pt_l[..., 0], o_pt_l[..., 1], o_pt_l[..., 2], n_l, o_pair,
+             o_pt_g[..., 0], o_pt_g[..., 1], o_pt_g[..., 2], n_g]                   # :504
+    out = linear(P, name + ".linear_out", torch.cat(feats, -1))                     # :510-514
+    if return_attn:
+        return out, a
+    return out
+
+
+# ----------------------------------------------------------------------------
+# IGSO(3) / VP-SDE score heads  (src/data/so3_diffuser.py, r3_diffuser.py)
+# ----------------------------------------------------------------------------
+
+
+class Schedules:
+    """Scalar schedule functions of SO3Diffuser / R3Diffuser (so3_diffuser.py:
+    176-213, r3_diffuser.py:26-43,159-167) with the yaml defaults."""
+
+    def __init__(self, min_sigma=0.1, max_sigma=1.5, num_sigma=1000, min_b=0.1, max_b=20.0,
+                 coordinate_scaling=1.0):
+        self.min_sigma, self.max_sigma, self.num_sigma = min_sigma, max_sigma, num_sigma
+        self.min_b, self.max_b, self.cs = min_b, max_b, coordinate_scaling
+        self.discrete_sigma = self.sigma(np.linspace(0.0, 1.0, num_sigma))
+
+    def sigma(self, t):
+        return np.log(t * np.exp(self.max_sigma) + (1 - t) * np.exp(self.min_sigma))
+
+    def t_to_idx(self, t):
+        return np.digitize(self.sigma(t), self.discrete_sigma) - 1
+
+    def marginal_b_t(self, t):
+        return t * self.min_b + 0.5 * (t ** 2) * (self.max_b - self.min_b)
+
+
+def igso3_score_torch(sched, vec, t, L=1000, eps=1e-6):
+    """SO3Diffuser.torch_score so3_diffuser.py:274-305 with use_cached_score=False
+    -> igso3_expansion :9-49 and score :71-117.  Reproduces the reference's mixed
+    precision: omega and the trig terms stay in vec.dtype (fp32), the Gaussian
+    envelope is float64 (sigma comes from numpy), the product promotes to float64."""
+    t_np = np.asarray(t.detach().cpu().numpy())
+    sigma = torch.tensor(sched.discrete_sigma[sched.t_to_idx(t_np)])      # float64 [1]
+    omega = torch.linalg.norm(vec, dim=-1) + eps                           # [F,N]
+    ls = torch.arange(L)
+    om = omega[..., None]
+    sg = sigma[:, None][..., None]                                         # [1,1,1]
+    env = (2 * ls + 1) * torch.exp(-ls * (ls + 1) * sg ** 2 / 2)           # float64
+    lo = torch.sin(om / 2)
+    hi = torch.sin(om * (ls + 1 / 2))
+    f = (env * hi / lo).sum(-1)
+    dhi = (ls + 1 / 2) * torch.cos(om * (ls + 1 / 2))
+    dlo = 1 / 2 * torch.cos(om / 2)
+    dsig = (env * (lo * dhi - hi * dlo) / lo ** 2).sum(-1)
+    sc = dsig / (f + 1e-4)
+    return sc[..., None] * vec / (omega[..., None] + eps)
+
+
+def calc_rot_score(sched, quats_t, quats_0, t):
+    """SE3Diffuser.calc_rot_score src/data/se3_diffuser.py:119-125."""
+    q0t = quat_mul(quat_invert(quats_0), quats_t)
+    return igso3_score_torch(sched, quat_to_rotvec(q0t), t)
+
+
+def calc_trans_score(sched, x_t, x_0, t):
+    """R3Diffuser.score (use_torch, scale=True) r3_diffuser.py:169-177; t is a tensor
+    broadcastable against [F,N,3]."""
+    x_t, x_0 = x_t * sched.cs, x_0 * sched.cs
+    bt = sched.marginal_b_t(t)
+    return -(x_t - torch.exp(-0.5 * bt) * x_0) / (1 - torch.exp(-bt))
+
+
+# ----------------------------------------------------------------------------
+# frames -> atoms   (openfold/utils/feats.py:165-228, src/data/all_atom.py:114-154,
+#                    src/model/Dfold_network_dynamic.py:574-594)
+# ----------------------------------------------------------------------------
+
+_TABLES = None
+
+
+def residue_tables():
+    global _TABLES
+    if _TABLES is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dynamicpdb_amd",
+                            "data", "residue_tables.npz")
+        d = np.load(path)
+        _TABLES = {k: torch.tensor(d[k]) for k in d.files}
+    return _TABLES
+
+
+def _compose(Ra, ta, Rb, tb):
+    return Ra @ Rb, rot_apply(Ra, tb) + ta
+
+
+def frames_to_atoms(t7, angles, aatype):
+    """t7[F,N,7] (unit quats), angles[F,N,7,2] (sin,cos), aatype[F,N] int64 ->
+    atom14[F,N,14,3], atom37[F,N,37,3]."""
+    T = residue_tables()
+    dt = t7.dtype
+    d44 = T["default_frames"][aatype].to(dt)                         # [F,N,8,4,4]
+    Rd, td = d44[..., :3, :3], d44[..., :3, 3]
+    bb = torch.zeros(angles.shape[:-2] + (1, 2), dtype=dt)
+    bb[..., 1] = 1
+    al = torch.cat([bb, angles], -2)                                 # [F,N,8,2]
+    Rt = torch.zeros(al.shape[:-1] + (3, 3), dtype=dt)
+    Rt[..., 0, 0] = 1
+    Rt[..., 1, 1] = al[..., 1]
+    Rt[..., 1, 2] = -al[..., 0]
+    Rt[..., 2, 1] = al[..., 0]
+    Rt[..., 2, 2] = al[..., 1]
+    Rf, tf = Rd @ Rt, td                                             # default_r.compose(all_rots) (trans None -> 0)
+    R_l, t_l = [Rf[..., i, :, :] for i in range(8)], [tf[..., i, :] for i in range(8)]
+    for i in (5, 6, 7):                                              # chi2..4 chained onto chi1
+        R_l[i], t_l[i] = _compose(R_l[i - 1], t_l[i - 1], R_l[i], t_l[i])
+    Rb, tb = torch.stack(R_l, -3), torch.stack(t_l, -2)              # [F,N,8,3,3],[F,N,8,3]
+    Rg = quat_to_rotmat(t7[..., :4])[..., None, :, :]
+    Rall, tall = Rg @ Rb, rot_apply(Rg, tb) + t7[..., None, 4:]
+    grp = T["atom14_group"][aatype]                                  # [F,N,14]
+    idx = grp[..., None, None].expand(grp.shape + (3, 3))
+    Ra = torch.gather(Rall, -3, idx)
+    ta = torch.gather(tall, -2, grp[..., None].expand(grp.shape + (3,)))
+    pos = rot_apply(Ra, T["atom14_pos"][aatype].to(dt)) + ta
+    atom14 = pos * T["atom14_mask"][aatype].to(dt)[..., None]
+    i37 = T["atom37_to_atom14"][aatype]                              # [F,N,37]
+    atom37 = torch.gather(atom14, -2, i37[..., None].expand(i37.shape + (3,)))
+    atom37 = atom37 * T["atom37_mask"][aatype].to(dt)[..., None]
+    return atom14, atom37
+
+
+# ----------------------------------------------------------------------------
+# DFOLDIpaScore + FullScoreNetwork
+# ----------------------------------------------------------------------------
+
+
+def _shift_last(x):
+    """cat([x[:-1], x[-2:-1]]) -- history + copy of frame F-2 as the guess for F-1
+    (ipa_pytorch_dynamic.py:819,822,826,842)."""
+    return torch.cat([x[:-1], x[-2:-1]], 0)
+
+
+def full_score_network(P, sched, feats, dtype=torch.float32, num_blocks=4, return_intermediates=False):
+    """FullScoreNetwork.forward Dfold_network_dynamic.py:450-546 + DFOLDIpaScore.forward
+    ipa_pytorch_dynamic.py:798-907 for ONE window (leading axis = frames).
+    The dead DFOLDv2_Embeder branch (outputs unused) is not evaluated."""
+    c = lambda k: feats[k].to(dtype)
+    N = feats["node_repr"].shape[0]
+    node_repr = linear(P, "expand_node", c("node_repr"))                                  # :473
+    edge = linear(P, "expand_edge", c("edge_repr").reshape(N * N, -1)).reshape(N, N, -1)  # :474
+    S = "score_model."
+    node_mask = c("res_mask")
+    diffuse_mask = (1 - c("fixed_mask")) * node_mask
+    rig0 = c("rigids_0")
+    Fr = rig0.shape[0]
+    curr = _shift_last(rig0)
+    force_e = embedder(P, S + "force_embeder", _shift_last(c("force")))
+    vel_e = embedder(P, S + "vel_embeder", _shift_last(c("vel")))
+    idx_e = embedder(P, S + "index_embeder", feats["seq_idx"][0:1].unsqueeze(-1).to(dtype))
+    node_embed = idx_e.expand(Fr, -1, -1) + node_repr
+    ang = c("torsion_angles_sin_cos") * c("torsion_angles_mask").unsqueeze(-1)
+    ang_e = embedder(P, S + "angle_embeder", _shift_last(ang).reshape(Fr, N, 14))
+    inter = {}
+    node_feat = init_feat = upd = None
+    for b in range(num_blocks):
+        rig_e = embedder(P, S + "rigid_embeder", curr)
+        ipa_e = my_layer_norm(ipa(P, f"{S}trunk.ipa_{b}", node_embed, edge, curr, node_mask))
+        node_feat = convnet(P, S + "trunk.conv_0", torch.cat([rig_e, ipa_e, force_e, vel_e, ang_e], -1))
+        upd = linear(P, f"{S}trunk.bb_update_{b}.linear", node_feat)
+        upd = torch.cat([upd[:-1] * 0.0, upd[-1:]], 0)                                    # :869
+        curr = compose_q_update_vec(curr, upd, diffuse_mask[..., None])
+        if b == 0:
+            init_feat = node_feat
+        if return_intermediates:
+            inter[f"ipa_ln_{b}"], inter[f"node_feat_{b}"], inter[f"rigids_{b}"] = ipa_e, node_feat, curr
+    unorm, angles = angle_resnet(P, S + "angle_resnet", node_feat, init_feat)
+    rig_t = c("rigids_t")
+    rot_score = calc_rot_score(sched, rig_t[..., :4], curr[..., :4], feats["t"]) * node_mask[..., None]
+    tt = feats["t"].to(dtype)[:, None, None]
+    trans_score = calc_trans_score(sched, rig_t[..., 4:], curr[..., 4:], tt) * node_mask[..., None]
+    gt = c("torsion_angles_sin_cos")
+    fm = (1 - c("fixed_mask"))[..., None, None]
+    angles_out = fm * angles + (1 - fm) * gt                                              # :515-519
+    unorm_out = fm * unorm + (1 - fm) * gt
+    atom14, atom37 = frames_to_atoms(curr, angles_out, feats["aatype"].long())
+    out = dict(angles=angles_out, unorm_angles=unorm_out, rot_score=rot_score, trans_score=trans_score,
+               rigids=curr, atom37=atom37, atom14=atom14, rigid_update=upd)
+    if return_intermediates:
+        out["_inter"] = inter
+    return out
+
+
+# ----------------------------------------------------------------------------
+# training loss  (train_DFOLD_dynamics.py:1182-1400, openfold/utils/loss.py:52-76)
+# ----------------------------------------------------------------------------
+
+
+def torsion_angle_loss(a, a_gt, a_alt_gt, mask):
+    """openfold/utils/loss.py:52-76 (this fork: +1e-8 in the normalisation, masked
+    sum / (sum(mask)+1e-2), angle-norm weight 0.0) as used at train:1219-1224."""
+    norm = torch.linalg.norm(a, dim=-1)
+    a = a / (norm.unsqueeze(-1) + 1e-8)
+    d_gt = ((a - a_gt) ** 2).sum(-1)
+    d_alt = ((a - a_alt_gt) ** 2).sum(-1)
+    m = torch.minimum(d_gt, d_alt)
+    return (m * mask).sum(dim=(-1, -2)) / (mask.sum(dim=(-1, -2)) + 1e-2)
+
+
+def loss_fn(out, batch, trans_w=100.0, rot_w=7.0, torsion_w=1.0, rot_t_threshold=0.0):
+    """The three live terms of Experiment.loss_fn (last frame only, each repeated F
+    times; gate trans_loss<100) -> (scalar loss, aux dict)."""
+    dt = out["rigids"].dtype
+    bb_mask = batch["res_mask"].to(dt)
+    diffuse_mask = 1 - batch["fixed_mask"].to(dt)
+    loss_mask = bb_mask * diffuse_mask
+    Fr = bb_mask.shape[0]
+    tl = torsion_angle_loss(out["angles"], batch["torsion_angles_sin_cos"].to(dt),
+                            batch["alt_torsion_angles_sin_cos"].to(dt),
+                            batch["torsion_angles_mask"].to(dt)) * torsion_w
+    torsion = tl[-1:].repeat(Fr)
+    gt_x0, pr_x0 = batch["rigids_0"][..., 4:].to(dt), out["rigids"][..., 4:]
+    trans = ((gt_x0[-1:] - pr_x0[-1:]) ** 2).mean(dim=(-1, -2)).repeat(Fr) * trans_w
+    pr_rot = out["rot_score"] * diffuse_mask[..., None]
+    rot_mse = (batch["rot_score"] - pr_rot) ** 2 * loss_mask[..., None]
+    rot = (rot_mse / batch["rot_score_scaling"][:, None, None] ** 2).sum(dim=(-1, -2)) / (loss_mask.sum(-1) + 1e-10)
+    rot = rot * rot_w
+    rot = rot * (batch["t"] > rot_t_threshold)
+    rot = rot[-1:].repeat(Fr)
+    gate = (trans < 100.0)
+    rot = rot * gate.to(rot.dtype)
+    trans = trans * gate.to(trans.dtype)
+    torsion = torsion * (trans < 100.0).to(torsion.dtype)
+    final = rot + trans + torsion
+    bmask = torch.any(bb_mask > 0, dim=-1)
+    norm = lambda x: x.sum() / (bmask.sum() + 1e-10)
+    return norm(final), dict(rot_loss=norm(rot), trans_loss=norm(trans), torsion_loss=norm(torsion))
+
+
+# ----------------------------------------------------------------------------
+# triangle operators  (openfold/model/triangular_multiplicative_update.py:26-126,
+#                      openfold/model/triangular_attention.py:31-139, primitives.py:219-448)
+# ----------------------------------------------------------------------------
+
+
+def _ln(P, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"].to(x.dtype), P[name + ".bias"].to(x.dtype), eps)
+
+
+def triangle_multiplication(P, z, mask=None, outgoing=True):
+    """z[N,N,c_z] -> [N,N,c_z]; mask[N,N]."""
+    if mask is None:
+        mask = z.new_ones(z.shape[:-1])
+    m = mask[..., None]
+    zn = _ln(P, "layer_norm_in", z)
+    a = linear(P, "linear_a_p", zn) * torch.sigmoid(linear(P, "linear_a_g", zn)) * m
+    b = linear(P, "linear_b_p", zn) * torch.sigmoid(linear(P, "linear_b_g", zn)) * m
+    x = torch.einsum("ikc,jkc->ijc", a, b) if outgoing else torch.einsum("kic,kjc->ijc", a, b)
+    x = linear(P, "linear_z", _ln(P, "layer_norm_out", x))
+    return x * torch.sigmoid(linear(P, "linear_g", zn))
+
+
+def triangle_attention(P, x, mask=None, starting=True, no_heads=4, inf=1e9):
+    """x[I,J,c] -> [I,J,c]; gated MHA over each row with pair bias."""
+    if mask is None:
+        mask = x.new_ones(x.shape[:-1])
+    if not starting:
+        x, mask = x.transpose(0, 1), mask.transpose(0, 1)
+    I, J, _ = x.shape
+    xn = _ln(P, "layer_norm", x)
+    tri_bias = linear(P, "linear", xn).permute(2, 0, 1)                   # [H,I,J] -> bias over (q=I?) see below
+    H = no_heads
+    q = linear(P, "mha.linear_q", xn).reshape(I, J, H, -1)
+    k = linear(P, "mha.linear_k", xn).reshape(I, J, H, -1)
+    v = linear(P, "mha.linear_v", xn).reshape(I, J, H, -1)
+    ch = q.shape[-1]
+    q = q / math.sqrt(ch)
+    # logits[i,h,q,k] = q[i,q,h]·k[i,k,h] + mask_bias[i,k] + tri_bias[h,q,k]
+    a = torch.einsum("iqhc,ikhc->ihqk", q, k)
+    a = a + (inf * (mask - 1))[:, None, None, :] + tri_bias[None]
+    a = torch.softmax(a, -1)
+    o = torch.einsum("ihqk,ikhc->iqhc", a, v)
+    g = torch.sigmoid(linear(P, "mha.linear_g", xn)).reshape(I, J, H, -1)
+    o = linear(P, "mha.linear_o", (o * g).reshape(I, J, -1))
+    if not starting:
+        o = o.transpose(0, 1)
+    return o
+
+
+# ----------------------------------------------------------------------------
+# SE(3) noise / denoise with injected randomness
+# (src/data/se3_diffuser.py:43-110,160-215; so3_diffuser.py:311-365; r3_diffuser.py:81-157)
+# ----------------------------------------------------------------------------
+
+
+def rotvec_to_rotmat(v):
+    """Rodrigues; equals scipy Rotation.from_rotvec(v).as_matrix() (src/data/utils.py:191-192)."""
+    v = np.asarray(v, np.float64)
+    th = np.linalg.norm(v, axis=-1, keepdims=True)
+    small = th < 1e-12
+    k = v / np.where(small, 1.0, th)
+    K = np.zeros(v.shape[:-1] + (3, 3))
+    K[..., 0, 1], K[..., 0, 2] = -k[..., 2], k[..., 1]
+    K[..., 1, 0], K[..., 1, 2] = k[..., 2], -k[..., 0]
+    K[..., 2, 0], K[..., 2, 1] = -k[..., 1], k[..., 0]
+    s, c = np.sin(th)[..., None], np.cos(th)[..., None]
+    return np.eye(3) + s * K + (1 - c) * (K @ K)
+
+
+def rotmat_to_rotvec(R):
+    """Log map via quaternion (robust near pi); equals scipy as_rotvec up to fp rounding."""
+    from scipy.spatial.transform import Rotation
+    shp = R.shape[:-2]
+    return Rotation.from_matrix(R.reshape(-1, 3, 3)).as_rotvec().reshape(shp + (3,))
+
+
+def r3_reverse(sched, x_t, score_t, t, dt, z, center=True):
+    """R3Diffuser.reverse r3_diffuser.py:106-157 with the Gaussian draw z injected."""
+    x = x_t * sched.cs
+    b_t = sched.min_b + t * (sched.max_b - sched.min_b)
+    g = np.sqrt(b_t)
+    f = -0.5 * b_t * x
+    x1 = x - ((f - g ** 2 * score_t) * dt + g * np.sqrt(dt) * z)
+    if center:
+        x1 = x1 - x1.sum(-2, keepdims=True) / x1.shape[-2]
+    return x1 / sched.cs
+
+
+def so3_reverse(sched, rotvec_t, score_t, t, dt, z):
+    """SO3Diffuser.reverse so3_diffuser.py:329-365 (geodesic random walk, right-multiply)."""
+    sg = sched.sigma(t)
+    g = np.sqrt(2 * (np.exp(sched.max_sigma) - np.exp(sched.min_sigma)) * sg / np.exp(sg))
+    perturb = g ** 2 * score_t * dt + g * np.sqrt(dt) * z
+    R = rotvec_to_rotmat(rotvec_t) @ rotvec_to_rotmat(perturb)
+    return rotmat_to_rotvec(R)

@@ -1,0 +1,186 @@
+"""Mint golden vectors from the REFERENCE's own code (run in the build container only;
+needs /root/reference).  Usage:  python tests/golden/make_golden.py
+
+Writes small .npz fixtures next to this file.  Weights are NOT stored: they are
+regenerated bit-identically from dynamicpdb_amd.synthetic.seeded_state_dict(seed)
+(numpy Generator, same image on the GPU box); loading them into the reference model
+with strict=True is itself the state_dict-compatibility check.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_harness"))
+import ref_import  # noqa: E402
+
+ref_import.install()
+os.chdir(os.environ.get("DFOLD_GOLDEN_WORKDIR", "/tmp/work"))
+
+from dynamicpdb_amd import synthetic  # noqa: E402
+from dynamicpdb_amd.rigid import Rigid  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def np_(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def subsample(g, stride=9973):
+    flat = g.reshape(-1)
+    return flat[::stride].clone()
+
+
+def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5):
+    from src.data.se3_diffuser import SE3Diffuser
+    import train_DFOLD_dynamics as T
+    conf = ref_import.make_conf(F, cache_dir=".cache/")
+    exp = T.Experiment(conf=conf)
+    model = exp.model
+    sd = synthetic.seeded_state_dict(seed_w)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    diffuser = exp.diffuser
+    win = synthetic.synthetic_window(seed_x, F, N, t=t, diffuser=diffuser)
+    batch = {k: v.clone() for k, v in win.items()}
+    # per-op captures through forward hooks on the reference modules
+    cap = {}
+    sm = model.score_model
+    hooks = []
+    def grab(name, first_only=False):
+        def h(mod, inp, out):
+            if first_only and name in cap:
+                return
+            cap[name] = out.detach().clone()
+        return h
+    for b in range(4):
+        hooks.append(sm.trunk[f"ipa_{b}"].register_forward_hook(grab(f"ipa_{b}")))
+        hooks.append(sm.trunk[f"ln_{b}"].register_forward_hook(grab(f"ipa_ln_{b}")))
+    conv_calls = []
+    hooks.append(sm.trunk["conv_0"].register_forward_hook(lambda m, i, o: conv_calls.append((i[0].detach().clone(), o.detach().clone()))))
+    hooks.append(sm.force_embeder.register_forward_hook(grab("force_embed")))
+    hooks.append(sm.rigid_embeder.register_forward_hook(grab("rigid_embed_0", first_only=True)))
+    random.seed(0)   # loss_fn flips a coin for the (output-irrelevant) self-conditioning pass
+    model.zero_grad()
+    loss, aux = exp.loss_fn(batch)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        out = model({k: v.clone() for k, v in win.items()})
+    fix = {f"in_{k}": np_(v) for k, v in win.items()}
+    for k in ("angles", "unorm_angles", "rot_score", "trans_score", "rigids", "atom37", "atom14", "rigid_update"):
+        fix[f"out_{k}"] = np_(out[k])
+    for k, v in cap.items():
+        fix[f"cap_{k}"] = np_(v)
+    for i, (ci, co) in enumerate(conv_calls[:4]):
+        fix[f"cap_conv_in_{i}"] = np_(ci)
+        fix[f"cap_conv_out_{i}"] = np_(co)
+    fix["loss"] = np_(loss)
+    for k, v in aux.items():
+        if k in ("rot_loss", "trans_loss", "torsion_loss", "total_loss"):
+            fix[f"aux_{k}"] = np_(v)
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            fix[f"gradnone_{name}"] = np.zeros(1)
+            continue
+        g = p.grad
+        fix[f"gnorm_{name}"] = np_(g.double().norm())
+        fix[f"gsub_{name}"] = np_(subsample(g) if g.numel() > 70000 else g)
+    fix["meta"] = np.array([F, N, seed_w, seed_x], np.int64)
+    np.savez_compressed(os.path.join(HERE, f"network_F{F}_N{N}.npz"), **fix)
+    print("network golden: loss", float(loss), {k: float(v) for k, v in aux.items() if "batch" not in k})
+    return exp
+
+
+def golden_triangle(N=24, seed=3):
+    from openfold.model.triangular_multiplicative_update import (TriangleMultiplicationIncoming,
+                                                                  TriangleMultiplicationOutgoing)
+    from openfold.model.triangular_attention import TriangleAttentionEndingNode, TriangleAttentionStartingNode
+    rng = np.random.default_rng(seed)
+    fix = {}
+    z = torch.tensor(rng.standard_normal((N, N, 128), dtype=np.float32))
+    mask = torch.tensor((rng.uniform(size=(N, N)) > 0.1).astype(np.float32))
+    fix["z"], fix["mask"] = np_(z), np_(mask)
+    mods = dict(tri_mul_out=TriangleMultiplicationOutgoing(128, 128), tri_mul_in=TriangleMultiplicationIncoming(128, 128),
+                tri_att_start=TriangleAttentionStartingNode(128, 32, 4), tri_att_end=TriangleAttentionEndingNode(128, 32, 4))
+    for name, m in mods.items():
+        sd = m.state_dict()
+        for i, (k, v) in enumerate(sd.items()):
+            if v.dim() >= 2:
+                w = rng.standard_normal(tuple(v.shape), dtype=np.float32) / np.sqrt(v.shape[-1])
+            elif k.endswith("weight"):
+                w = 1.0 + 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+            else:
+                w = 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+            sd[k] = torch.tensor(w.astype(np.float32))
+            fix[f"{name}.P.{k}"] = w.astype(np.float32)
+        m.load_state_dict(sd)
+        zz = z.clone().requires_grad_(True)
+        y = m(zz, mask=mask)
+        gy = torch.tensor(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+        y.backward(gy)
+        fix[f"{name}.out"], fix[f"{name}.gy"], fix[f"{name}.gz"] = np_(y), np_(gy), np_(zz.grad)
+        for k, p in m.named_parameters():
+            fix[f"{name}.G.{k}"] = np_(p.grad)
+    np.savez_compressed(os.path.join(HERE, f"triangle_N{N}.npz"), **fix)
+    print("triangle golden written")
+
+
+def golden_diffuser(exp, F=3, N=16):
+    d = exp.diffuser
+    so3, r3 = d._so3_diffuser, d._r3_diffuser
+    fix = {}
+    ts = np.array([0.01, 0.1, 0.25, 0.5, 0.77, 1.0])
+    fix["ts"] = ts
+    fix["t_to_idx"] = np.array([so3.t_to_idx(t) for t in ts])
+    fix["sigma"] = np.array([so3.sigma(t) for t in ts])
+    fix["so3_score_scaling"] = np.array([so3.score_scaling(t) for t in ts])
+    fix["r3_score_scaling"] = np.array([r3.score_scaling(t) for t in ts])
+    fix["so3_diffusion_coef"] = np.array([so3.diffusion_coef(t) for t in ts])
+    sl = (slice(None, None, 37), slice(None, None, 41))
+    fix["pdf_sub"], fix["cdf_sub"], fix["score_norms_sub"] = so3._pdf[sl], so3._cdf[sl], so3._score_norms[sl]
+    fix["score_scaling_full"] = so3._score_scaling
+    win = synthetic.synthetic_window(5, F, N)
+    r0 = win["rigids_0"]
+    fix["rigids_0"] = np_(r0)
+    for i, t in enumerate((0.05, 0.5, 0.9)):
+        np.random.seed(100 + i)
+        fm = d.forward_marginal(Rigid.from_tensor_7(r0), float(t))
+        for k, v in fm.items():
+            fix[f"fm{i}_{k}"] = np_(v)
+        # torch_score on the sampled geometry (fp32 quats in, mixed precision series)
+        q_t = fm["rigids_t"][..., :4]
+        rs = d.calc_rot_score(Rigid.from_tensor_7(fm["rigids_t"]).get_rots(), Rigid.from_tensor_7(r0).get_rots(),
+                              torch.tensor([t], dtype=torch.float32))
+        fix[f"fm{i}_calc_rot_score"] = np_(rs)
+        tsq = d.calc_trans_score(fm["rigids_t"][..., 4:], r0[..., 4:], torch.tensor([t], dtype=torch.float32)[:, None, None], use_torch=True)
+        fix[f"fm{i}_calc_trans_score"] = np_(tsq)
+        # one reverse step with the draws recorded
+        rng_state = 200 + i
+        rot_score = np.asarray(fm["rot_score"]); trans_score = np.asarray(fm["trans_score"])
+        np.random.seed(rng_state)
+        z_rot = np.random.normal(size=rot_score.shape)      # so3.reverse draws first (se3_diffuser.py:184-190)
+        z_trans = np.random.normal(size=trans_score.shape)  # then r3.reverse
+        np.random.seed(rng_state)
+        rig_prev = d.reverse(Rigid.from_tensor_7(fm["rigids_t"]), rot_score, trans_score, float(t), 0.1,
+                             diffuse_mask=None, center=True, noise_scale=0.5)
+        fix[f"rev{i}_z_rot"], fix[f"rev{i}_z_trans"] = z_rot, z_trans
+        fix[f"rev{i}_rot_mats"] = np_(rig_prev.get_rots().get_rot_mats())
+        fix[f"rev{i}_trans"] = np_(rig_prev.get_trans())
+    np.random.seed(7)
+    fix["sample_ref"] = np_(d.sample_ref(n_samples=F * N, as_tensor_7=True)["rigids_t"])
+    np.savez_compressed(os.path.join(HERE, "diffuser.npz"), **fix)
+    print("diffuser golden written")
+
+
+if __name__ == "__main__":
+    exp = golden_network()
+    golden_diffuser(exp)
+    golden_triangle()
