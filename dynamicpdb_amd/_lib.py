@@ -1,0 +1,70 @@
+"""ctypes binding of the C-ABI library (include/dfold_hip.h).  The library is loaded lazily on first
+device op; a missing library is a hard error -- the device path has no CPU / eager fallback."""
+import ctypes
+import os
+import re
+from ctypes import POINTER, Structure, byref, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdfold_hip.so")
+HEADER = os.path.join(_HERE, "..", "include", "dfold_hip.h")
+
+_lib = None
+
+
+class RowMap(Structure):
+    _fields_ = [("base", c_int64), ("ld", c_int64), ("mode", c_int32), ("n", c_int32), ("f", c_int32),
+                ("fp", c_int32), ("wp", c_int32)]
+
+
+class GemmDesc(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p),
+                ("R", c_void_p), ("R2", c_void_p), ("zeros", c_void_p), ("a_seg_off", c_void_p),
+                ("b_seg_off", c_void_p), ("a_rows", RowMap), ("c_rows", RowMap), ("ldb", c_int64),
+                ("sa0", c_int64), ("sa1", c_int64), ("sb0", c_int64), ("sb1", c_int64), ("sc0", c_int64),
+                ("sc1", c_int64), ("M", c_int32), ("N", c_int32), ("nseg", c_int32), ("seglen", c_int32),
+                ("nbatch", c_int32), ("nb1", c_int32), ("flags", c_int32), ("alpha", c_float)]
+
+
+GEMM_BIAS, GEMM_RELU, GEMM_RESID, GEMM_RELUMASK, GEMM_OUT_BF16, GEMM_ACCUM = 1, 2, 4, 8, 16, 32
+
+
+def header_symbols():
+    """Every entry point declared in include/dfold_hip.h."""
+    with open(HEADER) as fh:
+        txt = fh.read()
+    return sorted(set(re.findall(r"^\s*int\s+(dfold_\w+)\s*\(", txt, flags=re.M)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m dynamicpdb_amd.build_ext` "
+                "(the MI355X device path has no fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name in header_symbols():
+            fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = c_int32
+        if L.dfold_abi_version() != 1:
+            raise RuntimeError("libdfold_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError(f"{what}: invalid argument (DFOLD_EINVAL)")
+    raise RuntimeError(f"{what}: kernel launch failed (rc={rc})")
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

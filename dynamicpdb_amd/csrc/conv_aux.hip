@@ -1,0 +1,254 @@
+// Layout / reduction helpers around the implicit-GEMM conv tower (reference ConvNet,
+// src/model/ipa_pytorch_dynamic.py:664-706).  All HBM-bound; 16-B vector access where the layout allows.
+#include "dfold_common.h"
+#include "../../include/dfold_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast (n multiple of 4 handled vectorised, tail scalar)
+// ---------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *(const float4*)(src + i);
+    uint2 o;
+    o.x = pack2bf(v.x, v.y);
+    o.y = pack2bf(v.z, v.w);
+    *(uint2*)(dst + i) = o;
+  }
+  if (i < n && i + 3 >= n)
+    for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+}
+
+extern "C" int dfold_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0) return DFOLD_EINVAL;
+  if (n == 0) return DFOLD_OK;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return DFOLD_EINVAL;
+  long blocks = (n / 4 + 255) / 256 + 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, (long)n);
+  return dfold_check_launch();
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = bf2f(src[i]);
+}
+
+extern "C" int dfold_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0) return DFOLD_EINVAL;
+  if (n == 0) return DFOLD_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, dst, (long)n);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Conv weight pack: W fp32 [CO][CI][5][5] (reference OIHW) ->
+//   Wf bf16 [CO][25][CI]          forward implicit-GEMM B operand
+//   Wd bf16 [CI][25][CO], tap-flipped: Wd[ci][t][co] = W[co][ci][24-t]   dgrad B operand
+// One block = 32 co x 32 ci through LDS (bf16, 25 taps).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wf,
+                                                               bf16_t* __restrict__ Wd, int CO, int CI) {
+  __shared__ bf16_t t[32][32][26];
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  // load: for each co row, 32 ci x 25 taps = 800 contiguous floats
+  for (int r = 0; r < 32; ++r) {
+    const int co = co0 + r;
+    if (co >= CO) break;
+    const float* src = W + ((long)co * CI + ci0) * 25;
+    const int lim = min(32, CI - ci0) * 25;
+    for (int e = threadIdx.x; e < lim; e += 256) t[r][e / 25][e % 25] = f2bf(src[e]);
+  }
+  __syncthreads();
+  // Wf rows (co, tap): 32 contiguous ci
+  for (int e = threadIdx.x; e < 32 * 25 * 32; e += 256) {
+    const int ci = e & 31, tap = (e >> 5) % 25, r = e / (32 * 25);
+    if (co0 + r < CO && ci0 + ci < CI) Wf[((long)(co0 + r) * 25 + tap) * CI + ci0 + ci] = t[r][ci][tap];
+  }
+  // Wd rows (ci, tap'): 32 contiguous co
+  for (int e = threadIdx.x; e < 32 * 25 * 32; e += 256) {
+    const int r = e & 31, tap = (e >> 5) % 25, ci = e / (32 * 25);
+    if (co0 + r < CO && ci0 + ci < CI) Wd[((long)(ci0 + ci) * 25 + tap) * CO + co0 + r] = t[r][ci][24 - tap];
+  }
+}
+
+extern "C" int dfold_conv_weight_pack(const float* W, void* Wf, void* Wd, int32_t CO, int32_t CI, void* stream) {
+  if (!W || !Wf || !Wd || CO <= 0 || CI <= 0) return DFOLD_EINVAL;
+  dim3 grid((CI + 31) / 32, (CO + 31) / 32);
+  hipLaunchKernelGGL(conv_weight_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)Wf, (bf16_t*)Wd,
+                     CO, CI);
+  return dfold_check_launch();
+}
+
+// dWg fp32 [CO][25][CI] (GEMM layout) -> G fp32 [CO][CI][25] (reference layout); accumulate != 0 adds.
+__global__ __launch_bounds__(256) void conv_wgrad_unpack_kernel(const float* __restrict__ dWg, float* __restrict__ G,
+                                                                int CO, int CI, int accumulate) {
+  __shared__ float t[25][65];
+  const int co = blockIdx.y, ci0 = blockIdx.x * 64;
+  const int w = min(64, CI - ci0);
+  for (int e = threadIdx.x; e < 25 * 64; e += 256) {
+    const int ci = e & 63, tap = e >> 6;
+    if (ci < w) t[tap][ci] = dWg[((long)co * 25 + tap) * CI + ci0 + ci];
+  }
+  __syncthreads();
+  float* dst = G + ((long)co * CI + ci0) * 25;
+  for (int e = threadIdx.x; e < w * 25; e += 256) {
+    const float v = t[e % 25][e / 25];
+    dst[e] = accumulate ? dst[e] + v : v;
+  }
+}
+
+extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, int32_t accumulate,
+                                       void* stream) {
+  if (!dWg || !G || CO <= 0 || CI <= 0) return DFOLD_EINVAL;
+  dim3 grid((CI + 63) / 64, CO);
+  hipLaunchKernelGGL(conv_wgrad_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed, column-shifted copies of a padded grid tensor for the conv wgrad:
+//   X bf16 [W][Fp][Wp][C]  ->  T bf16 [nd][C][W][Fp][N],  T[d][c][w][f][n] = X[w][f][n + d0 + d][c]
+// block = (n tile of 64, c tile of 64, (w,f) row)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ T,
+                                                                   int Wn, int Fp, int Wp, int C, int N, int d0,
+                                                                   int nd) {
+  __shared__ bf16_t t[68][66];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int wf = blockIdx.z;  // w*Fp + f
+  const int cols = min(64 + nd - 1, Wp - (n0 + d0));  // padded columns available from n0+d0
+  const int cw = min(64, C - c0);
+  const bf16_t* src = X + ((long)wf * Wp + n0 + d0) * C + c0;
+  // 8 bf16 (16 B) per thread per row when the c tile is full and aligned
+  for (int e = threadIdx.x; e < 68 * 8; e += 256) {
+    const int col = e >> 3, cc = (e & 7) * 8;
+    if (col < cols) {
+      if (cw == 64 && (C & 7) == 0) {
+        const uint4 v = *(const uint4*)(src + (long)col * C + cc);
+        const bf16_t* pv = (const bf16_t*)&v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[col][cc + j] = pv[j];
+      } else {
+        for (int j = 0; j < 8; ++j)
+          if (cc + j < cw) t[col][cc + j] = src[(long)col * C + cc + j];
+      }
+    }
+  }
+  __syncthreads();
+  const long plane = (long)Wn * Fp * N;  // elements per (d, c)
+  const int nw = min(64, N - n0);
+  for (int d = 0; d < nd; ++d) {
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int n = e & 63, c = e >> 6;
+      if (n < nw && c < cw) T[((long)d * C + c0 + c) * plane + (long)wf * N + n0 + n] = t[n + d][c];
+    }
+  }
+}
+
+extern "C" int dfold_grid_transpose_shift(const void* X, void* T, int32_t Wn, int32_t Fp, int32_t Wp, int32_t C,
+                                          int32_t N, int32_t d0, int32_t nd, void* stream) {
+  if (!X || !T || Wn <= 0 || Fp <= 0 || Wp <= 0 || C <= 0 || N <= 0 || nd <= 0 || nd > 5 || d0 < 0) return DFOLD_EINVAL;
+  if (N + d0 + nd - 1 > Wp) return DFOLD_EINVAL;
+  dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * Fp);
+  hipLaunchKernelGGL(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
+                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums of a bf16 [R][C] matrix into fp32 [C] (bias gradients); out must be zeroed (or hold the
+// running sum) by the caller: partial sums are added atomically.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, float* __restrict__ out, long R,
+                                                          int C, long ld) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + rl; r < r1; r += 4) s += bf2f(X[r * ld + c]);
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+extern "C" int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream) {
+  if (!X || !out || R <= 0 || C <= 0 || ld < C) return DFOLD_EINVAL;
+  long chunks = (R + 511) / 512;
+  if (chunks > 1024) chunks = 1024;
+  dim3 grid((C + 63) / 64, (unsigned)chunks);
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, out, (long)R, C,
+                     (long)ld);
+  return dfold_check_launch();
+}
+
+// out = (v > 0) ? g : 0   (ReLU backward on bf16 tensors; n multiple of 8 fast path)
+__global__ void relu_mask_bf16_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                      long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (; i + 7 < n; i += stride) {
+    uint4 a = *(const uint4*)(g + i);
+    const uint4 b = *(const uint4*)(v + i);
+    bf16_t* pa = (bf16_t*)&a;
+    const bf16_t* pb = (const bf16_t*)&b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pa[j] = bf2f(pb[j]) > 0.f ? pa[j] : (bf16_t)0;
+    *(uint4*)(out + i) = a;
+  }
+  if (i < n)
+    for (long j = i; j < n; ++j) out[j] = bf2f(v[j]) > 0.f ? g[j] : (bf16_t)0;
+}
+
+extern "C" int dfold_relu_mask_bf16(const void* g, const void* v, void* out, int64_t n, void* stream) {
+  if (!g || !v || !out || n < 0) return DFOLD_EINVAL;
+  if (n == 0) return DFOLD_OK;
+  long blocks = (n / 8 + 255) / 256 + 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(relu_mask_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+                     (const bf16_t*)v, (bf16_t*)out, (long)n);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched 2-D transpose of bf16 matrices: dst[b][c][r] = src[b][r][c]
+//   src row stride lds_, batch stride sbs; dst row stride ldd, batch stride sbd (elements).
+// 64x64 tiles through LDS; reads and writes both coalesced along their contiguous axis.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             int R, int C, long lds_, long ldd, long sbs, long sbd) {
+  __shared__ bf16_t t[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* s = src + (long)blockIdx.z * sbs;
+  bf16_t* d = dst + (long)blockIdx.z * sbd;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e & 63, r = e >> 6;
+    if (r0 + r < R && c0 + c < C) t[r][c] = s[(long)(r0 + r) * lds_ + c0 + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    if (r0 + r < R && c0 + c < C) d[(long)(c0 + c) * ldd + r0 + r] = t[r][c];
+  }
+}
+
+extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst,
+                                    int32_t nbatch, int64_t bs_src, int64_t bs_dst, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || nbatch <= 0 || ld_src < C || ld_dst < R) return DFOLD_EINVAL;
+  if (nbatch > 65535) return DFOLD_EINVAL;
+  dim3 grid((C + 63) / 64, (R + 63) / 64, nbatch);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
+                     C, (long)ld_src, (long)ld_dst, (long)bs_src, (long)bs_dst);
+  return dfold_check_launch();
+}
+
+extern "C" int dfold_abi_version(void) { return DFOLD_ABI_VERSION; }

@@ -1,0 +1,64 @@
+// Shared device helpers for the DFOLDv2 gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all bf16 tensors cross the C ABI as uint16_t*
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DFOLD_OK 0
+#define DFOLD_EINVAL (-1)
+#define DFOLD_ELAUNCH (-2)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Row map: logical GEMM row m -> element offset of that row in a tensor.
+//   mode 0: base + m*ld
+//   mode 1: frame x residue grid stored zero-padded for the 5x5 conv tower:
+//           m = (w*F + f)*N + n  ->  base + (((w*Fp + f)*Wp) + n)*ld   (ld = channels)
+struct RowMap {
+  long base;
+  long ld;
+  int mode, n, f, fp, wp;
+};
+__device__ __forceinline__ long row_off(const RowMap& r, long m) {
+  if (r.mode == 0) return r.base + m * r.ld;
+  long wf = m / r.n;
+  int n = (int)(m - wf * r.n);
+  long w = wf / r.f;
+  int f = (int)(wf - w * r.f);
+  return r.base + (((w * r.fp + f) * r.wp) + n) * r.ld;
+}
+
+static inline int dfold_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DFOLD_OK : DFOLD_ELAUNCH;
+}

@@ -1,0 +1,197 @@
+// bf16 MFMA GEMM / implicit-GEMM engine for gfx950 (MI355X).
+//
+//   C[m, n] = epilogue( alpha * sum_k A[row(m), k] * B[n, k] )        ("NT": both operands K-contiguous)
+//
+// One kernel serves every dense contraction of the DFOLDv2 hot path:
+//   * the 5x5 conv tower (reference src/model/ipa_pytorch_dynamic.py:664-706) as an implicit GEMM over
+//     the zero-padded channels-last [window, frame+4, residue+4, C] activation grid: K is split into 25
+//     tap segments, each adding a constant element offset to the gathered A row (no im2col, no bounds
+//     checks: the border of the grid is zero) -- forward and dgrad (flipped/transposed weights);
+//   * its wgrad (K = frames x residues, per-window segments over transposed activations);
+//   * all nn.Linear layers of IPA / AngleResnet / embedders / triangle ops, forward and backward;
+//   * batched attention products (two-level batch strides).
+//
+// Structure: 128x128x64 tile, 4 waves (2x2), each wave 2x2 v_mfma_f32_32x32x16_bf16 tiles (fp32
+// accumulate); operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+// buffered, one barrier per K step; LDS rows are 128 B with a 16-B-chunk XOR swizzle applied on the
+// *source* address (the LDS-DMA image is lane-linear) and on the ds_read_b128 side, which makes the
+// fragment reads bank-conflict free; the blockIdx -> tile map is XCD-aware (tiles that share an A row
+// panel sit on one XCD's L2).
+#include "dfold_common.h"
+#include "../../include/dfold_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const bf16_t* R;
+  const bf16_t* R2;
+  const bf16_t* zeros;
+  const long* a_seg_off;
+  const long* b_seg_off;
+  RowMap am, cm;
+  long ldb;
+  long sa0, sa1, sb0, sb1, sc0, sc1;
+  int M, N, nseg, seglen, nb1, flags;
+  float alpha;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];  // [buf][A|B][128 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  // ---- XCD-aware tile id (bijective for any grid size) ----
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+  const bf16_t* A = p.A + z0 * p.sa0 + z1 * p.sa1;
+  const bf16_t* B = p.B + z0 * p.sb0 + z1 * p.sb1;
+  const long coff = z0 * p.sc0 + z1 * p.sc1;
+
+  // ---- staging assignment: wave w, pass t covers tile rows (t*4+w)*8 .. +8, lane -> (row, 16-B chunk) ----
+  const int cphys = lane & 7;
+  const int rsub = lane >> 3;
+  const int clog = cphys ^ ((((w & 1) << 2) + (lane >> 4)) & 7);  // logical k-chunk this lane fetches
+  const int kofs = clog * 8;
+  const bf16_t* arow[4];
+  const bf16_t* brow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = (t * 4 + w) * 8 + rsub;
+    const long m = (long)m0 + r;
+    arow[t] = m < p.M ? A + row_off(p.am, m) + kofs : nullptr;
+    const long n = (long)n0 + r;
+    brow[t] = n < p.N ? B + n * p.ldb + kofs : nullptr;
+  }
+  const int sps = (p.seglen + BK - 1) / BK;  // K steps per segment
+  const int nsteps = p.nseg * sps;
+
+  auto stage = [&](int buf, int step) {
+    const int seg = step / sps;
+    const int kk = (step - seg * sps) * BK;
+    const long ao = (p.a_seg_off ? p.a_seg_off[seg] : (long)seg * p.seglen) + kk;
+    const long bo = (p.b_seg_off ? p.b_seg_off[seg] : (long)seg * p.seglen) + kk;
+    const bool kin = (kk + kofs) < p.seglen;
+    char* la = lds + buf * 2 * TILE_BYTES;
+    char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16_t* sa = (arow[t] != nullptr && kin) ? arow[t] + ao : p.zeros;
+      __builtin_amdgcn_global_load_lds((const void*)sa, (lds_ptr_t)(la + (t * 4 + w) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16_t* sb = (brow[t] != nullptr && kin) ? brow[t] + bo : p.zeros;
+      __builtin_amdgcn_global_load_lds((const void*)sb, (lds_ptr_t)(lb + (t * 4 + w) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (lane >> 1) & 7;  // swizzle key of this lane's fragment rows ((row>>1)&7, row = 32*x + frow)
+  const int fhalf = lane >> 5;
+
+  stage(0, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nsteps) stage((s + 1) & 1, s + 1);
+    const char* la = lds + (s & 1) * 2 * TILE_BYTES;
+    const char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(la + (wm * 64 + i * 32 + frow) * 128 + ch);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(lb + (wn * 64 + j * 32 + frow) * 128 + ch);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+  const int fl = p.flags;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long m = (long)m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+      if (m >= p.M) continue;
+      const long ro = row_off(p.cm, m) + coff;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + frow;
+        if (n >= p.N) continue;
+        float v = acc[i][j][e] * p.alpha;
+        const long off = ro + n;
+        if (fl & DFOLD_GEMM_BIAS) v += p.bias[n];
+        if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (p.C2 != nullptr && p.R2 == nullptr) ((bf16_t*)p.C2)[off] = f2bf(v);
+        if (fl & DFOLD_GEMM_RESID) v += bf2f(p.R[off]);
+        if (fl & DFOLD_GEMM_RELUMASK) v = bf2f(p.R[off]) > 0.f ? v : 0.f;
+        if (fl & DFOLD_GEMM_OUT_BF16) {
+          ((bf16_t*)p.C)[off] = f2bf(v);
+        } else {
+          if (fl & DFOLD_GEMM_ACCUM) v += ((float*)p.C)[off];
+          ((float*)p.C)[off] = v;
+        }
+        if (p.C2 != nullptr && p.R2 != nullptr) ((bf16_t*)p.C2)[off] = bf2f(p.R2[off]) > 0.f ? f2bf(v) : (bf16_t)0;
+      }
+    }
+  }
+}
+
+static RowMap to_rowmap(const dfold_rowmap* r) {
+  RowMap o;
+  o.base = r->base; o.ld = r->ld; o.mode = r->mode; o.n = r->n; o.f = r->f; o.fp = r->fp; o.wp = r->wp;
+  return o;
+}
+
+extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C || !d->zeros) return DFOLD_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->nseg <= 0 || d->seglen <= 0 || d->nbatch <= 0) return DFOLD_EINVAL;
+  if ((d->seglen & 7) || (d->ldb & 7) || (d->a_rows.ld & 7) || (d->a_rows.base & 7)) return DFOLD_EINVAL;  // 16-B chunks
+  if ((d->flags & DFOLD_GEMM_BIAS) && !d->bias) return DFOLD_EINVAL;
+  if ((d->flags & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) && !d->R) return DFOLD_EINVAL;
+  if ((d->flags & DFOLD_GEMM_ACCUM) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
+  if (d->a_rows.mode == 1 && (d->a_rows.n <= 0 || d->a_rows.f <= 0)) return DFOLD_EINVAL;
+  if (d->c_rows.mode == 1 && (d->c_rows.n <= 0 || d->c_rows.f <= 0)) return DFOLD_EINVAL;
+  GemmParams p;
+  p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.C2 = d->C2;
+  p.bias = d->bias; p.R = (const bf16_t*)d->R; p.R2 = (const bf16_t*)d->R2; p.zeros = (const bf16_t*)d->zeros;
+  p.a_seg_off = (const long*)d->a_seg_off; p.b_seg_off = (const long*)d->b_seg_off;
+  p.am = to_rowmap(&d->a_rows); p.cm = to_rowmap(&d->c_rows);
+  p.ldb = d->ldb;
+  p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
+  p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
+  p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
+  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  dim3 grid(tiles, d->nbatch, 1);
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return dfold_check_launch();
+}

@@ -1,0 +1,320 @@
+"""Thin Python launchers over the C ABI (include/dfold_hip.h).  Tensors are torch CUDA tensors used
+purely as device buffers; all arithmetic happens in libdfold_hip.so.  bf16 tensors are torch.bfloat16."""
+import ctypes
+from ctypes import byref, c_int32, c_int64, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import (GEMM_ACCUM, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU, GEMM_RELUMASK, GEMM_RESID, GemmDesc, RowMap,
+                   check, stream)
+
+BF16 = torch.bfloat16
+_zero_pages = {}
+_seg_tables = {}
+
+
+def zeros_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def _p(t, off=0):
+    """device pointer of tensor t advanced by `off` ELEMENTS (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def rows_plain(ld, base=0):
+    return RowMap(base, ld, 0, 0, 0, 0, 0)
+
+
+def rows_grid(C, N, F, Fp, Wp, base=0):
+    return RowMap(base, C, 1, N, F, Fp, Wp)
+
+
+def seg_table(values, device):
+    key = (tuple(values), device)
+    t = _seg_tables.get(key)
+    if t is None:
+        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        _seg_tables[key] = t
+    return t
+
+
+def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
+         a_seg_off=None, b_seg_off=None, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
+         a_off=0, b_off=0, c_off=0):
+    """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
+    assert A.dtype == BF16 and B.dtype == BF16
+    if C.dtype == BF16:
+        flags |= GEMM_OUT_BF16
+    else:
+        assert C.dtype == torch.float32
+    if bias is not None:
+        flags |= GEMM_BIAS
+        assert bias.dtype == torch.float32
+    d = GemmDesc()
+    d.A, d.B, d.C, d.C2 = _p(A, a_off), _p(B, b_off), _p(C, c_off), _p(C2, c_off)
+    d.bias, d.R, d.R2 = _p(bias), _p(R, c_off), _p(R2, c_off)
+    d.zeros = _p(zeros_page(A.device))
+    d.a_seg_off, d.b_seg_off = _p(a_seg_off), _p(b_seg_off)
+    d.a_rows, d.c_rows = a_rows, c_rows
+    d.ldb = ldb
+    d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
+    d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
+    check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
+    return C
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 copy (HIP kernel)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.lib().dfold_cast_f32_bf16(_p(x), _p(out), c_int64(x.numel()), stream()), "dfold_cast_f32_bf16")
+    return out
+
+
+def cast_f32(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().dfold_cast_bf16_f32(_p(x), _p(out), c_int64(x.numel()), stream()), "dfold_cast_bf16_f32")
+    return out
+
+
+def transpose_bf16(src, R, C, ld_src=None, out=None, nbatch=1, bs_src=0, bs_dst=0, ld_dst=None):
+    """dst[b][c][r] = src[b][r][c]"""
+    ld_src = C if ld_src is None else ld_src
+    ld_dst = R if ld_dst is None else ld_dst
+    if out is None:
+        out = torch.empty((nbatch, C, R) if nbatch > 1 else (C, R), dtype=BF16, device=src.device)
+        bs_dst = C * R
+    check(_lib.lib().dfold_transpose_bf16(_p(src), _p(out), c_int32(R), c_int32(C), c_int64(ld_src), c_int64(ld_dst),
+                                          c_int32(nbatch), c_int64(bs_src), c_int64(bs_dst), stream()),
+          "dfold_transpose_bf16")
+    return out
+
+
+def colsum_bf16(x, out, R, C, ld):
+    check(_lib.lib().dfold_colsum_bf16(_p(x), _p(out), c_int64(R), c_int32(C), c_int64(ld), stream()),
+          "dfold_colsum_bf16")
+
+
+def relu_mask_bf16(g, v, out):
+    check(_lib.lib().dfold_relu_mask_bf16(_p(g), _p(v), _p(out), c_int64(g.numel()), stream()), "dfold_relu_mask_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dense layers on [rows, K] bf16 matrices
+# ------------------------------------------------------------------------------------------------
+
+def linear_fwd(x, w, bias=None, out_dtype=BF16, relu=False, out=None, x_rows=None, M=None, out_rows=None):
+    """y = x @ w^T + bias.  x bf16 [M,K] (or any tensor addressed through x_rows), w bf16 [N,K]."""
+    N, K = w.shape
+    if M is None:
+        M = x.numel() // K
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=w.device)
+    return gemm(x, w, out, M, N, K, a_rows=x_rows or rows_plain(K), c_rows=out_rows or rows_plain(N), ldb=K,
+                bias=bias, flags=GEMM_RELU if relu else 0)
+
+
+def linear_bwd(x, w_t, gy, need_dx=True, dw_out=None, accumulate=False, M=None):
+    """x bf16 [M,K], w_t bf16 [K,N] (= w transposed), gy bf16 [M,N]  ->  dx bf16 [M,K], dW fp32 [N,K]."""
+    K, N = w_t.shape
+    if M is None:
+        M = gy.numel() // N
+    dx = None
+    if need_dx:
+        dx = torch.empty((M, K), dtype=BF16, device=gy.device)
+        gemm(gy, w_t, dx, M, K, N, a_rows=rows_plain(N), c_rows=rows_plain(K), ldb=N)
+    gyT = transpose_bf16(gy, M, N)      # [N][M]
+    xT = transpose_bf16(x, M, K)        # [K][M]
+    if dw_out is None:
+        dw_out = torch.empty((N, K), dtype=torch.float32, device=gy.device)
+        accumulate = False
+    gemm(gyT, xT, dw_out, N, K, M, a_rows=rows_plain(M), c_rows=rows_plain(K), ldb=M,
+         flags=GEMM_ACCUM if accumulate else 0)
+    return dx, dw_out
+
+
+# ------------------------------------------------------------------------------------------------
+# 5x5 conv tower on the zero-padded frame x residue grid
+# ------------------------------------------------------------------------------------------------
+
+class Grid:
+    """Geometry of the zero-padded channels-last activation grid [windows, F+4, N+4, C]."""
+
+    def __init__(self, Wn, F, N, device):
+        if N % 8:
+            raise ValueError("N_res must be a multiple of 8 (16-byte bf16 chunks)")
+        self.Wn, self.F, self.N, self.Fp, self.Wp, self.device = Wn, F, N, F + 4, N + 4, device
+        self.M = Wn * F * N
+        self.plane = Wn * self.Fp * N
+
+    def alloc(self, C):
+        return torch.zeros((self.Wn, self.Fp, self.Wp, C), dtype=BF16, device=self.device)
+
+    def interior(self, t):
+        return t[:, 2:-2, 2:-2, :]
+
+    def rows_in(self, C):          # conv input rows: top-left corner of the 5x5 window
+        return rows_grid(C, self.N, self.F, self.Fp, self.Wp, 0)
+
+    def rows_center(self, C, ch_off=0):  # the cell itself
+        return rows_grid(C, self.N, self.F, self.Fp, self.Wp, (2 * self.Wp + 2) * C + ch_off)
+
+    def tap_offsets(self, C):
+        return seg_table([(df * self.Wp + dn) * C for df in range(5) for dn in range(5)], self.device)
+
+    def seg_shifted(self):
+        return seg_table([w * self.Fp * self.N for w in range(self.Wn)], self.device)
+
+    def seg_center(self):
+        return seg_table([w * self.Fp * self.N + 2 * self.N for w in range(self.Wn)], self.device)
+
+
+def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None):
+    """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO]."""
+    CO, _, CI = wf.shape
+    flags = GEMM_RELU if relu else 0
+    R = None
+    if resid is not None:
+        flags |= GEMM_RESID
+        R = resid
+    if relu_mask is not None:
+        flags |= GEMM_RELUMASK
+        R = relu_mask
+    if pre_resid_out is not None:
+        C2, R2 = pre_resid_out, None
+    return gemm(x, wf, out, g.M, CO, CI, nseg=25, a_rows=g.rows_in(CI), c_rows=g.rows_center(CO), ldb=25 * CI,
+                bias=bias, R=R, C2=C2, R2=R2, a_seg_off=g.tap_offsets(CI), flags=flags)
+
+
+def grid_transpose_shift(g, x, C, d0, nd, out):
+    check(_lib.lib().dfold_grid_transpose_shift(_p(x), _p(out), c_int32(g.Wn), c_int32(g.Fp), c_int32(g.Wp), c_int32(C),
+                                                c_int32(g.N), c_int32(d0), c_int32(nd), stream()),
+          "dfold_grid_transpose_shift")
+    return out
+
+
+def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True):
+    """dwg fp32 [CO][25][CI] (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.
+    The narrower operand gets the 5 column-shifted transposed copies, the wider one a single copy."""
+    CI, CO = x.shape[-1], gy.shape[-1]
+    plane, N, F = g.plane, g.N, g.F
+    fl = GEMM_ACCUM if accumulate else 0
+    if CI <= CO:   # shift x
+        tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)))
+        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)))
+        gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
+             a_seg_off=g.seg_center(), b_seg_off=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
+             sc=(5 * CI, CI), flags=fl)
+    else:          # shift gy, taps flipped
+        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)))
+        tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
+        gemm(tS, tU, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
+             a_seg_off=g.seg_shifted(), b_seg_off=g.seg_center(), nbatch=25, nb1=5, sa=(N, CO * plane),
+             sc=(-5 * CI, -CI), c_off=24 * CI, flags=fl)
+    return dwg
+
+
+class Workspace:
+    """Named scratch buffers reused across calls (caller-owned workspace, as the C ABI requires)."""
+
+    def __init__(self, device):
+        self.device, self.bufs = device, {}
+
+    def get(self, name, shape, dtype=BF16, zero=False):
+        n = 1
+        for s in shape:
+            n *= s
+        key = (name, tuple(shape), dtype)
+        b = self.bufs.get(key)
+        if b is None:
+            b = torch.zeros(n, dtype=dtype, device=self.device)
+            self.bufs[key] = b
+        elif zero:
+            b.zero_()
+        return b.view(*shape)
+
+
+class ConvTower:
+    """The shared conv_0 residual tower (reference ConvNet, src/model/ipa_pytorch_dynamic.py:664-706):
+    4 x [h = relu(conv2(relu(conv1(h)))) + h], conv1 C->C/2, conv2 C/2->C, 5x5, zero pad 2, bias.
+    Holds bf16 packed weights (refreshed by pack()) and fp32 gradient accumulators in GEMM layout."""
+
+    def __init__(self, weights, biases):
+        # weights: list of 8 fp32 [CO,CI,5,5] tensors in order conv1.0, conv1.2, conv2.0, ...; biases likewise
+        self.weights, self.biases = weights, biases
+        dev = weights[0].device
+        self.wf = [torch.empty((w.shape[0], 25, w.shape[1]), dtype=BF16, device=dev) for w in weights]
+        self.wd = [torch.empty((w.shape[1], 25, w.shape[0]), dtype=BF16, device=dev) for w in weights]
+        self.dwg = [torch.zeros((w.shape[0], 25, w.shape[1]), dtype=torch.float32, device=dev) for w in weights]
+        self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
+        self.ws = Workspace(dev)
+
+    def pack(self):
+        L = _lib.lib()
+        for w, wf, wd in zip(self.weights, self.wf, self.wd):
+            check(L.dfold_conv_weight_pack(_p(w.detach()), _p(wf), _p(wd), c_int32(w.shape[0]), c_int32(w.shape[1]), stream()),
+                  "dfold_conv_weight_pack")
+
+    def zero_grad(self):
+        for t in self.dwg + self.db:
+            t.zero_()
+
+    def forward(self, g, h0, save=True):
+        """h0: padded grid [Wn,Fp,Wp,C] bf16.  Returns (h4, saved)."""
+        C = h0.shape[-1]
+        saved = [h0]
+        h = h0
+        for i in range(4):
+            u = g.alloc(C // 2)
+            conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True)
+            hn, v = g.alloc(C), g.alloc(C)
+            conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v)
+            saved += [u, v, hn]
+            h = hn
+        return h, saved
+
+    def backward(self, g, saved, gtop):
+        """gtop: dL/dh4 on the padded grid (border zero).  Accumulates dwg/db, returns dL/dh0."""
+        C = gtop.shape[-1]
+        gi = gtop
+        ws = self.ws
+        dv = relu_mask_bf16(gi, saved[3 * 3 + 2], ws.get("dv", tuple(gtop.shape)))
+        for i in (3, 2, 1, 0):
+            hprev, u, v = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
+            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws)
+            colsum_bf16(dv, self.db[2 * i + 1], dv.numel() // C, C, C)
+            du = ws.get("du", tuple(u.shape))
+            self._zero_border_once(du, "du")
+            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u)
+            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws)
+            colsum_bf16(du, self.db[2 * i], du.numel() // (C // 2), C // 2, C // 2)
+            gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
+            if i > 0:
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2])
+            else:
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi)
+            gi = gn
+        return gi
+
+    def _zero_border_once(self, t, name):
+        pass  # workspace buffers are allocated zeroed and kernels only ever write interior cells
+
+    def finalize_grads(self):
+        """GEMM-layout fp32 accumulators -> .grad of the reference-layout parameters."""
+        L = _lib.lib()
+        for w, b, dwg, db in zip(self.weights, self.biases, self.dwg, self.db):
+            if w.grad is None:
+                w.grad = torch.zeros_like(w)
+            check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(w.grad), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
+                                            stream()), "dfold_conv_wgrad_unpack")
+            b.grad = db.clone()

@@ -1,0 +1,133 @@
+"""GPU parity of the bf16 MFMA contraction engine and the conv tower (C ABI: dfold_gemm_bf16 & helpers).
+Reference = fp32/fp64 torch math on the SAME bf16-rounded operands (kernel-level check); the oracle-level
+check of ConvNet against reference-minted golden vectors is test_convnet_vs_oracle_golden."""
+import numpy as np
+import pytest
+import torch
+
+from util import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand_bf16(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1024, 640, 1280), (77, 6, 1280), (4096, 40, 128)])
+def test_gemm_plain(dev, M, N, K):
+    from dynamicpdb_amd import ops
+    a, b = _rand_bf16((M, K), dev, 1), _rand_bf16((N, K), dev, 2)
+    bias = torch.randn(N, device=dev)
+    ref = a.double() @ b.double().t() + bias.double()
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ops.gemm(a, b, out, M, N, K, a_rows=ops.rows_plain(K), c_rows=ops.rows_plain(N), ldb=K, bias=bias)
+    assert rel_l2(out, ref) < 1e-5
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, b, outb, M, N, K, a_rows=ops.rows_plain(K), c_rows=ops.rows_plain(N), ldb=K, bias=bias,
+             flags=ops.GEMM_RELU)
+    assert rel_l2(outb, ref.clamp_min(0)) < 4e-3
+
+
+def test_gemm_asymmetric_identity(dev):
+    """transpose-detecting check: A = I, asymmetric B."""
+    from dynamicpdb_amd import ops
+    n = 128
+    a = torch.eye(n, device=dev).to(torch.bfloat16)
+    b = (torch.arange(n * n, device=dev).reshape(n, n) % 251).float().to(torch.bfloat16)
+    out = torch.empty((n, n), dtype=torch.float32, device=dev)
+    ops.gemm(a, b, out, n, n, n, a_rows=ops.rows_plain(n), c_rows=ops.rows_plain(n), ldb=n)
+    assert torch.equal(out, b.float().t())
+
+
+def test_gemm_batched_accumulate(dev):
+    from dynamicpdb_amd import ops
+    B0, B1, M, N, K = 3, 2, 96, 72, 96
+    a, b = _rand_bf16((B0, B1, M, K), dev, 3), _rand_bf16((B0, B1, N, K), dev, 4)
+    ref = torch.einsum("xymk,xynk->xymn", a.double(), b.double())
+    out = torch.ones((B0, B1, M, N), dtype=torch.float32, device=dev)
+    ops.gemm(a, b, out, M, N, K, a_rows=ops.rows_plain(K), c_rows=ops.rows_plain(N), ldb=K, nbatch=B0 * B1, nb1=B1,
+             sa=(B1 * M * K, M * K), sb=(B1 * N * K, N * K), sc=(B1 * M * N, M * N), flags=ops.GEMM_ACCUM, alpha=0.5)
+    assert rel_l2(out, 0.5 * ref + 1.0) < 1e-5
+
+
+def test_transpose_and_cast(dev):
+    from dynamicpdb_amd import ops
+    x = torch.randn(3, 70, 130, device=dev)
+    xb = ops.cast_bf16(x)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    t = ops.transpose_bf16(xb, 70, 130, nbatch=3, bs_src=70 * 130)
+    assert torch.equal(t, xb.transpose(1, 2).contiguous())
+    assert torch.equal(ops.cast_f32(xb), xb.float())
+
+
+def _torch_tower(x, ws, bs):
+    h = x
+    for i in range(4):
+        y = torch.relu(torch.nn.functional.conv2d(h, ws[2 * i], bs[2 * i], padding=2))
+        y = torch.relu(torch.nn.functional.conv2d(y, ws[2 * i + 1], bs[2 * i + 1], padding=2))
+        h = y + h
+    return h
+
+
+@pytest.mark.parametrize("Wn,F,N,C", [(2, 3, 16, 128), (1, 5, 40, 64)])
+def test_conv_tower_fwd_bwd_vs_torch(dev, Wn, F, N, C):
+    from dynamicpdb_amd import ops
+    torch.manual_seed(0)
+    ws, bs = [], []
+    for i in range(4):
+        ws += [torch.randn(C // 2, C, 5, 5, device=dev) / np.sqrt(25 * C) * 1.3, torch.randn(C, C // 2, 5, 5, device=dev) / np.sqrt(12.5 * C) * 1.3]
+        bs += [0.1 * torch.randn(C // 2, device=dev), 0.1 * torch.randn(C, device=dev)]
+    ws = [w.requires_grad_(True) for w in ws]
+    bs = [b.requires_grad_(True) for b in bs]
+    x = torch.randn(Wn, F, N, C, device=dev).to(torch.bfloat16)
+    gy = torch.randn(Wn, F, N, C, device=dev).to(torch.bfloat16)
+    # reference in fp64 on bf16-rounded weights / inputs
+    wr = [w.detach().to(torch.bfloat16).double().requires_grad_(True) for w in ws]
+    br = [b.detach().double().requires_grad_(True) for b in bs]
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = _torch_tower(xr, wr, br)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    tower = ops.ConvTower(ws, bs)
+    tower.pack()
+    g = ops.Grid(Wn, F, N, dev)
+    h0 = g.alloc(C)
+    g.interior(h0).copy_(x)
+    h4, saved = tower.forward(g, h0)
+    assert rel_l2(g.interior(h4), yr.permute(0, 2, 3, 1)) < 1e-2
+    assert float(h4[:, :2].abs().max()) == 0 and float(h4[:, :, :2].abs().max()) == 0   # border stays zero
+    gt = g.alloc(C)
+    g.interior(gt).copy_(gy)
+    g0 = tower.backward(g, saved, gt)
+    tower.finalize_grads()
+    assert rel_l2(g.interior(g0), xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    for i in range(8):
+        assert rel_l2(ws[i].grad, wr[i].grad) < 2e-2, i
+        assert rel_l2(bs[i].grad, br[i].grad) < 2e-2, i
+
+
+def test_convnet_vs_oracle_golden(dev):
+    """ConvNet on the reference-minted capture (F=3, N=16, C=1280; tests/golden/network_F3_N16.npz)."""
+    from dynamicpdb_amd import ops, synthetic
+    g_ = load_golden("network_F3_N16.npz")
+    sd = synthetic.seeded_state_dict(int(g_["meta"][2]))
+    t = "score_model.trunk.conv_0."
+    ws = [sd[f"{t}conv{i}.{j}.weight"].to(dev) for i in (1, 2, 3, 4) for j in (0, 2)]
+    bs = [sd[f"{t}conv{i}.{j}.bias"].to(dev) for i in (1, 2, 3, 4) for j in (0, 2)]
+    tower = ops.ConvTower(ws, bs)
+    tower.pack()
+    cin = torch.tensor(g_["cap_conv_in_0"]).to(dev)           # [F,N,1280] (reference ConvNet input)
+    cout = torch.tensor(g_["cap_conv_out_0"])
+    F, N, C = cin.shape
+    g = ops.Grid(1, F, N, dev)
+    h0 = g.alloc(C)
+    g.interior(h0).copy_(cin.to(torch.bfloat16)[None])
+    h4, _ = tower.forward(g, h0, save=False)
+    assert rel_l2(g.interior(h4)[0].cpu(), cout) < 1e-2     # bf16 operands, fp32 accumulate (tolerance: DESIGN.md)
