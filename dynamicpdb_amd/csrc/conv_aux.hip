@@ -225,11 +225,13 @@ extern "C" int dfold_relu_mask_bf16(const void* g, const void* v, void* out, int
 // 64x64 tiles through LDS; reads and writes both coalesced along their contiguous axis.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                             int R, int C, long lds_, long ldd, long sbs, long sbd) {
+                                                             int R, int C, long lds_, long ldd, long sbs0, long sbs1,
+                                                             long sbd0, long sbd1, int nb1) {
   __shared__ bf16_t t[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const bf16_t* s = src + (long)blockIdx.z * sbs;
-  bf16_t* d = dst + (long)blockIdx.z * sbd;
+  const int z0 = blockIdx.z / nb1, z1 = blockIdx.z - z0 * nb1;
+  const bf16_t* s = src + z0 * sbs0 + z1 * sbs1;
+  bf16_t* d = dst + z0 * sbd0 + z1 * sbd1;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int c = e & 63, r = e >> 6;
     if (r0 + r < R && c0 + c < C) t[r][c] = s[(long)(r0 + r) * lds_ + c0 + c];
@@ -242,12 +244,13 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 }
 
 extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst,
-                                    int32_t nbatch, int64_t bs_src, int64_t bs_dst, void* stream) {
-  if (!src || !dst || R <= 0 || C <= 0 || nbatch <= 0 || ld_src < C || ld_dst < R) return DFOLD_EINVAL;
+                                    int32_t nbatch, int32_t nb1, int64_t bs_src0, int64_t bs_src1, int64_t bs_dst0,
+                                    int64_t bs_dst1, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || nbatch <= 0 || nb1 <= 0 || ld_src < C || ld_dst < R) return DFOLD_EINVAL;
   if (nbatch > 65535) return DFOLD_EINVAL;
   dim3 grid((C + 63) / 64, (R + 63) / 64, nbatch);
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
-                     C, (long)ld_src, (long)ld_dst, (long)bs_src, (long)bs_dst);
+                     C, (long)ld_src, (long)ld_dst, (long)bs_src0, (long)bs_src1, (long)bs_dst0, (long)bs_dst1, nb1);
   return dfold_check_launch();
 }
 

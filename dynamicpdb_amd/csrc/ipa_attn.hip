@@ -1,0 +1,354 @@
+// Invariant Point Attention core for gfx950 -- the part of the reference's
+// InvariantPointAttention.forward (src/model/ipa_pytorch_dynamic.py:396-469) that the reference
+// materialises as [F,N,N,H,Pq,3] / [F,H,3,N,N,Pv] broadcast tensors:
+//
+//   logits[b,f,h,i,j] = S (= scaled q.k, from the MFMA engine) + sqrt(1/3) * bias[b,h,i,j]
+//                       - 0.5 * hw[h] * sum_p |q_pts[i,p] - k_pts[j,p]|^2 + inf * (m_i m_j - 1)      (:402-443)
+//   P = softmax_j(logits)                                                                             (:444)
+//   o_pt[b,f,i,h,p,:] = sum_j P[i,j] v_pts[j,p,:]   (global frame)                                    (:460-469)
+//
+// and the matching backward.  Point terms stay in fp32 on the VALU (coordinates are O(100 A); the
+// difference form |q-k|^2 is kept, never the bf16-hostile |q|^2+|k|^2-2qk expansion).  One wave owns
+// one attention row: the row lives in registers, max / sum / dot reductions are wave64 shuffles; the
+// per-(window,frame,head) key/value point tables are staged once per workgroup in LDS (padded rows,
+// conflict free for lane<->j access).
+#include "dfold_common.h"
+#include "../../include/dfold_hip.h"
+
+#define IPA_PQ 8
+#define IPA_PV 12
+#define KP (IPA_PQ * 3)  // 24 floats per (residue, head)
+#define VP (IPA_PV * 3)  // 36
+#define KPS 25           // padded LDS row strides
+#define VPS 37
+#define MAXT 16          // columns per lane (N <= 1024)
+#define ROWS_PER_BLOCK 16
+
+struct IpaDims {
+  int B, F, N, H;
+};
+
+// q_pts [B,F,N,H,PQ,3], k_pts [B,F,N,H,PQ,3], v_pts [B,F,N,H,PV,3] fp32; S/P [B,F,H,N,N]; bias [B,H,N,N]; mask [B,F,N]
+__global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, const float* __restrict__ bias,
+                                                              const float* __restrict__ q_pts,
+                                                              const float* __restrict__ k_pts,
+                                                              const float* __restrict__ mask, const float* __restrict__ hw,
+                                                              float* P, bf16_t* __restrict__ Pb, IpaDims d,
+                                                              float bias_scale, float inf) {
+  extern __shared__ float sm[];
+  float* kp = sm;  // [N][KPS]
+  const int N = d.N, H = d.H;
+  const int bf = blockIdx.z, h = blockIdx.y, b = bf / d.F;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
+  for (int e = threadIdx.x; e < N * KP; e += 256) {
+    const int j = e / KP, c = e - j * KP;
+    kp[j * KPS + c] = kbase[(long)j * H * KP + c];
+  }
+  __syncthreads();
+  const float hwh = hw[h];
+  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
+  for (int r = w; r < ROWS_PER_BLOCK; r += 4) {
+    const int i = i0 + r;
+    if (i >= N) break;
+    float qv[KP];
+    const float* qb = q_pts + (((long)bf * N + i) * H + h) * KP;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) qv[c] = qb[c];
+    const float mi = mask[(long)bf * N + i];
+    const long rowS = (((long)bf * H + h) * N + i) * N;
+    const long rowB = (((long)b * H + h) * N + i) * N;
+    float lg[MAXT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int j = lane + 64 * t;
+      lg[t] = -3.0e38f;
+      if (j < N) {
+        float d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+          const float df = qv[c] - kp[j * KPS + c];
+          d2 += df * df;
+        }
+        float v = S[rowS + j] + bias_scale * bias[rowB + j] - 0.5f * hwh * d2;
+        v += inf * (mi * mask[(long)bf * N + j] - 1.f);
+        lg[t] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        lg[t] = expf(lg[t] - mx);
+        sum += lg[t];
+      }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        const float p = lg[t] * inv;
+        P[rowS + j] = p;
+        Pb[rowS + j] = f2bf(p);
+      }
+    }
+  }
+}
+
+extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const float* q_pts, const float* k_pts,
+                                     const float* mask, const float* hw, float* P, void* P_bf16, int32_t B, int32_t F,
+                                     int32_t N, int32_t H, float bias_scale, float inf, void* stream) {
+  if (!S || !bias || !q_pts || !k_pts || !mask || !hw || !P || !P_bf16) return DFOLD_EINVAL;
+  if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
+  IpaDims d{B, F, N, H};
+  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  const size_t lds = (size_t)N * KPS * sizeof(float);
+  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, S, bias, q_pts, k_pts, mask, hw,
+                     P, (bf16_t*)P_bf16, d, bias_scale, inf);
+  return dfold_check_launch();
+}
+
+// o_pt[b,f,i,h,c] = sum_j P[b,f,h,i,j] * v_pts[b,f,j,h,c]   (c = 36 point components, fp32)
+__global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restrict__ P, const float* __restrict__ v_pts,
+                                                          float* __restrict__ o_pt, IpaDims d) {
+  extern __shared__ float sm[];
+  const int N = d.N, H = d.H;
+  float* vp = sm;             // [N][VPS]
+  float* pt = sm + N * VPS;   // [ROWS][N]
+  const int bf = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ROWS_PER_BLOCK;
+  const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
+  for (int e = threadIdx.x; e < N * VP; e += 256) {
+    const int j = e / VP, c = e - j * VP;
+    vp[j * VPS + c] = vbase[(long)j * H * VP + c];
+  }
+  const int rows = min(ROWS_PER_BLOCK, N - i0);
+  const float* pbase = P + (((long)bf * H + h) * N + i0) * N;
+  for (int e = threadIdx.x; e < rows * N; e += 256) pt[e] = pbase[e];
+  __syncthreads();
+  for (int o = threadIdx.x; o < rows * VP; o += 256) {
+    const int r = o / VP, c = o - r * VP;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc += pt[r * N + j] * vp[j * VPS + c];
+    o_pt[(((long)bf * N + i0 + r) * H + h) * VP + c] = acc;
+  }
+}
+
+extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt, int32_t B, int32_t F, int32_t N, int32_t H,
+                                 void* stream) {
+  if (!P || !v_pts || !o_pt || B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
+  IpaDims d{B, F, N, H};
+  const size_t lds = ((size_t)N * VPS + (size_t)ROWS_PER_BLOCK * N) * sizeof(float);
+  if (lds > 160 * 1024) return DFOLD_EINVAL;
+  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  hipFuncSetAttribute((const void*)ipa_opt_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, row pass.  Per attention row (b,f,h,i):
+//   g_ij  = dP_ij + sum_c do_pt[i,c] v_pts[j,c]
+//   dS_ij = P_ij (g_ij - sum_j' P_ij' g_ij')
+//   dq_pts[i,c] = -hw sum_j dS_ij (q_ic - k_jc);   dhw[h] += sum_j dS_ij * (-0.5 |q_i - k_j|^2)
+// writes dS (fp32, and bf16 for the MFMA products dQ/dK).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ P, const float* dP,
+                                                              const float* __restrict__ q_pts,
+                                                              const float* __restrict__ k_pts,
+                                                              const float* __restrict__ v_pts,
+                                                              const float* __restrict__ do_pt, const float* __restrict__ hw,
+                                                              float* dS, bf16_t* __restrict__ dSb,
+                                                              float* __restrict__ dq_pts, float* __restrict__ dhw,
+                                                              IpaDims d) {
+  extern __shared__ float sm[];
+  const int N = d.N, H = d.H;
+  float* kp = sm;            // [N][KPS]
+  float* vp = sm + N * KPS;  // [N][VPS]
+  const int bf = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
+  const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
+  for (int e = threadIdx.x; e < N * KP; e += 256) {
+    const int j = e / KP, c = e - j * KP;
+    kp[j * KPS + c] = kbase[(long)j * H * KP + c];
+  }
+  for (int e = threadIdx.x; e < N * VP; e += 256) {
+    const int j = e / VP, c = e - j * VP;
+    vp[j * VPS + c] = vbase[(long)j * H * VP + c];
+  }
+  __syncthreads();
+  const float hwh = hw[h];
+  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
+  float dhw_acc = 0.f;
+  for (int r = w; r < ROWS_PER_BLOCK; r += 4) {
+    const int i = i0 + r;
+    if (i >= N) break;
+    const long pix = ((long)bf * N + i) * H + h;
+    float qv[KP], dov[VP];
+#pragma unroll
+    for (int c = 0; c < KP; ++c) qv[c] = q_pts[pix * KP + c];
+#pragma unroll
+    for (int c = 0; c < VP; ++c) dov[c] = do_pt[pix * VP + c];
+    const long row = (((long)bf * H + h) * N + i) * N;
+    float pv[MAXT], gv[MAXT];
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int j = lane + 64 * t;
+      pv[t] = 0.f;
+      gv[t] = 0.f;
+      if (j < N) {
+        float g = dP[row + j];
+#pragma unroll
+        for (int c = 0; c < VP; ++c) g += dov[c] * vp[j * VPS + c];
+        pv[t] = P[row + j];
+        gv[t] = g;
+        dot += pv[t] * g;
+      }
+    }
+    dot = wave_sum(dot);
+    float dq[KP];
+#pragma unroll
+    for (int c = 0; c < KP; ++c) dq[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int j = lane + 64 * t;
+      if (j < N) {
+        const float ds = pv[t] * (gv[t] - dot);
+        dS[row + j] = ds;
+        dSb[row + j] = f2bf(ds);
+        float d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+          const float df = qv[c] - kp[j * KPS + c];
+          dq[c] += ds * df;
+          d2 += df * df;
+        }
+        dhw_acc += -0.5f * ds * d2;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KP; ++c) {
+      const float s = wave_sum(dq[c]);
+      if (lane == 0) dq_pts[pix * KP + c] = -hwh * s;
+    }
+  }
+  dhw_acc = wave_sum(dhw_acc);
+  if (lane == 0 && dhw_acc != 0.f) atomicAdd(dhw + h, dhw_acc);
+}
+
+extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const float* q_pts, const float* k_pts,
+                                     const float* v_pts, const float* do_pt, const float* hw, float* dS, void* dS_bf16,
+                                     float* dq_pts, float* dhw, int32_t B, int32_t F, int32_t N, int32_t H, void* stream) {
+  if (!P || !dP || !q_pts || !k_pts || !v_pts || !do_pt || !hw || !dS || !dS_bf16 || !dq_pts || !dhw) return DFOLD_EINVAL;
+  if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
+  IpaDims d{B, F, N, H};
+  const size_t lds = (size_t)N * (KPS + VPS) * sizeof(float);
+  if (lds > 160 * 1024) return DFOLD_EINVAL;
+  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(ipa_softmax_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dP, q_pts, k_pts, v_pts, do_pt,
+                     hw, dS, (bf16_t*)dS_bf16, dq_pts, dhw, d);
+  return dfold_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, column pass.  Per key/value residue (b,f,h,j), lane <-> j, loop over rows i:
+//   dk_pts[j,c] = hw (sum_i dS_ij q_ic - k_jc sum_i dS_ij);    dv_pts[j,c] = sum_i P_ij do_pt[i,c]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dS,
+                                                          const float* __restrict__ q_pts, const float* __restrict__ k_pts,
+                                                          const float* __restrict__ do_pt, const float* __restrict__ hw,
+                                                          float* __restrict__ dk_pts, float* __restrict__ dv_pts, IpaDims d) {
+  extern __shared__ float sm[];
+  const int N = d.N, H = d.H;
+  float* qp = sm;           // [N][KP]   (broadcast reads)
+  float* dop = sm + N * KP; // [N][VP]
+  const int bf = blockIdx.z, h = blockIdx.y;
+  const float* qbase = q_pts + ((long)bf * N * H + h) * KP;
+  const float* dbase = do_pt + ((long)bf * N * H + h) * VP;
+  for (int e = threadIdx.x; e < N * KP; e += 256) {
+    const int i = e / KP, c = e - i * KP;
+    qp[e] = qbase[(long)i * H * KP + c];
+  }
+  for (int e = threadIdx.x; e < N * VP; e += 256) {
+    const int i = e / VP, c = e - i * VP;
+    dop[e] = dbase[(long)i * H * VP + c];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float aq[KP], av[VP], cs = 0.f;
+#pragma unroll
+  for (int c = 0; c < KP; ++c) aq[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < VP; ++c) av[c] = 0.f;
+  const long base = ((long)bf * H + h) * N * N + j;
+  for (int i = 0; i < N; ++i) {
+    const float ds = dS[base + (long)i * N];
+    const float p = P[base + (long)i * N];
+    cs += ds;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) aq[c] += ds * qp[i * KP + c];
+#pragma unroll
+    for (int c = 0; c < VP; ++c) av[c] += p * dop[i * VP + c];
+  }
+  const float hwh = hw[h];
+  const long pix = ((long)bf * N + j) * H + h;
+#pragma unroll
+  for (int c = 0; c < KP; ++c) dk_pts[pix * KP + c] = hwh * (aq[c] - cs * k_pts[pix * KP + c]);
+#pragma unroll
+  for (int c = 0; c < VP; ++c) dv_pts[pix * VP + c] = av[c];
+}
+
+extern "C" int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
+                                 const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,
+                                 void* stream) {
+  if (!P || !dS || !q_pts || !k_pts || !do_pt || !hw || !dk_pts || !dv_pts) return DFOLD_EINVAL;
+  if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
+  IpaDims d{B, F, N, H};
+  const size_t lds = (size_t)N * (KP + VP) * sizeof(float);
+  if (lds > 160 * 1024) return DFOLD_EINVAL;
+  dim3 grid((N + 255) / 256, H, B * F);
+  hipFuncSetAttribute((const void*)ipa_col_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(ipa_col_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
+                     dv_pts, d);
+  return dfold_check_launch();
+}
+
+// dbias[b,h,i,j] = scale * sum_f dS[b,f,h,i,j]; written as bf16 in two layouts:
+//   out_hn [B][H][N*N]  (K-contiguous over (i,j): A operand of dW_b)  and  out_nh [B][N*N][H8] (H padded to 8, for dz)
+__global__ __launch_bounds__(256) void ipa_bias_grad_kernel(const float* __restrict__ dS, bf16_t* __restrict__ out_hn,
+                                                            bf16_t* __restrict__ out_nh, IpaDims d, float scale) {
+  const long NN = (long)d.N * d.N;
+  const long ij = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (ij >= NN) return;
+  __attribute__((aligned(16))) bf16_t row[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) row[h] = 0;
+  for (int h = 0; h < d.H; ++h) {
+    float s = 0.f;
+    for (int f = 0; f < d.F; ++f) s += dS[(((long)(b * d.F + f)) * d.H + h) * NN + ij];
+    const bf16_t v = f2bf(s * scale);
+    out_hn[((long)b * d.H + h) * NN + ij] = v;
+    row[h] = v;
+  }
+  *(uint4*)(out_nh + ((long)b * NN + ij) * 8) = *(const uint4*)row;
+}
+
+extern "C" int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, int32_t F, int32_t N, int32_t H,
+                                   float scale, void* stream) {
+  if (!dS || !out_hn || !out_nh || B <= 0 || F <= 0 || N <= 0 || H <= 0 || H > 8) return DFOLD_EINVAL;
+  IpaDims d{B, F, N, H};
+  dim3 grid((unsigned)(((long)N * N + 255) / 256), B);
+  hipLaunchKernelGGL(ipa_bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dS, (bf16_t*)out_hn, (bf16_t*)out_nh, d,
+                     scale);
+  return dfold_check_launch();
+}

@@ -48,9 +48,9 @@ class R3Diffuser:
     def score(self, x_t, x_0, t, use_torch=False, scale=False):
         """-(x_t - e^{-b/2} x_0) / (1 - e^{-b}) (reference :169-177)."""
         if use_torch and torch.is_tensor(x_t) and x_t.is_cuda:
-            from .. import ops
+            from ..model import score_heads
             s = self._r3_conf.coordinate_scaling if scale else 1.0
-            return ops.r3_score(x_t, x_0, t, self.min_b, self.max_b, s)
+            return score_heads.r3_score(x_t, x_0, t, self.min_b, self.max_b, s)
         exp_fn = torch.exp if use_torch else np.exp
         if scale:
             x_t, x_0 = self._scale(x_t), self._scale(x_0)

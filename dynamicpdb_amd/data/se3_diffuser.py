@@ -73,14 +73,21 @@ class SE3Diffuser:
         """score of q_0^{-1} (x) q_t as a rotation vector (reference :119-125)."""
         quats_t, quats_0 = rots_t.get_quats(), rots_0.get_quats()
         if quats_t.is_cuda:
-            from .. import ops
-            t_np = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
-            so3 = self._so3_diffuser
-            sigma = so3.discrete_sigma[so3.t_to_idx(t_np)]
-            return ops.rot_score(quats_t, quats_0, sigma)
+            return self.calc_rot_score_t7(quats_t, quats_0, t)
         from .. import host_math
         return self._so3_diffuser.torch_score(host_math.quat_to_rotvec(
             host_math.quat_multiply(host_math.invert_quat(quats_0), quats_t)), t)
+
+    def calc_rot_score_t7(self, quats_t, quats_0, t):
+        """Device path on raw quaternion tensors; the leading axis enumerates the windows of `t`
+        ([F,N,4] with t [1] as in the reference, or [B,F,N,4] with t [B])."""
+        from ..model import score_heads
+        t_np = np.atleast_1d(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+        so3 = self._so3_diffuser
+        sigma = so3.discrete_sigma[so3.t_to_idx(t_np)]
+        if len(sigma) == 1 and quats_t.dim() == 3:
+            return score_heads.rot_score(quats_t[None], quats_0[None], sigma)[0]
+        return score_heads.rot_score(quats_t, quats_0, sigma)
 
     def score(self, rigid_0: Rigid, rigid_t: Rigid, t: float):
         tran_0, rot_0 = _extract_trans_rots(rigid_0)

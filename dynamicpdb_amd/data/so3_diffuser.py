@@ -166,9 +166,11 @@ class SO3Diffuser:
         np.digitize on the discretised schedule (reference :274-305)."""
         t_np = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
         if vec.is_cuda and not self.use_cached_score:
-            from .. import ops
-            sigma = self.discrete_sigma[self.t_to_idx(t_np)]
-            return ops.igso3_score(vec, sigma, eps)
+            from ..model import score_heads
+            sigma = np.atleast_1d(self.discrete_sigma[self.t_to_idx(t_np)])
+            if len(sigma) == 1:
+                return score_heads.igso3_score(vec[None], sigma, eps)[0]
+            return score_heads.igso3_score(vec, sigma, eps)
         omega = torch.linalg.norm(vec, dim=-1) + eps
         if self.use_cached_score:
             score_norms_t = torch.tensor(self._score_norms[self.t_to_idx(t_np)]).to(vec.device)

@@ -1,0 +1,102 @@
+"""Training-step host logic: the slice of the reference's Experiment (train_DFOLD_dynamics.py:343-1568) that is
+on the hot path -- loss_fn (:1182-1400, live terms only), update_fn (:660-667) and data-parallel gradient
+averaging (DDP at :615) -- over a real window batch axis.  One process per GPU; gradients are averaged with
+torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def torsion_angle_loss(a, a_gt, a_alt_gt, mask):
+    """openfold/utils/loss.py:52-76 as called at train_DFOLD_dynamics.py:1219-1224 (angle-norm weight 0)."""
+    norm = torch.linalg.norm(a, dim=-1)
+    a = a / (norm.unsqueeze(-1) + 1e-8)
+    d_gt = ((a - a_gt) ** 2).sum(-1)
+    d_alt = ((a - a_alt_gt) ** 2).sum(-1)
+    m = torch.minimum(d_gt, d_alt)
+    return (m * mask).sum(dim=(-1, -2)) / (mask.sum(dim=(-1, -2)) + 1e-2)
+
+
+def loss_fn(out, batch, trans_w=100.0, rot_w=7.0, torsion_w=1.0, rot_t_threshold=0.0):
+    """Live loss terms for a [B,F,N,..] batch: last-frame torsion / translation-x0 / rotation-score losses, each
+    repeated over the F frames of its window, gated by trans_loss < 100 (train_DFOLD_dynamics.py:1210-1400).
+    Returns (mean over windows of the reference's per-window loss, aux dict)."""
+    dt = out['rigids'].dtype
+    bb_mask = batch['res_mask'].to(dt)                       # [B,F,N]
+    diffuse_mask = 1 - batch['fixed_mask'].to(dt)
+    loss_mask = bb_mask * diffuse_mask
+    B, Fr, _ = bb_mask.shape
+    tl = torsion_angle_loss(out['angles'], batch['torsion_angles_sin_cos'].to(dt),
+                            batch['alt_torsion_angles_sin_cos'].to(dt), batch['torsion_angles_mask'].to(dt)) * torsion_w
+    torsion = tl[:, -1:].expand(B, Fr)
+    gt_x0, pr_x0 = batch['rigids_0'][..., 4:].to(dt), out['rigids'][..., 4:]
+    trans = ((gt_x0[:, -1:] - pr_x0[:, -1:]) ** 2).mean(dim=(-1, -2)).expand(B, Fr) * trans_w
+    pr_rot = out['rot_score'] * diffuse_mask[..., None]
+    rot_mse = (batch['rot_score'] - pr_rot) ** 2 * loss_mask[..., None]
+    rss = batch['rot_score_scaling'].reshape(B, 1, 1, 1)
+    rot = (rot_mse / rss ** 2).sum(dim=(-1, -2)) / (loss_mask.sum(-1) + 1e-10)
+    rot = rot * rot_w
+    rot = rot * (batch['t'].reshape(B, 1) > rot_t_threshold)
+    rot = rot[:, -1:].expand(B, Fr)
+    gate = (trans < 100.0)
+    rot = rot * gate.to(rot.dtype)
+    trans_g = trans * gate.to(trans.dtype)
+    torsion = torsion * (trans_g < 100.0).to(torsion.dtype)
+    final = rot + trans_g + torsion                          # [B,F]
+    bmask = torch.any(bb_mask > 0, dim=-1)                   # [B,F]
+    norm = lambda x: (x.sum(-1) / (bmask.sum(-1) + 1e-10)).mean()
+    return norm(final), dict(rot_loss=norm(rot), trans_loss=norm(trans_g), torsion_loss=norm(torsion))
+
+
+class Trainer:
+    """update_fn of the reference (zero_grad, loss_fn, backward, optimizer step) for one rank's shard of windows,
+    with gradient averaging across ranks.  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
+
+    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=256 << 20):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
+        self.loss_kwargs = loss_kwargs or {}
+        self.bucket_bytes = bucket_bytes
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def allreduce_grads(self):
+        """Average gradients over ranks in large flat buckets (xGMI rings are per-link bound: few, big
+        collectives).  Parameters without a gradient (the reference's 91,540 dead ones) are skipped on every rank
+        identically, so no find_unused_parameters graph walk is needed."""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        bucket, size, handles = [], 0, []
+
+        def flush():
+            nonlocal bucket, size
+            if not bucket:
+                return
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            handles.append((h, flat, bucket))
+            bucket, size = [], 0
+
+        for g in grads:
+            bucket.append(g)
+            size += g.numel() * g.element_size()
+            if size >= self.bucket_bytes:
+                flush()
+        flush()
+        for h, flat, bucket in handles:
+            h.wait()
+            flat.div_(self.world)
+            off = 0
+            for g in bucket:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+
+    def update_fn(self, batch, step_optimizer=True):
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model(batch)
+        loss, aux = loss_fn(out, batch, **self.loss_kwargs)
+        loss.backward()
+        self.allreduce_grads()
+        if step_optimizer:
+            self.opt.step()
+        return loss.detach(), aux

@@ -1,0 +1,79 @@
+"""Drop-in for the reference's src/model/Dfold_network_dynamic.py: FullScoreNetwork (:429-546) with the same
+constructor, forward(input_feats, drop_ref=False) -> dict contract, output keys and state_dict keys.
+
+Batching: the reference runs one window per call (tensors [F,N,..], node_repr [N,256], t [1]).  This engine
+also accepts a leading window axis on every entry ([B,F,N,..], node_repr [B,N,256], edge_repr [B,N,N,128],
+t [B]); outputs then carry the same leading axis.  Results for B windows equal B independent reference calls."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..ops import BF16
+from . import functional as F_
+from . import geometry as G
+from . import ipa_pytorch_dynamic
+
+
+class DFOLDv2_Embeder(nn.Module):
+    """Parameters of the reference embedder (:19-88).  Its outputs are discarded by DFOLDIpaScore.forward
+    (src/model/ipa_pytorch_dynamic.py:829-834), so nothing is evaluated; the parameters exist so that
+    checkpoints load with strict=True (91,540 parameters that never receive a gradient)."""
+
+    def __init__(self, model_conf):
+        super().__init__()
+        d, e = model_conf.node_embed_size, model_conf.edge_embed_size
+        self.node_timestep_proj = nn.Sequential(nn.Linear(d, d // 2), nn.SiLU(), nn.Linear(d // 2, d))
+        self.node_ln = nn.LayerNorm(d)
+        self.edge_timestep_proj = nn.Sequential(nn.Linear(d, e // 2), nn.SiLU(), nn.Linear(e // 2, e))
+        self.edge_ln = nn.LayerNorm(e)
+
+
+class FullScoreNetwork(nn.Module):
+    def __init__(self, model_conf, diffuser):
+        super().__init__()
+        self._model_conf = model_conf
+        self.embedding_layer = DFOLDv2_Embeder(model_conf)
+        self.diffuser = diffuser
+        self.score_model = ipa_pytorch_dynamic.DFOLDIpaScore(model_conf, diffuser)
+        self.expand_node = nn.Linear(256, model_conf.node_embed_size)
+        self.expand_edge = nn.Linear(128, model_conf.edge_embed_size)
+
+    def _apply_mask(self, aatype_diff, aatype_0, diff_mask):
+        return diff_mask * aatype_diff + (1 - diff_mask) * aatype_0
+
+    _PER_WINDOW = ('node_repr', 'edge_repr', 't')
+
+    def forward(self, input_feats, drop_ref=False):
+        batched = input_feats['rigids_0'].dim() == 4
+        feats = input_feats if batched else {k: (v[None] if torch.is_tensor(v) and k not in ('t',) else v)
+                                             for k, v in input_feats.items()}
+        if not batched:
+            feats['t'] = input_feats['t'].reshape(1)
+        dev = feats['rigids_0'].device
+        if dev.type != 'cuda':
+            raise RuntimeError("FullScoreNetwork (dynamicpdb_amd) needs device tensors on an MI355X; no CPU fallback")
+        fixed_mask = feats['fixed_mask'].to(torch.float32)
+        node_repr = feats['node_repr'].to(torch.float32)
+        edge_repr = feats['edge_repr'].to(torch.float32)
+        B, N = node_repr.shape[0], node_repr.shape[1]
+        exp_node = F_.linear(node_repr.to(BF16), self.expand_node.weight, self.expand_node.bias)          # :473
+        from .. import ops
+        exp_edge = F_.linear(ops.cast_bf16(edge_repr).view(B * N * N, -1), self.expand_edge.weight,
+                             self.expand_edge.bias).view(B, N, N, -1)                                    # :474
+        feats['expand_node_repr'], feats['expand_edge_repr'] = exp_node, exp_edge
+        model_out = self.score_model(None, None, feats, drop_ref=drop_ref)
+        gt_angles = feats['torsion_angles_sin_cos'].to(torch.float32)
+        fm = 1 - fixed_mask[..., None, None]
+        angles_pred = self._apply_mask(model_out['angles'], gt_angles, fm)
+        unorm_angles = self._apply_mask(model_out['unorm_angles'], gt_angles, fm)
+        rigids = model_out['final_rigids']
+        with torch.no_grad():   # atoms do not enter the live loss terms (train_DFOLD_dynamics.py:1367-1373)
+            atom14, atom37 = G.frames_to_atoms(rigids.detach(), angles_pred.detach(), feats['aatype'].long())
+        pred_out = {'angles': angles_pred, 'unorm_angles': unorm_angles, 'rot_score': model_out['rot_score'],
+                    'trans_score': model_out['trans_score'], 'rigids': rigids, 'atom37': atom37, 'atom14': atom14,
+                    'rigid_update': model_out['rigid_update']}
+        if not batched:
+            pred_out = {k: v[0] for k, v in pred_out.items()}
+            input_feats['expand_node_repr'], input_feats['expand_edge_repr'] = exp_node[0], exp_edge[0]
+        return pred_out

@@ -1,0 +1,360 @@
+"""Autograd nodes of the DFOLDv2 trunk.  Each node's forward AND backward arithmetic runs in
+libdfold_hip.so (bf16 MFMA contraction engine + fused HIP kernels); torch only chains the nodes and owns
+the device buffers.  Activations crossing nodes are bf16, geometry (frames, points, scores) fp32."""
+import math
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib, ops
+from .._lib import check, stream
+from ..ops import BF16, GEMM_ACCUM, _p, c_int32, c_int64, gemm, rows_grid, rows_plain
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 weight cache (parameters stay fp32 in the reference layout; the engine consumes bf16 copies)
+# ------------------------------------------------------------------------------------------------
+
+class WeightCache:
+    def __init__(self):
+        self._w, self._wt = {}, {}
+
+    @staticmethod
+    def _stamp(p):
+        return (p.data_ptr(), p._version)
+
+    def w(self, p):
+        e = self._w.get(id(p))
+        if e is None or e[0] != self._stamp(p):
+            e = (self._stamp(p), ops.cast_bf16(p.detach()))
+            self._w[id(p)] = e
+        return e[1]
+
+    def wt(self, p, pad_rows_to=8):
+        """transposed bf16 copy [K][N8] (N zero-padded to a multiple of 8 so it can be a GEMM K axis)."""
+        e = self._wt.get(id(p))
+        if e is None or e[0] != self._stamp(p):
+            w = self.w(p)
+            N, K = w.shape
+            N8 = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+            if N8 != N:
+                wp = torch.zeros((N8, K), dtype=BF16, device=w.device)
+                wp[:N].copy_(w)
+                w = wp
+            e = (self._stamp(p), ops.transpose_bf16(w, N8, K))
+            self._wt[id(p)] = e
+        return e[1]
+
+
+CACHE = WeightCache()
+
+
+def _pad_cols8(g2d):
+    """bf16 [M,N] -> [M,N8] zero padded (only for the few narrow heads: N = 6, 14)."""
+    M, N = g2d.shape
+    N8 = (N + 7) // 8 * 8
+    if N8 == N:
+        return g2d
+    out = torch.zeros((M, N8), dtype=BF16, device=g2d.device)
+    out[:, :N].copy_(g2d)
+    return out
+
+
+def _linear_backward(x2d, weight, g2d, need_dx=True):
+    """x2d bf16 [M,K], g2d bf16 [M,N]  ->  dx bf16 [M,K] | None, dW fp32 [N,K], db fp32 [N]"""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    g8 = _pad_cols8(g2d)
+    N8 = g8.shape[1]
+    dx = None
+    if need_dx:
+        wt = CACHE.wt(weight)                       # [K][N8]
+        dx = torch.empty((M, K), dtype=BF16, device=x2d.device)
+        gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
+    gT = ops.transpose_bf16(g8, M, N8)              # [N8][M]
+    xT = ops.transpose_bf16(x2d, M, K)              # [K][M]
+    dW = torch.empty((N8, K), dtype=torch.float32, device=x2d.device)
+    gemm(gT, xT, dW, N8, K, M, a_rows=rows_plain(M), c_rows=rows_plain(K), ldb=M)
+    db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)
+    ops.colsum_bf16(g8, db, M, N8, N8)
+    return dx, dW[:N], db[:N]
+
+
+class LinearFn(Function):
+    """y = x W^T + b (+ReLU).  x bf16 [..,K]; y bf16 or fp32.  Reference: nn.Linear / openfold Linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_fp32, relu):
+        K = weight.shape[1]
+        x2d = x.reshape(-1, K)
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        y = ops.linear_fwd(x2d, CACHE.w(weight), bias.detach() if bias is not None else None,
+                           out_dtype=torch.float32 if out_fp32 else BF16, relu=relu)
+        ctx.save_for_backward(x2d, weight, y if relu else None)
+        ctx.has_bias, ctx.xshape = bias is not None, x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2d, weight, y = ctx.saved_tensors
+        N = weight.shape[0]
+        g2d = gy.reshape(-1, N)
+        g2d = ops.cast_bf16(g2d) if g2d.dtype == torch.float32 else g2d.contiguous()
+        if y is not None:
+            g2d = ops.relu_mask_bf16(g2d, y if y.dtype == BF16 else ops.cast_bf16(y), torch.empty_like(g2d))
+        dx, dW, db = _linear_backward(x2d, weight, g2d, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.xshape) if dx is not None else None, dW, db if ctx.has_bias else None, None, None)
+
+
+def linear(x, weight, bias=None, out_fp32=False, relu=False):
+    return LinearFn.apply(x, weight, bias, out_fp32, relu)
+
+
+class LinearGLNFn(Function):
+    """[Linear ->] MyLayerNorm [-> SiLU] with per-window statistics (reference MyLayerNorm,
+    src/model/ipa_pytorch_dynamic.py:709-724; embedder tails :757-796; post-IPA :858).
+    x bf16 [W, ..., K] -> bf16 [W, ..., N]; the fp32 pre-norm activations never leave the node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, silu):
+        W = x.shape[0]
+        K = weight.shape[1]
+        x2d = x.reshape(-1, K)
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        h = ops.linear_fwd(x2d, CACHE.w(weight), bias.detach(), out_dtype=torch.float32)
+        n = h.numel() // W
+        y = torch.empty(h.shape, dtype=BF16, device=h.device)
+        stats = torch.empty(2 * W, dtype=torch.float64, device=h.device)
+        mr = torch.empty(2 * W, dtype=torch.float32, device=h.device)
+        check(_lib.lib().dfold_gln_fwd(_p(h), _p(stats), _p(y), _p(mr), c_int32(W), c_int64(n),
+                                       ctypes_float(1e-4), c_int32(1 if silu else 0), stream()), "dfold_gln_fwd")
+        ctx.save_for_backward(x2d, weight, h, mr)
+        ctx.silu, ctx.W, ctx.n, ctx.xshape = silu, W, n, x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2d, weight, h, mr = ctx.saved_tensors
+        g = gy.reshape(h.shape).contiguous()
+        dh = torch.empty(h.shape, dtype=BF16, device=h.device)
+        stats = torch.empty(2 * ctx.W, dtype=torch.float64, device=h.device)
+        check(_lib.lib().dfold_gln_bwd(_p(h), _p(g), _p(mr), _p(stats), _p(dh), c_int32(ctx.W), c_int64(ctx.n),
+                                       c_int32(1 if ctx.silu else 0), stream()), "dfold_gln_bwd")
+        dx, dW, db = _linear_backward(x2d, weight, dh, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.xshape) if dx is not None else None, dW, db, None)
+
+
+def ctypes_float(v):
+    import ctypes
+    return ctypes.c_float(v)
+
+
+def linear_gln(x, weight, bias, silu):
+    return LinearGLNFn.apply(x, weight, bias, silu)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv tower node
+# ------------------------------------------------------------------------------------------------
+
+class ConvTowerFn(Function):
+    """ConvNet (src/model/ipa_pytorch_dynamic.py:664-706) on bf16 [W,F,N,C].  `tower` is the shared
+    ops.ConvTower; weight gradients of all applications in a step are accumulated inside it (GEMM layout,
+    fp32) and handed to autograd once, by the application whose backward runs last."""
+
+    @staticmethod
+    def forward(ctx, x, tower, *params):
+        Wn, F, N, C = x.shape
+        g = ops.Grid(Wn, F, N, x.device)
+        tower.refresh()
+        h0 = g.alloc(C)
+        g.interior(h0).copy_(x)
+        h4, saved = tower.forward(g, h0)
+        ctx.tower, ctx.g, ctx.saved = tower, g, saved
+        tower.pending += 1
+        return g.interior(h4).contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        tower, g = ctx.tower, ctx.g
+        gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]))
+        g.interior(gt).copy_(gy)
+        g0 = tower.backward(g, ctx.saved, gt)
+        ctx.saved = None
+        tower.pending -= 1
+        grads = [None] * (2 * len(tower.weights))
+        if tower.pending == 0:
+            grads = tower.collect_grads()
+        return (g.interior(g0).contiguous(), None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# IPA attention core
+# ------------------------------------------------------------------------------------------------
+
+def _zT(z2d):
+    """transposed copy of the pair tensor rows [R,128] -> [128][R], cached on the tensor (z is reused by all
+    four trunk blocks of a step)."""
+    c = getattr(z2d, "_dfold_T", None)
+    if c is None:
+        c = ops.transpose_bf16(z2d, z2d.shape[0], z2d.shape[1])
+        z2d._dfold_T = c
+    return c
+
+
+class IpaCoreFn(Function):
+    """Attention core of InvariantPointAttention.forward (src/model/ipa_pytorch_dynamic.py:396-502).
+      q [B,F,N,H*C] bf16, kv [B,F,N,H*2C] bf16 (k | v per head), q_pts/k_pts [B,F,N,H,8,3], v_pts [B,F,N,H,12,3]
+      fp32 global frame, z [B,N,N,c_z] bf16, mask [B,F,N], hw [H]
+      -> o [B,F,N,H*C] bf16, o_pt [B,F,N,H,12,3] fp32 (global frame), o_pair [B,F,N,H*c_z/4] bf16."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw):
+        L = _lib.lib()
+        B, F, N, HC = q.shape
+        H = hw.shape[0]
+        C = HC // H
+        CZ = z.shape[-1]
+        PZ = w_dz.shape[0]
+        dev = q.device
+        q, kv, z = q.contiguous(), kv.contiguous(), z.contiguous()
+        q_pts, k_pts, v_pts = q_pts.contiguous(), k_pts.contiguous(), v_pts.contiguous()
+        mask = mask.contiguous().float()
+        hwc = hw.detach().contiguous()
+        wb, wdz = CACHE.w(w_b), CACHE.w(w_dz)
+        NN = N * N
+        # pair projections: bias_t [B,H,N,N] fp32, pzT [B,N,PZ,N] bf16, pz [B,N,N,PZ] bf16 (bias of linear_b drops out
+        # of the softmax; bias of down_z is added after the aggregation since sum_j P = 1)
+        bias_t = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
+        gemm(wb, z, bias_t, H, NN, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(NN), ldb=CZ, nbatch=B,
+             sb=(NN * CZ, 0), sc=(H * NN, 0))
+        pzT = torch.empty((B, N, PZ, N), dtype=BF16, device=dev)
+        gemm(wdz, z, pzT, PZ, N, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(N), ldb=CZ, nbatch=B * N, nb1=N,
+             sb=(NN * CZ, N * CZ), sc=(N * PZ * N, PZ * N))
+        pz = torch.empty((B, N, N, PZ), dtype=BF16, device=dev)
+        gemm(z, wdz, pz, B * NN, PZ, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(PZ), ldb=CZ)
+        # logits: S = sqrt(1/(3C)) q k^T  (:402-406)
+        P = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
+        gemm(q, kv, P, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=2 * HC, nbatch=B * F * H, nb1=H,
+             sa=(N * HC, C), sb=(N * 2 * HC, 2 * C), sc=(H * NN, NN), alpha=math.sqrt(1.0 / (3 * C)))
+        Pb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
+        check(L.dfold_ipa_softmax_fwd(_p(P), _p(bias_t), _p(q_pts), _p(k_pts), _p(mask), _p(hwc), _p(P), _p(Pb),
+                                      c_int32(B), c_int32(F), c_int32(N), c_int32(H), ctypes_float(math.sqrt(1.0 / 3)),
+                                      ctypes_float(1e5), stream()), "dfold_ipa_softmax_fwd")
+        # o = P v  (:452-457)
+        vT = ops.transpose_bf16(kv, N, C, ld_src=2 * HC, nbatch=B * F * H, nb1=H, bs_src=(N * 2 * HC, 2 * C), src_off=C)
+        o = torch.empty((B, F, N, HC), dtype=BF16, device=dev)
+        gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=B * F * H, nb1=H,
+             sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C))
+        # o_pt (fp32 VALU) (:460-469)
+        o_pt = torch.empty((B, F, N, H, 12, 3), dtype=torch.float32, device=dev)
+        check(L.dfold_ipa_opt_fwd(_p(P), _p(v_pts), _p(o_pt), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
+              "dfold_ipa_opt_fwd")
+        # o_pair[b,f,i,h,:] = sum_j P[b,f,h,i,j] pz[b,i,j,:] + b_dz   (:498-502): per (b,i) a [F*H, N] x [N, PZ] product
+        o_pair = torch.empty((B, F, N, H * PZ), dtype=BF16, device=dev)
+        gemm(Pb, pzT, o_pair, F * H, PZ, N, a_rows=rows_plain(NN), c_rows=rows_grid(PZ, H, F, F, N * H), ldb=N,
+             bias=b_dz.detach(), nbatch=B * N, nb1=N, sa=(F * H * NN, N), sb=(N * PZ * N, PZ * N),
+             sc=(F * N * H * PZ, H * PZ))
+        ctx.save_for_backward(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, P, Pb, pz)
+        ctx.dims = (B, F, N, H, C, CZ, PZ)
+        return o, o_pt, o_pair
+
+    @staticmethod
+    def backward(ctx, do, do_pt, do_pair):
+        L = _lib.lib()
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, P, Pb, pz = ctx.saved_tensors
+        B, F, N, H, C, CZ, PZ = ctx.dims
+        HC, NN, dev = H * C, N * N, q.device
+        alpha = math.sqrt(1.0 / (3 * C))
+        do, do_pair, do_pt = do.contiguous(), do_pair.contiguous(), do_pt.contiguous()
+        # dP = do v^T + do_pair pz^T
+        dP = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
+        gemm(do, kv, dP, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=2 * HC, nbatch=B * F * H, nb1=H,
+             sa=(N * HC, C), sb=(N * 2 * HC, 2 * C), sc=(H * NN, NN), b_off=C)
+        gemm(do_pair, pz, dP, F * H, N, PZ, a_rows=rows_grid(PZ, H, F, F, N * H), c_rows=rows_plain(NN), ldb=PZ,
+             nbatch=B * N, nb1=N, sa=(F * N * H * PZ, H * PZ), sb=(NN * PZ, N * PZ), sc=(F * H * NN, N),
+             flags=GEMM_ACCUM)
+        dSb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
+        dq_pts = torch.empty_like(q_pts)
+        dk_pts = torch.empty_like(k_pts)
+        dv_pts = torch.empty_like(v_pts)
+        dhw = torch.zeros(H, dtype=torch.float32, device=dev)
+        check(L.dfold_ipa_softmax_bwd(_p(P), _p(dP), _p(q_pts), _p(k_pts), _p(v_pts), _p(do_pt), _p(hw), _p(dP), _p(dSb),
+                                      _p(dq_pts), _p(dhw), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
+              "dfold_ipa_softmax_bwd")
+        dS = dP
+        check(L.dfold_ipa_col_bwd(_p(P), _p(dS), _p(q_pts), _p(k_pts), _p(do_pt), _p(hw), _p(dk_pts), _p(dv_pts),
+                                  c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()), "dfold_ipa_col_bwd")
+        nb = B * F * H
+        # dq = alpha dS k
+        kT = ops.transpose_bf16(kv, N, C, ld_src=2 * HC, nbatch=nb, nb1=H, bs_src=(N * 2 * HC, 2 * C))
+        dq = torch.empty_like(q)
+        gemm(dSb, kT, dq, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C), alpha=alpha)
+        # dk = alpha dS^T q ; dv = P^T do
+        dkv = torch.empty_like(kv)
+        dSbT = ops.transpose_bf16(dSb, N, N, nbatch=nb, nb1=1, bs_src=(NN, 0))
+        qT = ops.transpose_bf16(q, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
+        gemm(dSbT, qT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * 2 * HC, 2 * C), alpha=alpha)
+        del dSbT, qT
+        PbT = ops.transpose_bf16(Pb, N, N, nbatch=nb, nb1=1, bs_src=(NN, 0))
+        doT = ops.transpose_bf16(do, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
+        gemm(PbT, doT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * 2 * HC, 2 * C), c_off=C)
+        del PbT, doT
+        # pair-side gradients
+        FH = F * H
+        PbT2 = ops.transpose_bf16(Pb, FH, N, ld_src=NN, nbatch=B * N, nb1=N, bs_src=(FH * NN, N))       # [B,N(i),N(j),FH]
+        dop = do_pair.view(B, F, N, H, PZ).permute(0, 2, 1, 3, 4).contiguous()                          # [B,N,F,H,PZ]
+        dopT = ops.transpose_bf16(dop, FH, PZ, nbatch=B * N, nb1=1, bs_src=(FH * PZ, 0))                 # [B,N,PZ,FH]
+        dpz = torch.empty((B, N, N, PZ), dtype=BF16, device=dev)
+        gemm(PbT2, dopT, dpz, N, PZ, FH, a_rows=rows_plain(FH), c_rows=rows_plain(PZ), ldb=FH, nbatch=B * N, nb1=1,
+             sa=(N * FH, 0), sb=(PZ * FH, 0), sc=(N * PZ, 0))
+        del PbT2, dopT
+        db_hn = torch.empty((B, H, NN), dtype=BF16, device=dev)
+        db_nh = torch.empty((B, NN, 8), dtype=BF16, device=dev)
+        check(L.dfold_ipa_bias_grad(_p(dS), _p(db_hn), _p(db_nh), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                    ctypes_float(math.sqrt(1.0 / 3)), stream()), "dfold_ipa_bias_grad")
+        dz32 = torch.empty((B * NN, CZ), dtype=torch.float32, device=dev)
+        gemm(dpz, CACHE.wt(w_dz), dz32, B * NN, CZ, PZ, a_rows=rows_plain(PZ), c_rows=rows_plain(CZ), ldb=PZ)
+        gemm(db_nh, CACHE.wt(w_b), dz32, B * NN, CZ, 8, a_rows=rows_plain(8), c_rows=rows_plain(CZ), ldb=8,
+             flags=GEMM_ACCUM)
+        dz = ops.cast_bf16(dz32).view(z.shape)
+        del dz32
+        zT = _zT(z.view(B * NN, CZ))                                                                     # [CZ][B*NN]
+        dpzT = ops.transpose_bf16(dpz.view(B * NN, PZ), B * NN, PZ)                                      # [PZ][B*NN]
+        dw_dz = torch.empty((PZ, CZ), dtype=torch.float32, device=dev)
+        gemm(dpzT, zT, dw_dz, PZ, CZ, B * NN, a_rows=rows_plain(B * NN), c_rows=rows_plain(CZ), ldb=B * NN)
+        dw_b = torch.empty((H, CZ), dtype=torch.float32, device=dev)
+        gemm(db_hn, zT, dw_b, H, CZ, NN, nseg=B, a_rows=rows_plain(NN), c_rows=rows_plain(CZ), ldb=B * NN,
+             a_seg_off=ops.seg_table([b * H * NN for b in range(B)], dev))
+        db_dz = torch.zeros(PZ, dtype=torch.float32, device=dev)
+        ops.colsum_bf16(do_pair, db_dz, do_pair.numel() // PZ, PZ, PZ)
+        return dq, dkv, dq_pts, dk_pts, dv_pts, dz, dw_b, dw_dz, db_dz, None, dhw
+
+
+# ------------------------------------------------------------------------------------------------
+# IGSO(3) score series node
+# ------------------------------------------------------------------------------------------------
+
+class Igso3SeriesFn(Function):
+    """sc = dsig(omega)/(f(omega)+1e-4) (src/data/so3_diffuser.py:71-117); omega fp32 [W, ...], env fp64 [W, L]."""
+
+    @staticmethod
+    def forward(ctx, omega, env):
+        om = omega.contiguous()
+        W, L = env.shape
+        sc = torch.empty(om.shape, dtype=torch.float64, device=om.device)
+        dsc = torch.empty_like(sc)
+        check(_lib.lib().dfold_igso3_series(_p(om), _p(env), _p(sc), _p(dsc), c_int64(om.numel()),
+                                            c_int64(om.numel() // W), c_int32(L), stream()), "dfold_igso3_series")
+        ctx.save_for_backward(dsc)
+        return sc
+
+    @staticmethod
+    def backward(ctx, g):
+        (dsc,) = ctx.saved_tensors
+        return (g * dsc).float(), None

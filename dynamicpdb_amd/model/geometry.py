@@ -1,0 +1,110 @@
+"""Small-tensor geometry of the trunk (quaternion / rigid algebra, torsion frames -> atoms, score-head
+chain rules).  These act on [.., 3|4|7]-sized fp32 tensors (a few hundred KB per window); they are chained
+by autograd around the HIP nodes.  Semantics follow the reference files cited per function (paths under the
+reference tree)."""
+import math
+import os
+
+import numpy as np
+import torch
+
+
+def quat_to_rot(q):
+    """openfold/utils/rigid_utils.py:185-205 -- quadratic form, no normalisation."""
+    a, b, c, d = q.unbind(-1)
+    m = torch.stack([
+        a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c),
+        2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b),
+        2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d], -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+def quat_mul(p, q):
+    """openfold/utils/rigid_utils.py:230-263"""
+    a1, b1, c1, d1 = p.unbind(-1)
+    a2, b2, c2, d2 = q.unbind(-1)
+    return torch.stack([a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2, a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+                        a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2], -1)
+
+
+def quat_invert(q):
+    """openfold/utils/rigid_utils.py:282-286"""
+    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0]) / (q * q).sum(-1, keepdim=True)
+
+
+def rot_apply(R, x):
+    """openfold/utils/rigid_utils.py:82-106"""
+    return (R * x[..., None, :]).sum(-1)
+
+
+def compose_q_update_vec(t7, upd6, mask):
+    """Rigid.compose_q_update_vec (openfold/utils/rigid_utils.py:1039-1063, Rotation :587-616, normalisation :331-332)."""
+    q, t = t7[..., :4], t7[..., 4:]
+    zero = torch.zeros_like(upd6[..., :1])
+    dq = quat_mul(q, torch.cat([zero, upd6[..., :3]], -1)) * mask
+    qn = q + dq
+    qn = qn / torch.linalg.norm(qn, dim=-1, keepdim=True)
+    dt = rot_apply(quat_to_rot(q), upd6[..., 3:]) * mask
+    return torch.cat([qn, t + dt], -1)
+
+
+def quat_to_rotvec(quat, eps=1e-6):
+    """src/data/utils.py:589-606"""
+    flip = (quat[..., :1] < 0).to(quat.dtype)
+    quat = quat * (1 - 2 * flip)
+    angle = 2 * torch.atan2(torch.linalg.norm(quat[..., 1:], dim=-1), quat[..., 0])
+    a2 = angle * angle
+    small = 2 + a2 / 12 + 7 * a2 * a2 / 2880
+    large = angle / torch.sin(angle / 2 + eps)
+    is_small = (angle <= 1e-3).to(quat.dtype)
+    scale = small * is_small + (1 - is_small) * large
+    return scale[..., None] * quat[..., 1:]
+
+
+_TABLES = {}
+
+
+def residue_tables(device):
+    t = _TABLES.get(device)
+    if t is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data", "residue_tables.npz")
+        d = np.load(path)
+        t = {k: torch.tensor(d[k]).to(device) for k in d.files}
+        _TABLES[device] = t
+    return t
+
+
+def frames_to_atoms(t7, angles, aatype):
+    """feats.torsion_angles_to_frames (openfold/utils/feats.py:165-228) + all_atom.frames_to_atom14_pos
+    (src/data/all_atom.py:114-154) + atom14_to_atom37 (src/model/Dfold_network_dynamic.py:574-594).
+    t7 [..,7], angles [..,7,2] (sin,cos), aatype [..] int64 -> atom14 [..,14,3], atom37 [..,37,3].
+    Integer gathers use the reference's own tables (dynamicpdb_amd/data/residue_tables.npz)."""
+    T = residue_tables(t7.device)
+    dt = t7.dtype
+    d44 = T["default_frames"][aatype].to(dt)
+    Rd, td = d44[..., :3, :3], d44[..., :3, 3]
+    bb = torch.zeros(angles.shape[:-2] + (1, 2), dtype=dt, device=t7.device)
+    bb[..., 1] = 1
+    al = torch.cat([bb, angles], -2)
+    Rt = torch.zeros(al.shape[:-1] + (3, 3), dtype=dt, device=t7.device)
+    Rt[..., 0, 0] = 1
+    Rt[..., 1, 1] = al[..., 1]
+    Rt[..., 1, 2] = -al[..., 0]
+    Rt[..., 2, 1] = al[..., 0]
+    Rt[..., 2, 2] = al[..., 1]
+    Rf = Rd @ Rt
+    R_l, t_l = [Rf[..., i, :, :] for i in range(8)], [td[..., i, :] for i in range(8)]
+    for i in (5, 6, 7):
+        R_l[i], t_l[i] = R_l[i - 1] @ R_l[i], rot_apply(R_l[i - 1], t_l[i]) + t_l[i - 1]
+    Rb, tb = torch.stack(R_l, -3), torch.stack(t_l, -2)
+    Rg = quat_to_rot(t7[..., :4])[..., None, :, :]
+    Rall, tall = Rg @ Rb, rot_apply(Rg, tb) + t7[..., None, 4:]
+    grp = T["atom14_group"][aatype]
+    Ra = torch.gather(Rall, -3, grp[..., None, None].expand(grp.shape + (3, 3)))
+    ta = torch.gather(tall, -2, grp[..., None].expand(grp.shape + (3,)))
+    pos = rot_apply(Ra, T["atom14_pos"][aatype].to(dt)) + ta
+    atom14 = pos * T["atom14_mask"][aatype].to(dt)[..., None]
+    i37 = T["atom37_to_atom14"][aatype]
+    atom37 = torch.gather(atom14, -2, i37[..., None].expand(i37.shape + (3,)))
+    atom37 = atom37 * T["atom37_mask"][aatype].to(dt)[..., None]
+    return atom14, atom37

@@ -1,0 +1,284 @@
+"""Drop-in operators for the reference's src/model/ipa_pytorch_dynamic.py: same class names, constructor
+arguments, forward signatures, output keys and state_dict key names / shapes -- backed by the MI355X engine
+(libdfold_hip.so).  Every module also accepts a leading window (batch) axis, which the reference lacks
+(its per-rank batch is one window, train_DFOLD_dynamics.py:551,680-684); statistics stay per window.
+
+Operators: InvariantPointAttention (:242-516), ConvNet (:664-706), BackboneUpdate (:575-602),
+MyLayerNorm (:709-724), AngleResnet (openfold/model/structure_module.py:47-158), DFOLDIpaScore (:726-907).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as Fn
+
+from .. import _lib, ops
+from ..ops import BF16
+from ..rigid import Rigid
+from . import functional as F_
+from . import geometry as G
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("dynamicpdb_amd operators run on an MI355X device tensor (no CPU fallback); "
+                           "the CPU restatement lives in oracle/ and is test-only")
+
+
+class MyLayerNorm(nn.Module):
+    """(x - mean_all) / sqrt(var_all_unbiased + 1e-4) over one window's whole [F,N,C] tensor."""
+
+    def __init__(self):
+        super().__init__()
+        self.eps = 1e-4
+
+    def forward(self, x):
+        _require_cuda(x)
+        batched = x.dim() == 4
+        xb = x if batched else x[None]
+        eye = torch.eye(xb.shape[-1], device=x.device)
+        zero = torch.zeros(xb.shape[-1], device=x.device)
+        y = F_.linear_gln(xb.to(BF16), eye, zero, False)   # standalone use: identity projection + fused norm
+        y = y.to(x.dtype)
+        return y if batched else y[0]
+
+
+class ConvNet(nn.Module):
+    """4 x [x = ReLU(conv5x5(ReLU(conv5x5(x)))) + x] over the frame x residue grid (1280 <-> 640 channels)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        for i in (1, 2, 3, 4):
+            setattr(self, f"conv{i}", nn.Sequential(
+                nn.Conv2d(dim, dim // 2, kernel_size=5, stride=1, padding=2, bias=True), nn.ReLU(),
+                nn.Conv2d(dim // 2, dim, kernel_size=5, stride=1, padding=2, bias=True), nn.ReLU()))
+        self._tower = None
+
+    def _params(self):
+        ws, bs = [], []
+        for i in (1, 2, 3, 4):
+            seq = getattr(self, f"conv{i}")
+            ws += [seq[0].weight, seq[2].weight]
+            bs += [seq[0].bias, seq[2].bias]
+        return ws, bs
+
+    def tower(self):
+        ws, bs = self._params()
+        if self._tower is None or self._tower.weights[0].data_ptr() != ws[0].data_ptr():
+            self._tower = ops.ConvTower(ws, bs)
+        return self._tower
+
+    def run(self, x):
+        """x bf16 [W,F,N,C] -> bf16 [W,F,N,C]"""
+        ws, bs = self._params()
+        inter = [p for pair in zip(ws, bs) for p in pair]
+        return F_.ConvTowerFn.apply(x, self.tower(), *inter)
+
+    def forward(self, x):
+        _require_cuda(x)
+        batched = x.dim() == 4
+        xb = x if batched else x[None]
+        y = self.run(xb.to(BF16)).to(x.dtype)
+        return y if batched else y[0]
+
+
+class BackboneUpdate(nn.Module):
+    def __init__(self, c_s):
+        super().__init__()
+        self.c_s = c_s
+        self.linear = nn.Linear(c_s, 6)
+        with torch.no_grad():
+            self.linear.weight.zero_()
+            self.linear.bias.zero_()
+
+    def forward(self, s):
+        _require_cuda(s)
+        return F_.linear(s.to(BF16), self.linear.weight, self.linear.bias, out_fp32=True)
+
+
+class AngleResnetBlock(nn.Module):
+    def __init__(self, c_hidden):
+        super().__init__()
+        self.linear_1 = nn.Linear(c_hidden, c_hidden)
+        self.linear_2 = nn.Linear(c_hidden, c_hidden)
+
+
+class AngleResnet(nn.Module):
+    """openfold/model/structure_module.py:75-158"""
+
+    def __init__(self, c_in, c_hidden, no_blocks, no_angles, epsilon):
+        super().__init__()
+        self.c_in, self.c_hidden, self.no_blocks, self.no_angles, self.eps = c_in, c_hidden, no_blocks, no_angles, epsilon
+        self.linear_in = nn.Linear(c_in, c_hidden)
+        self.linear_initial = nn.Linear(c_in, c_hidden)
+        self.layers = nn.ModuleList([AngleResnetBlock(c_hidden) for _ in range(no_blocks)])
+        self.linear_out = nn.Linear(c_hidden, no_angles * 2)
+
+    def forward(self, s, s_initial):
+        _require_cuda(s)
+        s, s_initial = s.to(BF16), s_initial.to(BF16)
+        a = F_.linear(torch.relu(s), self.linear_in.weight, self.linear_in.bias) + \
+            F_.linear(torch.relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
+        for l in self.layers:
+            h = F_.linear(torch.relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
+            a = a + F_.linear(h, l.linear_2.weight, l.linear_2.bias)
+        out = F_.linear(torch.relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
+        out = out.view(out.shape[:-1] + (-1, 2))
+        unnorm = out
+        denom = torch.sqrt(torch.clamp(torch.sum(out ** 2, dim=-1, keepdim=True), min=self.eps))
+        return unnorm, out / denom
+
+
+class InvariantPointAttention(nn.Module):
+    def __init__(self, ipa_conf, inf: float = 1e5, eps: float = 1e-8):
+        super().__init__()
+        self._ipa_conf = ipa_conf
+        self.c_s, self.c_z, self.c_hidden = ipa_conf.c_s, ipa_conf.c_z, ipa_conf.c_hidden
+        self.no_heads, self.no_qk_points, self.no_v_points = ipa_conf.no_heads, ipa_conf.no_qk_points, ipa_conf.no_v_points
+        self.inf, self.eps = inf, eps
+        if self.no_qk_points != 8 or self.no_v_points != 12 or inf != 1e5:
+            raise ValueError("the HIP attention core is built for no_qk_points=8, no_v_points=12, inf=1e5")
+        hc = self.c_hidden * self.no_heads
+        self.linear_q = nn.Linear(self.c_s, hc)
+        self.linear_kv = nn.Linear(self.c_s, 2 * hc)
+        self.linear_q_points = nn.Linear(self.c_s, self.no_heads * self.no_qk_points * 3)
+        self.linear_kv_points = nn.Linear(self.c_s, self.no_heads * (self.no_qk_points + self.no_v_points) * 3)
+        self.linear_b = nn.Linear(self.c_z, self.no_heads)
+        self.down_z = nn.Linear(self.c_z, self.c_z // 4)
+        self.head_weights = nn.Parameter(torch.full((self.no_heads,), 0.541324854612918))
+        concat_out_dim = self.c_z // 4 + self.c_hidden + self.no_v_points * 4
+        self.linear_out = nn.Linear(self.no_heads * (concat_out_dim + self.no_v_points * 4), self.c_s)
+        self.linear_rbf = nn.Linear(20, 1)      # unused in the reference forward (:311); kept for state_dict parity
+        with torch.no_grad():
+            self.linear_out.weight.zero_()
+            self.linear_out.bias.zero_()
+
+    def features(self, s, z, t7, mask):
+        """s bf16 [B,F,N,c_s], z bf16 [B,N,N,c_z], t7 fp32 [B,F,N,7], mask [B,F,N] -> bf16 [B,F,N,H*(...)]  (:350-504)"""
+        B, Fr, N, _ = s.shape
+        H, PQ, PV = self.no_heads, self.no_qk_points, self.no_v_points
+        q = F_.linear(s, self.linear_q.weight, self.linear_q.bias)
+        kv = F_.linear(s, self.linear_kv.weight, self.linear_kv.bias)
+        qp = F_.linear(s, self.linear_q_points.weight, self.linear_q_points.bias, out_fp32=True)
+        kvp = F_.linear(s, self.linear_kv_points.weight, self.linear_kv_points.bias, out_fp32=True)
+        R = G.quat_to_rot(t7[..., :4])                    # [B,F,N,3,3]
+        tr = t7[..., 4:]
+
+        def to_global(raw, npts):
+            xyz = torch.stack(torch.chunk(raw, 3, dim=-1), -1)            # [B,F,N,H*npts,3]
+            glob = G.rot_apply(R[..., None, :, :], xyz) + tr[..., None, :]
+            return glob.view(B, Fr, N, H, npts, 3)
+
+        q_pts = to_global(qp, PQ)
+        kv_pts = to_global(kvp, PQ + PV)
+        k_pts, v_pts = kv_pts[..., :PQ, :].contiguous(), kv_pts[..., PQ:, :].contiguous()
+        hw = Fn.softplus(self.head_weights) * math.sqrt(1.0 / (3 * (PQ * 9.0 / 2)))
+        o, o_pt_g, o_pair = F_.IpaCoreFn.apply(q, kv, q_pts, k_pts, v_pts, z, self.linear_b.weight, self.down_z.weight,
+                                               self.down_z.bias, mask, hw)
+        o_pt_l = G.rot_apply(R.transpose(-1, -2)[..., None, None, :, :], o_pt_g - tr[..., None, None, :])  # :481
+        n_l = torch.sqrt((o_pt_l ** 2).sum(-1) + self.eps).reshape(B, Fr, N, H * PV)
+        n_g = torch.sqrt((o_pt_g ** 2).sum(-1) + self.eps).reshape(B, Fr, N, H * PV)
+        o_pt_l = o_pt_l.reshape(B, Fr, N, H * PV, 3)
+        o_pt_gf = o_pt_g.reshape(B, Fr, N, H * PV, 3)
+        geo = torch.cat([o_pt_l[..., 0], o_pt_l[..., 1], o_pt_l[..., 2], n_l], -1).to(BF16)
+        geo_g = torch.cat([o_pt_gf[..., 0], o_pt_gf[..., 1], o_pt_gf[..., 2], n_g], -1).to(BF16)
+        return torch.cat([o, geo, o_pair, geo_g], -1)                                                       # :504
+
+    def forward(self, s, z, r, mask, _offload_inference=False, _z_reference_list=None):
+        """Reference signature: s [*,N,c_s], z [N,N,c_z] (no frame axis), r Rigid [*,N], mask [*,N] -> [*,N,c_s]."""
+        _require_cuda(s)
+        t7 = r.to_tensor_7() if isinstance(r, Rigid) else r
+        batched = s.dim() == 4
+        if not batched:
+            s, z, t7, mask = s[None], z[None], t7[None], mask[None]
+        feats = self.features(s.to(BF16), z.to(BF16), t7.float(), mask.float())
+        out = F_.linear(feats, self.linear_out.weight, self.linear_out.bias, out_fp32=True)
+        return out if batched else out[0]
+
+
+def _embedder(k, d):
+    return nn.Sequential(nn.Linear(k, d), nn.SiLU(), nn.Linear(d, d), MyLayerNorm(), nn.SiLU())
+
+
+class DFOLDIpaScore(nn.Module):
+    def __init__(self, model_conf, diffuser):
+        super().__init__()
+        self._model_conf = model_conf
+        ipa_conf = model_conf.ipa
+        self._ipa_conf = ipa_conf
+        self.diffuser = diffuser
+        self.scale_pos = lambda x: x * ipa_conf.coordinate_scaling
+        self.unscale_pos = lambda x: x / ipa_conf.coordinate_scaling
+        self.trunk = nn.ModuleDict()
+        for b in range(ipa_conf.num_blocks):
+            self.trunk[f'ipa_{b}'] = InvariantPointAttention(ipa_conf)
+            self.trunk[f'ln_{b}'] = MyLayerNorm()
+            self.trunk[f'bb_update_{b}'] = BackboneUpdate(ipa_conf.c_s * 5)
+        self.trunk['conv_0'] = ConvNet(ipa_conf.c_s * 5)
+        self.angle_resnet = AngleResnet(c_in=ipa_conf.c_s * 5, c_hidden=ipa_conf.c_s * 5, no_blocks=2, no_angles=7,
+                                        epsilon=1e-12)
+        d = model_conf.node_embed_size
+        self.force_embeder = _embedder(3, d)
+        self.vel_embeder = _embedder(3, d)
+        self.index_embeder = _embedder(1, d)
+        self.rigid_embeder = _embedder(7, d)
+        self.angle_embeder = _embedder(14, d)
+
+    def unscale_rigids(self, t7):
+        return torch.cat([t7[..., :4], self.unscale_pos(t7[..., 4:])], -1)
+
+    @staticmethod
+    def _embed(seq, x):
+        """Linear-SiLU-Linear-MyLayerNorm-SiLU (:757-796); x fp32 [B,F',N,k] -> bf16 [B,F',N,d]."""
+        h = Fn.silu(Fn.linear(x, seq[0].weight, seq[0].bias)).to(BF16)     # k <= 14: negligible work
+        return F_.linear_gln(h, seq[2].weight, seq[2].bias, True)
+
+    @staticmethod
+    def _shift_last(x):
+        """cat([x[:-1], x[-2:-1]]) along the frame axis (axis 1 of the batched layout) (:819,822,826,842)"""
+        return torch.cat([x[:, :-1], x[:, -2:-1]], 1)
+
+    def forward(self, init_node_embed, edge_embed, input_feats, drop_ref=False):
+        """Batched mirror of the reference forward (:798-907).  All per-window tensors in `input_feats` carry a
+        leading window axis here ([B,F,N,..], node/edge repr [B,N,..], t [B]); FullScoreNetwork adds it for
+        reference-shaped inputs.  init_node_embed / edge_embed are ignored exactly like the reference (:829-834)."""
+        f32 = torch.float32
+        node_mask = input_feats['res_mask'].to(f32)
+        diffuse_mask = (1 - input_feats['fixed_mask'].to(f32)) * node_mask
+        rigids_t = input_feats['rigids_t'].to(f32)
+        rig0 = input_feats['rigids_0'].to(f32)
+        B, Fr, N = node_mask.shape
+        curr_rigids = self._shift_last(rig0)
+        force_embed = self._embed(self.force_embeder, self._shift_last(input_feats['force'].to(f32)))
+        vel_embed = self._embed(self.vel_embeder, self._shift_last(input_feats['vel'].to(f32)))
+        idx = input_feats['seq_idx'][:, 0:1].unsqueeze(-1).to(f32)                         # [B,1,N,1]
+        idx_embed = self._embed(self.index_embeder, idx)                                   # [B,1,N,d]
+        node_embed = (idx_embed.float() + input_feats['expand_node_repr'].float()[:, None]).to(BF16)
+        node_embed = node_embed.expand(B, Fr, N, node_embed.shape[-1]).contiguous()
+        edge = input_feats['expand_edge_repr']                                             # bf16 [B,N,N,c_z]
+        angle = input_feats['torsion_angles_sin_cos'].to(f32) * input_feats['torsion_angles_mask'].to(f32).unsqueeze(-1)
+        angle = self._shift_last(angle).reshape(B, Fr, N, -1)
+        angle_embed = self._embed(self.angle_embeder, angle)
+        conv = self.trunk['conv_0']
+        node_feat = init_node_feat = rigid_update = None
+        for b in range(self._ipa_conf.num_blocks):
+            rigids_embed = self._embed(self.rigid_embeder, curr_rigids)
+            ipa = self.trunk[f'ipa_{b}']
+            feats = ipa.features(node_embed, edge, curr_rigids, node_mask)
+            ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
+            node_feat = torch.cat([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], dim=-1)
+            node_feat = conv.run(node_feat)
+            rigid_update = self.trunk[f'bb_update_{b}'](node_feat)
+            rigid_update = torch.cat([rigid_update[:, :-1] * 0.0, rigid_update[:, -1:]], 1)      # :869
+            curr_rigids = G.compose_q_update_vec(curr_rigids, rigid_update, diffuse_mask[..., None])
+            if b == 0:
+                init_node_feat = node_feat
+        unorm_angles, angles = self.angle_resnet(node_feat, init_node_feat)
+        t = input_feats['t'].reshape(B)
+        rot_score = self.diffuser.calc_rot_score_t7(rigids_t[..., :4], curr_rigids[..., :4], t) * node_mask[..., None]
+        curr_rigids = self.unscale_rigids(curr_rigids)
+        trans_score = self.diffuser.calc_trans_score(rigids_t[..., 4:], curr_rigids[..., 4:], t[:, None, None, None],
+                                                     use_torch=True) * node_mask[..., None]
+        return {'angles': angles, 'unorm_angles': unorm_angles, 'rot_score': rot_score, 'trans_score': trans_score,
+                'final_rigids': curr_rigids, 'rigid_update': rigid_update}

@@ -86,15 +86,19 @@ def cast_f32(x):
     return out
 
 
-def transpose_bf16(src, R, C, ld_src=None, out=None, nbatch=1, bs_src=0, bs_dst=0, ld_dst=None):
-    """dst[b][c][r] = src[b][r][c]"""
+def transpose_bf16(src, R, C, ld_src=None, out=None, nbatch=1, nb1=1, bs_src=(0, 0), bs_dst=None, ld_dst=None,
+                   src_off=0):
+    """dst[z][c][r] = src[z][r][c]; batch z -> (z // nb1, z % nb1) with element strides bs_src / bs_dst."""
     ld_src = C if ld_src is None else ld_src
     ld_dst = R if ld_dst is None else ld_dst
+    if isinstance(bs_src, int):
+        bs_src = (bs_src * nb1, bs_src)
     if out is None:
         out = torch.empty((nbatch, C, R) if nbatch > 1 else (C, R), dtype=BF16, device=src.device)
-        bs_dst = C * R
-    check(_lib.lib().dfold_transpose_bf16(_p(src), _p(out), c_int32(R), c_int32(C), c_int64(ld_src), c_int64(ld_dst),
-                                          c_int32(nbatch), c_int64(bs_src), c_int64(bs_dst), stream()),
+        bs_dst = (C * R * nb1, C * R)
+    check(_lib.lib().dfold_transpose_bf16(_p(src, src_off), _p(out), c_int32(R), c_int32(C), c_int64(ld_src),
+                                          c_int64(ld_dst), c_int32(nbatch), c_int32(nb1), c_int64(bs_src[0]),
+                                          c_int64(bs_src[1]), c_int64(bs_dst[0]), c_int64(bs_dst[1]), stream()),
           "dfold_transpose_bf16")
     return out
 
@@ -258,6 +262,27 @@ class ConvTower:
         self.dwg = [torch.zeros((w.shape[0], 25, w.shape[1]), dtype=torch.float32, device=dev) for w in weights]
         self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
         self.ws = Workspace(dev)
+        self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
+        self._stamp = None
+
+    def refresh(self):
+        """re-pack the bf16 operands if any fp32 parameter changed (optimizer step / load_state_dict)."""
+        stamp = tuple((w.data_ptr(), w._version) for w in self.weights)
+        if stamp != self._stamp:
+            self.pack()
+            self._stamp = stamp
+
+    def collect_grads(self):
+        """[dW0, db0, dW1, db1, ...] in the reference parameter layout; resets the accumulators."""
+        L = _lib.lib()
+        out = []
+        for w, dwg, db in zip(self.weights, self.dwg, self.db):
+            gw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(gw), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
+                                            stream()), "dfold_conv_wgrad_unpack")
+            out += [gw, db.clone()]
+        self.zero_grad()
+        return out
 
     def pack(self):
         L = _lib.lib()

@@ -117,8 +117,7 @@ class Rigid:
         return Rigid(self._rots, fn(self._trans))
 
     def compose_q_update_vec(self, q_update_vec, update_mask=None):
-        from . import ops
+        from .model import geometry
         if update_mask is None:
             update_mask = torch.ones_like(q_update_vec[..., :1])
-        t7 = ops.compose_q_update(self.to_tensor_7(), q_update_vec, update_mask)
-        return Rigid.from_tensor_7(t7)
+        return Rigid.from_tensor_7(geometry.compose_q_update_vec(self.to_tensor_7(), q_update_vec, update_mask))

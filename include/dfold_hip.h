@@ -91,9 +91,54 @@ int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, in
 int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream);
 /* out = v > 0 ? g : 0  (bf16) */
 int dfold_relu_mask_bf16(const void* g, const void* v, void* out, int64_t n, void* stream);
-/* batched 2-D transpose dst[b][c][r] = src[b][r][c] (bf16; strides in elements) */
+/* batched 2-D transpose dst[z][c][r] = src[z][r][c] (bf16; strides in elements; batch z -> (z / nb1, z % nb1)) */
 int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst,
-                         int32_t nbatch, int64_t bs_src, int64_t bs_dst, void* stream);
+                         int32_t nbatch, int32_t nb1, int64_t bs_src0, int64_t bs_src1, int64_t bs_dst0,
+                         int64_t bs_dst1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MyLayerNorm (src/model/ipa_pytorch_dynamic.py:709-724): whole-window statistics, unbiased variance,
+ * eps inside the sqrt, no affine; optional fused SiLU (embedders :757-796).  x fp32 [W][n] -> y bf16.
+ * stats: caller workspace of 2*W doubles; mean_rstd: 2*W floats kept for the backward.
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_gln_fwd(const float* x, double* stats, void* y_bf16, float* mean_rstd, int32_t W, int64_t n, float eps,
+                  int32_t silu, void* stream);
+int dfold_gln_bwd(const float* x, const void* g_bf16, const float* mean_rstd, double* stats, void* dx_bf16, int32_t W,
+                  int64_t n, int32_t silu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Invariant Point Attention core (InvariantPointAttention.forward, src/model/ipa_pytorch_dynamic.py:396-469).
+ * Layouts: S / P / dP / dS fp32 [B,F,H,N,N]; bias fp32 [B,H,N,N] (linear_b(z) :396, head-major);
+ * q_pts,k_pts [B,F,N,H,8,3], v_pts / o_pt [B,F,N,H,12,3] fp32 in the GLOBAL frame (:363-390);
+ * mask [B,F,N]; hw[H] = softplus(head_weights) * sqrt(1/(3*(Pq*9/2))) (:415-421).
+ * ---------------------------------------------------------------------------------------------- */
+/* P = softmax_j(S + bias_scale*bias - 0.5*hw*|q_pts_i - k_pts_j|^2 + inf*(m_i m_j - 1))  (:407-444) */
+int dfold_ipa_softmax_fwd(const float* S, const float* bias, const float* q_pts, const float* k_pts, const float* mask,
+                          const float* hw, float* P, void* P_bf16, int32_t B, int32_t F, int32_t N, int32_t H,
+                          float bias_scale, float inf, void* stream);
+/* o_pt[b,f,i,h,:] = sum_j P[b,f,h,i,j] v_pts[b,f,j,h,:]  (:460-469) */
+int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt, int32_t B, int32_t F, int32_t N, int32_t H,
+                      void* stream);
+/* row pass of the backward: dS, dq_pts, dhw (dhw accumulated atomically: zero it first) */
+int dfold_ipa_softmax_bwd(const float* P, const float* dP, const float* q_pts, const float* k_pts, const float* v_pts,
+                          const float* do_pt, const float* hw, float* dS, void* dS_bf16, float* dq_pts, float* dhw,
+                          int32_t B, int32_t F, int32_t N, int32_t H, void* stream);
+/* column pass of the backward: dk_pts, dv_pts */
+int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
+                      const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,
+                      void* stream);
+/* dbias = scale * sum_f dS, bf16, as [B][H][N*N] and as [B][N*N][8] (H zero-padded to 8) */
+int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, int32_t F, int32_t N, int32_t H,
+                        float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * IGSO(3) score series (SO3Diffuser.torch_score src/data/so3_diffuser.py:274-305, igso3_expansion :9-49,
+ * score :71-117): sc[p] = dsig(omega_p)/(f(omega_p)+1e-4) with the reference's fp32-trig / fp64-envelope
+ * mixed precision, plus dsc = d sc / d omega for the backward.  env fp64 [windows][L] = (2l+1)exp(-l(l+1)s^2/2);
+ * element p belongs to window p / per_window (P % per_window == 0).
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_igso3_series(const float* omega, const double* env, double* sc, double* dsc, int64_t P, int64_t per_window,
+                       int32_t L, void* stream);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,37 @@ def _torch_tower(x, ws, bs):
     return h
 
 
+def _bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+def _emulated_tower(x, ws, bs, gy, engine_saved=None):
+    """fp64 forward/backward of the tower with bf16 rounding at exactly the points where the engine stores
+    bf16 (activations, activation gradients); weights already bf16-rounded.  Returns (h4, g0, dWs, dbs)."""
+    import torch.nn.functional as Fn
+    from torch.nn.grad import conv2d_input, conv2d_weight
+    h, saved = x, []
+    for i in range(4):
+        u = _bf(torch.relu(Fn.conv2d(h, ws[2 * i], bs[2 * i], padding=2)))
+        pre = torch.relu(Fn.conv2d(u, ws[2 * i + 1], bs[2 * i + 1], padding=2))
+        v, hn = _bf(pre), _bf(pre + h)
+        saved.append((h, u, v))
+        h = hn
+    if engine_saved is not None:      # backward on the engine's own stored activations (identical ReLU masks)
+        saved = engine_saved
+    g, dW, db = gy, [None] * 8, [None] * 8
+    for i in (3, 2, 1, 0):
+        hp, u, v = saved[i]
+        dv = g * (v > 0)
+        dW[2 * i + 1] = conv2d_weight(u, ws[2 * i + 1].shape, dv, padding=2)
+        db[2 * i + 1] = dv.sum((0, 2, 3))
+        du = _bf(conv2d_input(u.shape, ws[2 * i + 1], dv, padding=2) * (u > 0))
+        dW[2 * i] = conv2d_weight(hp, ws[2 * i].shape, du, padding=2)
+        db[2 * i] = du.sum((0, 2, 3))
+        g = _bf(conv2d_input(hp.shape, ws[2 * i], du, padding=2) + g)
+    return h, g, dW, db
+
+
 @pytest.mark.parametrize("Wn,F,N,C", [(2, 3, 16, 128), (1, 5, 40, 64)])
 def test_conv_tower_fwd_bwd_vs_torch(dev, Wn, F, N, C):
     from dynamicpdb_amd import ops
@@ -89,28 +120,40 @@ def test_conv_tower_fwd_bwd_vs_torch(dev, Wn, F, N, C):
     bs = [b.requires_grad_(True) for b in bs]
     x = torch.randn(Wn, F, N, C, device=dev).to(torch.bfloat16)
     gy = torch.randn(Wn, F, N, C, device=dev).to(torch.bfloat16)
-    # reference in fp64 on bf16-rounded weights / inputs
-    wr = [w.detach().to(torch.bfloat16).double().requires_grad_(True) for w in ws]
-    br = [b.detach().double().requires_grad_(True) for b in bs]
-    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
-    yr = _torch_tower(xr, wr, br)
-    yr.backward(gy.double().permute(0, 3, 1, 2))
     tower = ops.ConvTower(ws, bs)
     tower.pack()
     g = ops.Grid(Wn, F, N, dev)
     h0 = g.alloc(C)
     g.interior(h0).copy_(x)
     h4, saved = tower.forward(g, h0)
-    assert rel_l2(g.interior(h4), yr.permute(0, 2, 3, 1)) < 1e-2
-    assert float(h4[:, :2].abs().max()) == 0 and float(h4[:, :, :2].abs().max()) == 0   # border stays zero
     gt = g.alloc(C)
     g.interior(gt).copy_(gy)
     g0 = tower.backward(g, saved, gt)
     tower.finalize_grads()
-    assert rel_l2(g.interior(g0), xr.grad.permute(0, 2, 3, 1)) < 2e-2
+    assert float(h4[:, :2].abs().max()) == 0 and float(h4[:, :, :2].abs().max()) == 0   # border stays zero
+    # (a) kernel-logic check: reference with the engine's bf16 storage points emulated -> tight tolerance
+    wq = [w.detach().to(torch.bfloat16).double() for w in ws]
+    bq = [b.detach().double() for b in bs]
+    nchw = lambda t: g.interior(t).double().permute(0, 3, 1, 2)
+    eng = [(nchw(saved[3 * i]), nchw(saved[3 * i + 1]), nchw(saved[3 * i + 2])) for i in range(4)]
+    he, ge, dWe, dbe = _emulated_tower(x.double().permute(0, 3, 1, 2), wq, bq, gy.double().permute(0, 3, 1, 2), eng)
+    # (bf16 re-rounding of values that differ in the last fp32 bits leaves ~1e-3..1e-2 relative noise)
+    assert rel_l2(g.interior(h4), he.permute(0, 2, 3, 1)) < 5e-3
+    assert rel_l2(g.interior(g0), ge.permute(0, 2, 3, 1)) < 1e-2
     for i in range(8):
-        assert rel_l2(ws[i].grad, wr[i].grad) < 2e-2, i
-        assert rel_l2(bs[i].grad, br[i].grad) < 2e-2, i
+        # a ReLU mask that flips on a pre-activation within rounding of 0 changes single terms of these short sums
+        assert rel_l2(ws[i].grad, dWe[i]) < 1e-2, i
+        assert rel_l2(bs[i].grad, dbe[i]) < 1e-2, i
+    # (b) against exact fp64 autograd (no storage rounding): bf16-path tolerance (ReLU masks may flip)
+    wr = [w.clone().requires_grad_(True) for w in wq]
+    br = [b.clone().requires_grad_(True) for b in bq]
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = _torch_tower(xr, wr, br)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    assert rel_l2(g.interior(h4), yr.permute(0, 2, 3, 1)) < 1e-2
+    assert rel_l2(g.interior(g0), xr.grad.permute(0, 2, 3, 1)) < 0.15   # toy sizes: ReLU mask flips dominate
+    for i in range(8):
+        assert rel_l2(ws[i].grad, wr[i].grad) < 0.15, i     # 96-term sums, mask flips dominate at this toy size
 
 
 def test_convnet_vs_oracle_golden(dev):

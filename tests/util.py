@@ -14,13 +14,13 @@ def load_golden(name):
 
 
 def rel_l2(a, b):
-    a = torch.as_tensor(a).detach().double().reshape(-1)
-    b = torch.as_tensor(b).detach().double().reshape(-1)
+    a = torch.as_tensor(a).detach().cpu().double().reshape(-1)
+    b = torch.as_tensor(b).detach().cpu().double().reshape(-1)
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
 def max_abs(a, b):
-    return float((torch.as_tensor(a).detach().double() - torch.as_tensor(b).detach().double()).abs().max())
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
 
 
 def canon_quat(t7):
