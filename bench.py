@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Bench contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one
+rank per GPU over RCCL).  A "step" is one update_fn of the DFOLDv2 trajectory-prediction path (zero_grad, forward,
+loss, backward, gradient all-reduce, Adam/amsgrad step) on one batch of synthetic trajectory windows per rank
+(weak scaling).  Rank 0 prints ONE JSON line:
+
+  metric = trajectory frames/s (fwd+bwd) at N_res=256; value = windows*frames of all ranks / max-over-ranks time;
+  roofline = the dominant kernel (5x5 conv implicit GEMM, bf16 MFMA) vs the dense bf16 MFMA peak;
+  cpu_baseline = the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def T(L):
+    return 5 * L - 6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=8, help="trajectory windows per GPU (BASELINE config 3: 8)")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--nres", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+def make_batch(synthetic, diffuser, B, F, N, rank, dev):
+    ws = [synthetic.synthetic_window(1000 * rank + i, F, N, t=0.5, diffuser=diffuser) for i in range(B)]
+    batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0] if k != "t"}
+    batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
+    return batch
+
+
+def conv_kernel_roofline(model, trainer, batch, B, F, N):
+    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_mfma_gemm_kernel<1>)
+    of ONE extra, instrumented step, measured with HIP events on the stream the kernels are launched on."""
+    from dynamicpdb_amd import ops
+    events = []
+    orig = ops.gemm
+
+    def timed_gemm(*a, **kw):
+        rows = kw.get("a_rows")
+        is_conv = rows is not None and rows.mode == 1 and kw.get("nseg", 1) == 25
+        if not is_conv:
+            return orig(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(*a, **kw)
+        e1.record()
+        events.append((e0, e1))
+        return r
+
+    ops.gemm = timed_gemm
+    try:
+        trainer.update_fn(batch, step_optimizer=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = orig
+    ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    avg_s = sum(ms) / len(ms) * 1e-3
+    flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
+    achieved = flops / avg_s / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "dfold_mfma_gemm_kernel<1> (5x5 conv implicit GEMM fwd+dgrad)", "launches": len(ms),
+            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
+
+
+def cpu_baseline(F, N, seed_w=0):
+    """The oracle (CPU port of the reference path) fwd + loss + bwd on host cores, bounded sample."""
+    from oracle import dfold_oracle as O
+    from dynamicpdb_amd import synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    sd = synthetic.seeded_state_dict(seed_w)
+    w = synthetic.synthetic_window(7, F, N, t=0.5, diffuser=diffuser)
+    times = []
+    for it in range(3):
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        t0 = time.time()
+        out = O.full_score_network(P, O.Schedules(), w)
+        loss, _ = O.loss_fn(out, w)
+        loss.backward()
+        times.append(time.time() - t0)
+    t = min(times[1:])
+    return {"value": round(F / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd, 1 window of {F} frames x N_res={N}, best of 2 after 1 warm-up "
+                      f"({t:.2f} s/iter, torch CPU threads={cores})"}
+
+
+def main():
+    args = parse()
+    T0 = time.perf_counter()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    B, F, N = args.windows, args.frames, args.nres
+    tlog = lambda msg: print(f"[bench rank{rank} +{time.perf_counter() - T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    model.load_state_dict(synthetic.seeded_state_dict(0), strict=True)     # same weights on every rank
+    model.to(dev)
+    trainer = experiment.Trainer(model, lr=1e-4)
+    tlog("model ready")
+    batch = make_batch(synthetic, diffuser, B, F, N, rank, dev)
+    tlog("batch ready")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.update_fn(batch)
+        torch.cuda.synchronize()
+        tlog("warm-up step done")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, aux = trainer.update_fn(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt)
+    tlog(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
+    roof = conv_kernel_roofline(model, trainer, batch, B, F, N) if rank == 0 else None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * F * args.steps / elapsed
+        line = {
+            "metric": "trajectory_frames_per_sec_fwd_bwd_nres%d" % N, "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: synthetic N_res=%d, %d-frame windows, %d windows/GPU, full "
+                                   "update_fn (fwd+loss+bwd+grad all-reduce+Adam amsgrad), random-init seeded weights"
+                                   % (N, F, B),
+                       "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world},
+            "loss": round(float(loss), 5),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames, N)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ extern "C" int dfold_cast_f32_bf16(const float* src, void* dst, int64_t n, void*
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return DFOLD_EINVAL;
   long blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+  DFOLD_LAUNCH(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, (long)n);
   return dfold_check_launch();
 }
@@ -42,7 +42,7 @@ extern "C" int dfold_cast_bf16_f32(const void* src, float* dst, int64_t n, void*
   if (n == 0) return DFOLD_OK;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+  DFOLD_LAUNCH(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, dst, (long)n);
   return dfold_check_launch();
 }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __re
 extern "C" int dfold_conv_weight_pack(const float* W, void* Wf, void* Wd, int32_t CO, int32_t CI, void* stream) {
   if (!W || !Wf || !Wd || CO <= 0 || CI <= 0) return DFOLD_EINVAL;
   dim3 grid((CI + 31) / 32, (CO + 31) / 32);
-  hipLaunchKernelGGL(conv_weight_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)Wf, (bf16_t*)Wd,
+  DFOLD_LAUNCH(conv_weight_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)Wf, (bf16_t*)Wd,
                      CO, CI);
   return dfold_check_launch();
 }
@@ -108,7 +108,7 @@ extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, i
                                        void* stream) {
   if (!dWg || !G || CO <= 0 || CI <= 0) return DFOLD_EINVAL;
   dim3 grid((CI + 63) / 64, CO);
-  hipLaunchKernelGGL(conv_wgrad_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
+  DFOLD_LAUNCH(conv_wgrad_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
   return dfold_check_launch();
 }
 
@@ -157,7 +157,7 @@ extern "C" int dfold_grid_transpose_shift(const void* X, void* T, int32_t Wn, in
   if (!X || !T || Wn <= 0 || Fp <= 0 || Wp <= 0 || C <= 0 || N <= 0 || nd <= 0 || nd > 5 || d0 < 0) return DFOLD_EINVAL;
   if (N + d0 + nd - 1 > Wp) return DFOLD_EINVAL;
   dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * Fp);
-  hipLaunchKernelGGL(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
+  DFOLD_LAUNCH(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
                      (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd);
   return dfold_check_launch();
 }
@@ -186,7 +186,7 @@ extern "C" int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C
   long chunks = (R + 511) / 512;
   if (chunks > 1024) chunks = 1024;
   dim3 grid((C + 63) / 64, (unsigned)chunks);
-  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, out, (long)R, C,
+  DFOLD_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, out, (long)R, C,
                      (long)ld);
   return dfold_check_launch();
 }
@@ -214,7 +214,7 @@ extern "C" int dfold_relu_mask_bf16(const void* g, const void* v, void* out, int
   if (n == 0) return DFOLD_OK;
   long blocks = (n / 8 + 255) / 256 + 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(relu_mask_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+  DFOLD_LAUNCH(relu_mask_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
                      (const bf16_t*)v, (bf16_t*)out, (long)n);
   return dfold_check_launch();
 }
@@ -249,7 +249,7 @@ extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32
   if (!src || !dst || R <= 0 || C <= 0 || nbatch <= 0 || nb1 <= 0 || ld_src < C || ld_dst < R) return DFOLD_EINVAL;
   if (nbatch > 65535) return DFOLD_EINVAL;
   dim3 grid((C + 63) / 64, (R + 63) / 64, nbatch);
-  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
+  DFOLD_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
                      C, (long)ld_src, (long)ld_dst, (long)bs_src0, (long)bs_src1, (long)bs_dst0, (long)bs_dst1, nb1);
   return dfold_check_launch();
 }

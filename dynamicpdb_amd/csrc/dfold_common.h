@@ -58,6 +58,15 @@ __device__ __forceinline__ long row_off(const RowMap& r, long m) {
   return r.base + (((w * r.fp + f) * r.wp) + n) * r.ld;
 }
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (e.g. a benign
+// hipErrorNotReady from an event query made by the host framework): clear it before every launch so that
+// dfold_check_launch() reflects this launch only.
+#define DFOLD_LAUNCH(...)          \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 static inline int dfold_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DFOLD_OK : DFOLD_ELAUNCH;

@@ -45,7 +45,11 @@ struct GemmParams {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p) {
+// ROLE only selects the kernel symbol (so that profiles attribute time to the conv tower separately):
+//   0 = generic dense / batched GEMM, 1 = 5x5 conv implicit GEMM over the padded grid (forward & dgrad),
+//   2 = 5x5 conv wgrad (25 tap batches over transposed activations)
+template <int ROLE>
+__global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];  // [buf][A|B][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
@@ -192,6 +196,11 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   dim3 grid(tiles, d->nbatch, 1);
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (d->a_rows.mode == 1 && d->nseg == 25)
+    DFOLD_LAUNCH(dfold_mfma_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (d->nbatch == 25 && d->nb1 == 5)
+    DFOLD_LAUNCH(dfold_mfma_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    DFOLD_LAUNCH(dfold_mfma_gemm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
   return dfold_check_launch();
 }

@@ -109,7 +109,7 @@ extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const fl
   IpaDims d{B, F, N, H};
   dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
   const size_t lds = (size_t)N * KPS * sizeof(float);
-  hipLaunchKernelGGL(ipa_softmax_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, S, bias, q_pts, k_pts, mask, hw,
+  DFOLD_LAUNCH(ipa_softmax_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, S, bias, q_pts, k_pts, mask, hw,
                      P, (bf16_t*)P_bf16, d, bias_scale, inf);
   return dfold_check_launch();
 }
@@ -147,7 +147,7 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
   hipFuncSetAttribute((const void*)ipa_opt_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d);
+  DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d);
   return dfold_check_launch();
 }
 
@@ -253,7 +253,7 @@ extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const floa
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
   hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(ipa_softmax_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dP, q_pts, k_pts, v_pts, do_pt,
+  DFOLD_LAUNCH(ipa_softmax_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dP, q_pts, k_pts, v_pts, do_pt,
                      hw, dS, (bf16_t*)dS_bf16, dq_pts, dhw, d);
   return dfold_check_launch();
 }
@@ -317,7 +317,7 @@ extern "C" int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid((N + 255) / 256, H, B * F);
   hipFuncSetAttribute((const void*)ipa_col_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(ipa_col_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
+  DFOLD_LAUNCH(ipa_col_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
                      dv_pts, d);
   return dfold_check_launch();
 }
@@ -348,7 +348,7 @@ extern "C" int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, 
   if (!dS || !out_hn || !out_nh || B <= 0 || F <= 0 || N <= 0 || H <= 0 || H > 8) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
   dim3 grid((unsigned)(((long)N * N + 255) / 256), B);
-  hipLaunchKernelGGL(ipa_bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dS, (bf16_t*)out_hn, (bf16_t*)out_nh, d,
+  DFOLD_LAUNCH(ipa_bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dS, (bf16_t*)out_hn, (bf16_t*)out_nh, d,
                      scale);
   return dfold_check_launch();
 }

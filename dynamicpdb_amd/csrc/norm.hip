@@ -86,8 +86,8 @@ extern "C" int dfold_gln_fwd(const float* x, double* stats, void* y_bf16, float*
   long bx = (n / 4 + 255) / 256;
   if (bx > 512) bx = 512;
   dim3 grid((unsigned)bx, W);
-  hipLaunchKernelGGL(gln_stats_kernel, grid, dim3(256), 0, st, x, stats, (long)n);
-  hipLaunchKernelGGL(gln_apply_kernel, grid, dim3(256), 0, st, x, (const double*)stats, (bf16_t*)y_bf16, mean_rstd, (long)n,
+  DFOLD_LAUNCH(gln_stats_kernel, grid, dim3(256), 0, st, x, stats, (long)n);
+  DFOLD_LAUNCH(gln_apply_kernel, grid, dim3(256), 0, st, x, (const double*)stats, (bf16_t*)y_bf16, mean_rstd, (long)n,
                      eps, silu);
   return dfold_check_launch();
 }
@@ -150,8 +150,8 @@ extern "C" int dfold_gln_bwd(const float* x, const void* g_bf16, const float* me
   long bx = (n + 255) / 256;
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, W);
-  hipLaunchKernelGGL(gln_bwd_stats_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd, stats, (long)n, silu);
-  hipLaunchKernelGGL(gln_bwd_apply_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd,
+  DFOLD_LAUNCH(gln_bwd_stats_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd, stats, (long)n, silu);
+  DFOLD_LAUNCH(gln_bwd_apply_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd,
                      (const double*)stats, (bf16_t*)dx_bf16, (long)n, silu);
   return dfold_check_launch();
 }

@@ -51,7 +51,7 @@ extern "C" int dfold_igso3_series(const float* omega, const double* env, double*
   if (!omega || !env || !sc || !dsc || P <= 0 || per_window <= 0 || L <= 0 || L > 4096) return DFOLD_EINVAL;
   if (P % per_window) return DFOLD_EINVAL;
   dim3 grid((unsigned)((per_window + 255) / 256), (unsigned)(P / per_window));
-  hipLaunchKernelGGL(igso3_series_kernel, grid, dim3(256), (size_t)L * sizeof(double), (hipStream_t)stream, omega, env, sc,
+  DFOLD_LAUNCH(igso3_series_kernel, grid, dim3(256), (size_t)L * sizeof(double), (hipStream_t)stream, omega, env, sc,
                      dsc, (long)P, (long)per_window, L);
   return dfold_check_launch();
 }
