@@ -19,14 +19,15 @@ class RowMap(Structure):
 
 class GemmDesc(Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p),
-                ("R", c_void_p), ("R2", c_void_p), ("zeros", c_void_p), ("a_seg_off", c_void_p),
-                ("b_seg_off", c_void_p), ("a_rows", RowMap), ("c_rows", RowMap), ("ldb", c_int64),
+                ("R", c_void_p), ("R2", c_void_p), ("zeros", c_void_p), ("a_seg0", c_int64), ("a_seg_s1", c_int64),
+                ("a_seg_s2", c_int64), ("b_seg0", c_int64), ("b_seg_s1", c_int64), ("b_seg_s2", c_int64),
+                ("seg_div", c_int32), ("a_rows", RowMap), ("c_rows", RowMap), ("ldb", c_int64),
                 ("sa0", c_int64), ("sa1", c_int64), ("sb0", c_int64), ("sb1", c_int64), ("sc0", c_int64),
                 ("sc1", c_int64), ("M", c_int32), ("N", c_int32), ("nseg", c_int32), ("seglen", c_int32),
                 ("nbatch", c_int32), ("nb1", c_int32), ("flags", c_int32), ("alpha", c_float)]
 
 
-GEMM_BIAS, GEMM_RELU, GEMM_RESID, GEMM_RELUMASK, GEMM_OUT_BF16, GEMM_ACCUM = 1, 2, 4, 8, 16, 32
+GEMM_BIAS, GEMM_RELU, GEMM_RESID, GEMM_RELUMASK, GEMM_OUT_BF16, GEMM_ACCUM, GEMM_ATOMIC = 1, 2, 4, 8, 16, 32, 64
 
 
 def header_symbols():
@@ -43,6 +44,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m dynamicpdb_amd.build_ext` "
                 "(the MI355X device path has no fallback)")
+        # torch bundles its own libamdhip64.so.7; it must be resident BEFORE our library is dlopen'ed so that both bind
+        # to the same HIP runtime instance (loading ours first pulls /opt/rocm's copy in and torch's device pointers
+        # then belong to a different runtime: every launch fails).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name in header_symbols():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol

@@ -19,6 +19,7 @@
 // panel sit on one XCD's L2).
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -34,8 +35,9 @@ struct GemmParams {
   const bf16_t* R;
   const bf16_t* R2;
   const bf16_t* zeros;
-  const long* a_seg_off;
-  const long* b_seg_off;
+  long a_seg0, a_seg_s1, a_seg_s2;  // A offset of K segment g: a_seg0 + (g / seg_div) * a_seg_s1 + (g % seg_div) * a_seg_s2
+  long b_seg0, b_seg_s1, b_seg_s2;
+  int seg_div;
   RowMap am, cm;
   long ldb;
   long sa0, sa1, sb0, sb1, sc0, sc1;
@@ -44,6 +46,44 @@ struct GemmParams {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Shared epilogue: 2x2 MFMA 32x32 accumulator tiles of one wave -> C (C/D layout: col = lane&31,
+// row = (e&3) + 8*(e>>2) + 4*(lane>>5)).
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], long mbase, int nbase, long coff,
+                                              int lane) {
+  const int fl = p.flags;
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long m = mbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+      if (m >= p.M) continue;
+      const long ro = row_off(p.cm, m) + coff;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = nbase + j * 32 + frow;
+        if (n >= p.N) continue;
+        float v = acc[i][j][e] * p.alpha;
+        const long off = ro + n;
+        if (fl & DFOLD_GEMM_BIAS) v += p.bias[n];
+        if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
+        if (p.C2 != nullptr && p.R2 == nullptr) ((bf16_t*)p.C2)[off] = f2bf(v);
+        if (fl & DFOLD_GEMM_RESID) v += bf2f(p.R[off]);
+        if (fl & DFOLD_GEMM_RELUMASK) v = bf2f(p.R[off]) > 0.f ? v : 0.f;
+        if (fl & DFOLD_GEMM_OUT_BF16) {
+          ((bf16_t*)p.C)[off] = f2bf(v);
+        } else if (fl & DFOLD_GEMM_ATOMIC) {
+          atomicAdd((float*)p.C + off, v);
+        } else {
+          if (fl & DFOLD_GEMM_ACCUM) v += ((float*)p.C)[off];
+          ((float*)p.C)[off] = v;
+        }
+        if (p.C2 != nullptr && p.R2 != nullptr) ((bf16_t*)p.C2)[off] = bf2f(p.R2[off]) > 0.f ? f2bf(v) : (bf16_t)0;
+      }
+    }
+  }
+}
 
 // ROLE only selects the kernel symbol (so that profiles attribute time to the conv tower separately):
 //   0 = generic dense / batched GEMM, 1 = 5x5 conv implicit GEMM over the padded grid (forward & dgrad),
@@ -83,12 +123,22 @@ __global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParam
   const int sps = (p.seglen + BK - 1) / BK;  // K steps per segment
   const int nsteps = p.nseg * sps;
 
-  auto stage = [&](int buf, int step) {
-    const int seg = step / sps;
-    const int kk = (step - seg * sps) * BK;
-    const long ao = (p.a_seg_off ? p.a_seg_off[seg] : (long)seg * p.seglen) + kk;
-    const long bo = (p.b_seg_off ? p.b_seg_off[seg] : (long)seg * p.seglen) + kk;
+  // K-step cursor of the NEXT tile to stage (stages are issued in increasing step order): segment (hi, lo) and
+  // offset kk inside it -- pure scalar arithmetic, no table loads (a VMEM load here would force vmcnt(0)).
+  int st_hi = 0, st_lo = 0, st_kk = 0;
+  auto stage = [&](int buf, int) {
+    const long ao = p.a_seg0 + st_hi * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
+    const long bo = p.b_seg0 + st_hi * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
+    const int kk = st_kk;
     const bool kin = (kk + kofs) < p.seglen;
+    st_kk += BK;
+    if (st_kk >= p.seglen) {
+      st_kk = 0;
+      if (++st_lo == p.seg_div) {
+        st_lo = 0;
+        ++st_hi;
+      }
+    }
     char* la = lds + buf * 2 * TILE_BYTES;
     char* lb = la + TILE_BYTES;
 #pragma unroll
@@ -138,36 +188,134 @@ __global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParam
     }
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
-  const int fl = p.flags;
+  gemm_epilogue(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Large-problem variant: 256(M) x 128(N) x 64 tile, 8 waves (4 x 2, each 64x64 = 2x2 MFMA 32x32x16),
+// THREE LDS stages (3 x 48 KiB) filled by LDS-DMA with a counted s_waitcnt: the loads of tile s+1 stay in
+// flight across the barrier of step s (raw s_barrier -- __syncthreads() would drain vmcnt to 0), so HBM/L2
+// latency is hidden behind two MFMA phases.  Per K step a wave issues 6 LDS-DMA pieces (4 A + 2 B) and 16 MFMAs;
+// L2->LDS bytes per flop are 0.75x the 128x128 kernel's.
+// ------------------------------------------------------------------------------------------------
+#define BM2 256
+#define A2_BYTES (BM2 * BK * 2)
+#define STAGE2_BYTES (A2_BYTES + TILE_BYTES)
+#define NSTAGE2 3
+
+template <int ROLE>
+__global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds2[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (lid / tiles_n) * BM2, n0 = (lid % tiles_n) * BN;
+  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+  const bf16_t* A = p.A + z0 * p.sa0 + z1 * p.sa1;
+  const bf16_t* B = p.B + z0 * p.sb0 + z1 * p.sb1;
+  const long coff = z0 * p.sc0 + z1 * p.sc1;
+
+  const int cphys = lane & 7;
+  const int rsub = lane >> 3;
+  const int clog = cphys ^ ((((w & 1) << 2) + (lane >> 4)) & 7);
+  const int kofs = clog * 8;
+  const bf16_t* arow[4];
+  const bf16_t* brow[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int t = 0; t < 4; ++t) {
+    const long m = (long)m0 + (t * 8 + w) * 8 + rsub;
+    arow[t] = m < p.M ? A + row_off(p.am, m) + kofs : nullptr;
+  }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long m = (long)m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-      if (m >= p.M) continue;
-      const long ro = row_off(p.cm, m) + coff;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + frow;
-        if (n >= p.N) continue;
-        float v = acc[i][j][e] * p.alpha;
-        const long off = ro + n;
-        if (fl & DFOLD_GEMM_BIAS) v += p.bias[n];
-        if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (p.C2 != nullptr && p.R2 == nullptr) ((bf16_t*)p.C2)[off] = f2bf(v);
-        if (fl & DFOLD_GEMM_RESID) v += bf2f(p.R[off]);
-        if (fl & DFOLD_GEMM_RELUMASK) v = bf2f(p.R[off]) > 0.f ? v : 0.f;
-        if (fl & DFOLD_GEMM_OUT_BF16) {
-          ((bf16_t*)p.C)[off] = f2bf(v);
-        } else {
-          if (fl & DFOLD_GEMM_ACCUM) v += ((float*)p.C)[off];
-          ((float*)p.C)[off] = v;
-        }
-        if (p.C2 != nullptr && p.R2 != nullptr) ((bf16_t*)p.C2)[off] = bf2f(p.R2[off]) > 0.f ? f2bf(v) : (bf16_t)0;
+  for (int t = 0; t < 2; ++t) {
+    const long n = (long)n0 + (t * 8 + w) * 8 + rsub;
+    brow[t] = n < p.N ? B + n * p.ldb + kofs : nullptr;
+  }
+  const int sps = (p.seglen + BK - 1) / BK;
+  const int nsteps = p.nseg * sps;
+
+  // K-step cursor of the NEXT tile to stage (stages are issued in increasing step order): segment (hi, lo) and
+  // offset kk inside it -- pure scalar arithmetic, no table loads (a VMEM load here would force vmcnt(0)).
+  int st_hi = 0, st_lo = 0, st_kk = 0;
+  auto stage = [&](int buf, int) {
+    const long ao = p.a_seg0 + st_hi * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
+    const long bo = p.b_seg0 + st_hi * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
+    const int kk = st_kk;
+    const bool kin = (kk + kofs) < p.seglen;
+    st_kk += BK;
+    if (st_kk >= p.seglen) {
+      st_kk = 0;
+      if (++st_lo == p.seg_div) {
+        st_lo = 0;
+        ++st_hi;
       }
     }
+    char* la = lds2 + buf * STAGE2_BYTES;
+    char* lb = la + A2_BYTES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16_t* sa = (arow[t] != nullptr && kin) ? arow[t] + ao : p.zeros;
+      __builtin_amdgcn_global_load_lds((const void*)sa, (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16_t* sb = (brow[t] != nullptr && kin) ? brow[t] + bo : p.zeros;
+      __builtin_amdgcn_global_load_lds((const void*)sb, (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (lane >> 1) & 7;
+  const int fhalf = lane >> 5;
+
+  stage(0, 0);
+  if (nsteps > 1) stage(1, 1);
+  int cur = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // tile s must have landed; tile s+1 (6 pieces per wave) may stay in flight across the barrier
+    if (s + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < nsteps) {
+      int nb = cur + 2;
+      if (nb >= NSTAGE2) nb -= NSTAGE2;
+      stage(nb, s + 2);
+    }
+    const char* la = lds2 + cur * STAGE2_BYTES;
+    const char* lb = la + A2_BYTES;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(la + (wm * 64 + i * 32 + frow) * 128 + ch);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(lb + (wn * 64 + j * 32 + frow) * 128 + ch);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NSTAGE2 ? 0 : cur + 1;
   }
+
+  gemm_epilogue(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
 }
 
 static RowMap to_rowmap(const dfold_rowmap* r) {
@@ -180,20 +328,49 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C || !d->zeros) return DFOLD_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->nseg <= 0 || d->seglen <= 0 || d->nbatch <= 0) return DFOLD_EINVAL;
   if ((d->seglen & 7) || (d->ldb & 7) || (d->a_rows.ld & 7) || (d->a_rows.base & 7)) return DFOLD_EINVAL;  // 16-B chunks
+  if ((d->a_seg0 | d->a_seg_s1 | d->a_seg_s2 | d->b_seg0 | d->b_seg_s1 | d->b_seg_s2) & 7) return DFOLD_EINVAL;
   if ((d->flags & DFOLD_GEMM_BIAS) && !d->bias) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) && !d->R) return DFOLD_EINVAL;
-  if ((d->flags & DFOLD_GEMM_ACCUM) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
+  if ((d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
   if (d->a_rows.mode == 1 && (d->a_rows.n <= 0 || d->a_rows.f <= 0)) return DFOLD_EINVAL;
   if (d->c_rows.mode == 1 && (d->c_rows.n <= 0 || d->c_rows.f <= 0)) return DFOLD_EINVAL;
   GemmParams p;
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.C2 = d->C2;
   p.bias = d->bias; p.R = (const bf16_t*)d->R; p.R2 = (const bf16_t*)d->R2; p.zeros = (const bf16_t*)d->zeros;
-  p.a_seg_off = (const long*)d->a_seg_off; p.b_seg_off = (const long*)d->b_seg_off;
+  p.a_seg0 = d->a_seg0; p.a_seg_s1 = d->a_seg_s1; p.a_seg_s2 = d->a_seg_s2;
+  p.b_seg0 = d->b_seg0; p.b_seg_s1 = d->b_seg_s1; p.b_seg_s2 = d->b_seg_s2;
+  p.seg_div = d->seg_div > 0 ? d->seg_div : 1;
   p.am = to_rowmap(&d->a_rows); p.cm = to_rowmap(&d->c_rows);
   p.ldb = d->ldb;
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
+  const int role = (d->a_rows.mode == 1 && d->nseg == 25) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
+  const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
+  const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);
+  static int variant = -1;   // DFOLD_GEMM_VARIANT=128 forces the 128x128 kernel (A/B measurements)
+  if (variant < 0) {
+    const char* e = getenv("DFOLD_GEMM_VARIANT");
+    variant = (e && atoi(e) == 128) ? 128 : 256;
+  }
+  if (variant == 256 && d->M >= 1024 && steps >= 4 && tiles256 * d->nbatch >= 192) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2_BYTES);
+      attr_done = true;
+    }
+    dim3 grid2((unsigned)tiles256, d->nbatch, 1);
+    const size_t lds = NSTAGE2 * STAGE2_BYTES;
+    if (role == 1)
+      DFOLD_LAUNCH(dfold_mfma_gemm256_kernel<1>, grid2, dim3(512), lds, (hipStream_t)stream, p);
+    else if (role == 2)
+      DFOLD_LAUNCH(dfold_mfma_gemm256_kernel<2>, grid2, dim3(512), lds, (hipStream_t)stream, p);
+    else
+      DFOLD_LAUNCH(dfold_mfma_gemm256_kernel<0>, grid2, dim3(512), lds, (hipStream_t)stream, p);
+    return dfold_check_launch();
+  }
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   dim3 grid(tiles, d->nbatch, 1);
   if (d->a_rows.mode == 1 && d->nseg == 25)

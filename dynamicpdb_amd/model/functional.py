@@ -73,8 +73,7 @@ def _linear_backward(x2d, weight, g2d, need_dx=True):
         gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
     gT = ops.transpose_bf16(g8, M, N8)              # [N8][M]
     xT = ops.transpose_bf16(x2d, M, K)              # [K][M]
-    dW = torch.empty((N8, K), dtype=torch.float32, device=x2d.device)
-    gemm(gT, xT, dW, N8, K, M, a_rows=rows_plain(M), c_rows=rows_plain(K), ldb=M)
+    dW = ops.gemm_reduce_rows(gT, xT, N8, K, M)
     db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)
     ops.colsum_bf16(g8, db, M, N8, N8)
     return dx, dW[:N], db[:N]
@@ -326,11 +325,14 @@ class IpaCoreFn(Function):
         del dz32
         zT = _zT(z.view(B * NN, CZ))                                                                     # [CZ][B*NN]
         dpzT = ops.transpose_bf16(dpz.view(B * NN, PZ), B * NN, PZ)                                      # [PZ][B*NN]
-        dw_dz = torch.empty((PZ, CZ), dtype=torch.float32, device=dev)
-        gemm(dpzT, zT, dw_dz, PZ, CZ, B * NN, a_rows=rows_plain(B * NN), c_rows=rows_plain(CZ), ldb=B * NN)
-        dw_b = torch.empty((H, CZ), dtype=torch.float32, device=dev)
-        gemm(db_hn, zT, dw_b, H, CZ, NN, nseg=B, a_rows=rows_plain(NN), c_rows=rows_plain(CZ), ldb=B * NN,
-             a_seg_off=ops.seg_table([b * H * NN for b in range(B)], dev))
+        dw_dz = ops.gemm_reduce_rows(dpzT, zT, PZ, CZ, B * NN)
+        dw_b = torch.zeros((H, CZ), dtype=torch.float32, device=dev)
+        S2 = max(1, min(64, 256 // B))
+        while S2 > 1 and NN % (S2 * 64):
+            S2 -= 1
+        ks = NN // S2                                    # split-K over (window, K slice): 1 output tile otherwise
+        gemm(db_hn, zT, dw_b, H, CZ, ks, a_rows=rows_plain(NN), c_rows=rows_plain(CZ), ldb=B * NN, nbatch=B * S2,
+             nb1=S2, sa=(H * NN, ks), sb=(NN, ks), sc=(0, 0), flags=ops.GEMM_ATOMIC)
         db_dz = torch.zeros(PZ, dtype=torch.float32, device=dev)
         ops.colsum_bf16(do_pair, db_dz, do_pair.numel() // PZ, PZ, PZ)
         return dq, dkv, dq_pts, dk_pts, dv_pts, dz, dw_b, dw_dz, db_dz, None, dhw

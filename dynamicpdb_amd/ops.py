@@ -6,8 +6,8 @@ from ctypes import byref, c_int32, c_int64, c_void_p
 import torch
 
 from . import _lib
-from ._lib import (GEMM_ACCUM, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU, GEMM_RELUMASK, GEMM_RESID, GemmDesc, RowMap,
-                   check, stream)
+from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU, GEMM_RELUMASK, GEMM_RESID, GemmDesc,
+                   RowMap, check, stream)
 
 BF16 = torch.bfloat16
 _zero_pages = {}
@@ -47,7 +47,7 @@ def seg_table(values, device):
 
 
 def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
-         a_seg_off=None, b_seg_off=None, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
+         a_seg=None, b_seg=None, seg_div=1, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
          a_off=0, b_off=0, c_off=0):
     """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
     assert A.dtype == BF16 and B.dtype == BF16
@@ -62,13 +62,35 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.A, d.B, d.C, d.C2 = _p(A, a_off), _p(B, b_off), _p(C, c_off), _p(C2, c_off)
     d.bias, d.R, d.R2 = _p(bias), _p(R, c_off), _p(R2, c_off)
     d.zeros = _p(zeros_page(A.device))
-    d.a_seg_off, d.b_seg_off = _p(a_seg_off), _p(b_seg_off)
+    # K-segment offsets (seg0, s1, s2): seg0 + (g // seg_div)*s1 + (g % seg_div)*s2; default = contiguous K
+    a_seg = a_seg or (0, seglen * seg_div, seglen)
+    b_seg = b_seg or (0, seglen * seg_div, seglen)
+    d.a_seg0, d.a_seg_s1, d.a_seg_s2 = a_seg
+    d.b_seg0, d.b_seg_s1, d.b_seg_s2 = b_seg
+    d.seg_div = seg_div
     d.a_rows, d.c_rows = a_rows, c_rows
     d.ldb = ldb
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
     d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
     check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
     return C
+
+
+def gemm_reduce_rows(AT, BT, M, N, K, out=None):
+    """out[M,N] fp32 = AT[M,K] @ BT[N,K]^T for a LONG reduction axis K (weight gradients: K = windows*frames*residues)
+    and a small output: the K axis is split over workgroups (split-K) whose partial tiles are combined with fp32
+    atomics, so that a [256 x 256] gradient still fills the 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    S = max(1, min(64, 512 // tiles))
+    while S > 1 and (K % (S * 64)):
+        S -= 1
+    if out is None:
+        out = torch.zeros((M, N), dtype=torch.float32, device=AT.device)
+    if S == 1:
+        return gemm(AT, BT, out, M, N, K, a_rows=rows_plain(K), c_rows=rows_plain(N), ldb=K, flags=GEMM_ACCUM)
+    ks = K // S
+    return gemm(AT, BT, out, M, N, ks, a_rows=rows_plain(K), c_rows=rows_plain(N), ldb=K, nbatch=S, nb1=1,
+                sa=(ks, 0), sb=(ks, 0), sc=(0, 0), flags=GEMM_ATOMIC)
 
 
 def cast_bf16(x):
@@ -174,13 +196,16 @@ class Grid:
         return rows_grid(C, self.N, self.F, self.Fp, self.Wp, (2 * self.Wp + 2) * C + ch_off)
 
     def tap_offsets(self, C):
-        return seg_table([(df * self.Wp + dn) * C for df in range(5) for dn in range(5)], self.device)
+        """K segment g = 5*df + dn of the implicit GEMM reads the cell at (+df rows, +dn columns)."""
+        return (0, self.Wp * C, C)
 
     def seg_shifted(self):
-        return seg_table([w * self.Fp * self.N for w in range(self.Wn)], self.device)
+        """wgrad K segment = window w of a transposed [c][w][f'][n] copy, starting at padded frame row 0 ..."""
+        return (0, self.Fp * self.N, 0)
 
     def seg_center(self):
-        return seg_table([w * self.Fp * self.N + 2 * self.N for w in range(self.Wn)], self.device)
+        """... or at padded frame row 2 (the un-shifted operand)."""
+        return (2 * self.N, self.Fp * self.N, 0)
 
 
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None):
@@ -197,7 +222,7 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     if pre_resid_out is not None:
         C2, R2 = pre_resid_out, None
     return gemm(x, wf, out, g.M, CO, CI, nseg=25, a_rows=g.rows_in(CI), c_rows=g.rows_center(CO), ldb=25 * CI,
-                bias=bias, R=R, C2=C2, R2=R2, a_seg_off=g.tap_offsets(CI), flags=flags)
+                bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI), seg_div=5, flags=flags)
 
 
 def grid_transpose_shift(g, x, C, d0, nd, out):
@@ -217,13 +242,13 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True):
         tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)))
         tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)))
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
-             a_seg_off=g.seg_center(), b_seg_off=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
+             a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
     else:          # shift gy, taps flipped
         tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)))
         tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
         gemm(tS, tU, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
-             a_seg_off=g.seg_shifted(), b_seg_off=g.seg_center(), nbatch=25, nb1=5, sa=(N, CO * plane),
+             a_seg=g.seg_shifted(), b_seg=g.seg_center(), nbatch=25, nb1=5, sa=(N, CO * plane),
              sc=(-5 * CI, -CI), c_off=24 * CI, flags=fl)
     return dwg
 

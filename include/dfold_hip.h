@@ -30,7 +30,7 @@ int dfold_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction engine (bf16 MFMA, fp32 accumulate).
- *   C[m,n] = epi( alpha * sum_{seg,k} A[arow(m) + a_seg_off[seg] + k] * B[n*ldb + b_seg_off[seg] + k] )
+ *   C[m,n] = epi( alpha * sum_{seg,k} A[arow(m) + a_off(seg) + k] * B[n*ldb + b_off(seg) + k] )
  * replaces aten conv2d / linear / matmul at: ConvNet src/model/ipa_pytorch_dynamic.py:664-706
  * (implicit GEMM over the zero-padded [window, F+4, N+4, C] grid, fwd / dgrad / wgrad),
  * IPA projections :350-396,:498-514, AngleResnet openfold/model/structure_module.py:114-158,
@@ -52,6 +52,7 @@ typedef struct {
 #define DFOLD_GEMM_RELUMASK 8  /* v = R[off] > 0 ? v : 0  (ReLU backward) */
 #define DFOLD_GEMM_OUT_BF16 16 /* C is bf16 (else fp32) */
 #define DFOLD_GEMM_ACCUM 32    /* fp32 C += v */
+#define DFOLD_GEMM_ATOMIC 64   /* fp32 atomicAdd(C, v): split-K slices (batches that share C) */
 
 typedef struct {
   const void* A;        /* bf16 */
@@ -63,8 +64,11 @@ typedef struct {
   const void* R;        /* bf16, see flags */
   const void* R2;       /* bf16 mask for C2 */
   const void* zeros;    /* >= 16 bytes of zeros, 16-B aligned (source for out-of-range tile cells) */
-  const int64_t* a_seg_off; /* [nseg] element offsets added to every A row, NULL -> seg*seglen */
-  const int64_t* b_seg_off; /* [nseg] element offsets added to every B row, NULL -> seg*seglen */
+  /* element offset added to every A (B) row for K segment g:  seg0 + (g / seg_div)*seg_s1 + (g % seg_div)*seg_s2
+     (conv taps: g = 5*df + dn -> (df*Wp + dn)*C;  plain contiguous K: seg_s1 = seglen, seg_div = 1) */
+  int64_t a_seg0, a_seg_s1, a_seg_s2;
+  int64_t b_seg0, b_seg_s1, b_seg_s2;
+  int32_t seg_div;
   dfold_rowmap a_rows, c_rows;
   int64_t ldb;
   int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements): batch z -> (z / nb1, z % nb1) */

@@ -21,7 +21,8 @@ def _rand_bf16(shape, dev, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1024, 640, 1280), (77, 6, 1280), (4096, 40, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1024, 640, 1280), (77, 6, 1280), (4096, 40, 128),
+                                   (16384, 384, 520), (16500, 700, 256)])   # the last two run the 256x128 3-stage kernel
 def test_gemm_plain(dev, M, N, K):
     from dynamicpdb_amd import ops
     a, b = _rand_bf16((M, K), dev, 1), _rand_bf16((N, K), dev, 2)
@@ -58,12 +59,44 @@ def test_gemm_batched_accumulate(dev):
     assert rel_l2(out, 0.5 * ref + 1.0) < 1e-5
 
 
+def test_splitk_reduce_rows(dev):
+    """weight-gradient shaped products: long K, small output, split-K with fp32 atomics"""
+    from dynamicpdb_amd import ops
+    for M, N, K in ((256, 256, 65536), (8, 128, 4096 * 9), (2048, 256, 8192), (16, 1280, 640)):
+        a, b = _rand_bf16((M, K), dev, 5, 0.1), _rand_bf16((N, K), dev, 6, 0.1)
+        out = ops.gemm_reduce_rows(a, b, M, N, K)
+        ref = a.double() @ b.double().t()
+        assert rel_l2(out, ref) < 1e-5, (M, N, K)
+
+
+def test_conv_fwd_large_grid_vs_torch(dev):
+    """implicit-GEMM conv on a grid large enough for the 256x128 3-stage kernel, vs torch conv2d (fp64)"""
+    from dynamicpdb_amd import ops
+    Wn, F, N, CI, CO = 6, 8, 128, 64, 512
+    torch.manual_seed(3)
+    w = (torch.randn(CO, CI, 5, 5, device=dev) / np.sqrt(25 * CI))
+    bias = 0.1 * torch.randn(CO, device=dev)
+    x = torch.randn(Wn, F, N, CI, device=dev).to(torch.bfloat16)
+    wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+    from dynamicpdb_amd._lib import check, lib, stream
+    from ctypes import c_int32
+    check(lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), stream()), "pack")
+    g = ops.Grid(Wn, F, N, dev)
+    xin, out = g.alloc(CI), g.alloc(CO)
+    g.interior(xin).copy_(x)
+    ops.conv5x5_fwd(g, xin, wf, bias, out, relu=False)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), bias.double(), padding=2)
+    assert rel_l2(g.interior(out), ref.permute(0, 2, 3, 1)) < 4e-3
+    assert float(out[:, :2].abs().max()) == 0 and float(out[:, :, -2:].abs().max()) == 0
+
+
 def test_transpose_and_cast(dev):
     from dynamicpdb_amd import ops
     x = torch.randn(3, 70, 130, device=dev)
     xb = ops.cast_bf16(x)
     assert torch.equal(xb, x.to(torch.bfloat16))
-    t = ops.transpose_bf16(xb, 70, 130, nbatch=3, bs_src=70 * 130)
+    t = ops.transpose_bf16(xb, 70, 130, nbatch=3, nb1=1, bs_src=(70 * 130, 0))
     assert torch.equal(t, xb.transpose(1, 2).contiguous())
     assert torch.equal(ops.cast_f32(xb), xb.float())
 
