@@ -1,0 +1,112 @@
+// First layer of the five feature embedders (reference DFOLDIpaScore force/vel/index/rigid/angle_embeder,
+// src/model/ipa_pytorch_dynamic.py:757-796):   h = SiLU(x W^T + b),  x fp32 [P, k] with k = 1, 3, 7 or 14.
+// K is far too small for the matrix cores (and for a vendor GEMM: hipBLASLt spent 2.2 ms per call on it), so
+// this is a VALU kernel: one thread per output column keeps its W row in registers, rows stream through LDS.
+#include "dfold_common.h"
+#include "../../include/dfold_hip.h"
+
+#define EMB_MAXK 16
+#define EMB_ROWS 64
+
+__device__ __forceinline__ float sigmoid_f(float y) { return 1.f / (1.f + expf(-y)); }
+
+// out bf16 [P][D] (D == blockDim.x == 256)
+__global__ __launch_bounds__(256) void embed_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ b, bf16_t* __restrict__ out, long P,
+                                                           int k, int D) {
+  __shared__ float xs[EMB_ROWS][EMB_MAXK];
+  const int o = threadIdx.x;
+  float w[EMB_MAXK];
+#pragma unroll
+  for (int c = 0; c < EMB_MAXK; ++c) w[c] = c < k ? W[(long)o * k + c] : 0.f;
+  const float bo = b[o];
+  for (long r0 = (long)blockIdx.x * EMB_ROWS; r0 < P; r0 += (long)gridDim.x * EMB_ROWS) {
+    const int rows = (int)min((long)EMB_ROWS, P - r0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * k; e += 256) xs[e / k][e % k] = x[r0 * k + e];
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      float acc = bo;
+#pragma unroll
+      for (int c = 0; c < EMB_MAXK; ++c)
+        if (c < k) acc += xs[r][c] * w[c];
+      out[(r0 + r) * D + o] = f2bf(acc * sigmoid_f(acc));
+    }
+  }
+}
+
+extern "C" int dfold_embed_in_fwd(const float* x, const float* W, const float* b, void* out_bf16, int64_t P, int32_t k,
+                                  int32_t D, void* stream) {
+  if (!x || !W || !b || !out_bf16 || P <= 0 || k <= 0 || k > EMB_MAXK || D != 256) return DFOLD_EINVAL;
+  long blocks = (P + EMB_ROWS - 1) / EMB_ROWS;
+  if (blocks > 2048) blocks = 2048;
+  DFOLD_LAUNCH(embed_in_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, W, b, (bf16_t*)out_bf16,
+               (long)P, k, D);
+  return dfold_check_launch();
+}
+
+// backward: g bf16 [P][D] = dL/dh.  gpre = g * silu'(pre) with pre recomputed;
+//   dW[o][c] += sum_r gpre[r][o] x[r][c];  db[o] += sum_r gpre[r][o];  dx[r][c] = sum_o gpre[r][o] W[o][c] (optional)
+// dW / db are accumulated with fp32 atomics (zero them first).
+__global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ b, const bf16_t* __restrict__ g,
+                                                           float* __restrict__ dW, float* __restrict__ db,
+                                                           float* __restrict__ dx, long P, int k, int D) {
+  __shared__ float xs[EMB_ROWS][EMB_MAXK];
+  __shared__ float dxs[EMB_ROWS][EMB_MAXK];
+  const int o = threadIdx.x, lane = threadIdx.x & 63;
+  float w[EMB_MAXK], aw[EMB_MAXK];
+#pragma unroll
+  for (int c = 0; c < EMB_MAXK; ++c) {
+    w[c] = c < k ? W[(long)o * k + c] : 0.f;
+    aw[c] = 0.f;
+  }
+  const float bo = b[o];
+  float ab = 0.f;
+  for (long r0 = (long)blockIdx.x * EMB_ROWS; r0 < P; r0 += (long)gridDim.x * EMB_ROWS) {
+    const int rows = (int)min((long)EMB_ROWS, P - r0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * k; e += 256) xs[e / k][e % k] = x[r0 * k + e];
+    if (dx != nullptr)
+      for (int e = threadIdx.x; e < EMB_ROWS * EMB_MAXK; e += 256) dxs[e / EMB_MAXK][e % EMB_MAXK] = 0.f;
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      float pre = bo;
+#pragma unroll
+      for (int c = 0; c < EMB_MAXK; ++c)
+        if (c < k) pre += xs[r][c] * w[c];
+      const float sg = sigmoid_f(pre);
+      const float gp = bf2f(g[(r0 + r) * D + o]) * sg * (1.f + pre * (1.f - sg));
+      ab += gp;
+#pragma unroll
+      for (int c = 0; c < EMB_MAXK; ++c)
+        if (c < k) aw[c] += gp * xs[r][c];
+      if (dx != nullptr) {
+#pragma unroll
+        for (int c = 0; c < EMB_MAXK; ++c)
+          if (c < k) {
+            const float s = wave_sum(gp * w[c]);
+            if (lane == 0) atomicAdd(&dxs[r][c], s);
+          }
+      }
+    }
+    if (dx != nullptr) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < rows * k; e += 256) dx[r0 * k + e] = dxs[e / k][e % k];
+    }
+  }
+  atomicAdd(db + o, ab);
+#pragma unroll
+  for (int c = 0; c < EMB_MAXK; ++c)
+    if (c < k) atomicAdd(dW + (long)o * k + c, aw[c]);
+}
+
+extern "C" int dfold_embed_in_bwd(const float* x, const float* W, const float* b, const void* g_bf16, float* dW, float* db,
+                                  float* dx, int64_t P, int32_t k, int32_t D, void* stream) {
+  if (!x || !W || !b || !g_bf16 || !dW || !db || P <= 0 || k <= 0 || k > EMB_MAXK || D != 256) return DFOLD_EINVAL;
+  long blocks = (P + EMB_ROWS - 1) / EMB_ROWS;
+  if (blocks > 512) blocks = 512;
+  DFOLD_LAUNCH(embed_in_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, W, b, (const bf16_t*)g_bf16,
+               dW, db, dx, (long)P, k, D);
+  return dfold_check_launch();
+}

@@ -22,7 +22,7 @@
 #define KPS 25           // padded LDS row strides
 #define VPS 37
 #define MAXT 16          // columns per lane (N <= 1024)
-#define ROWS_PER_BLOCK 16
+#define ROWS_PER_BLOCK 64   // attention rows per workgroup (16 per wave): amortises the per-block point-table staging
 
 struct IpaDims {
   int B, F, N, H;
@@ -116,18 +116,18 @@ extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const fl
 
 // o_pt[b,f,i,h,c] = sum_j P[b,f,h,i,j] * v_pts[b,f,j,h,c]   (c = 36 point components, fp32)
 __global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restrict__ P, const float* __restrict__ v_pts,
-                                                          float* __restrict__ o_pt, IpaDims d) {
+                                                          float* __restrict__ o_pt, IpaDims d, int rows_per_block) {
   extern __shared__ float sm[];
   const int N = d.N, H = d.H;
   float* vp = sm;             // [N][VPS]
-  float* pt = sm + N * VPS;   // [ROWS][N]
-  const int bf = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ROWS_PER_BLOCK;
+  float* pt = sm + N * VPS;   // [rows][N]
+  const int bf = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * rows_per_block;
   const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
   for (int e = threadIdx.x; e < N * VP; e += 256) {
     const int j = e / VP, c = e - j * VP;
     vp[j * VPS + c] = vbase[(long)j * H * VP + c];
   }
-  const int rows = min(ROWS_PER_BLOCK, N - i0);
+  const int rows = min(rows_per_block, N - i0);
   const float* pbase = P + (((long)bf * H + h) * N + i0) * N;
   for (int e = threadIdx.x; e < rows * N; e += 256) pt[e] = pbase[e];
   __syncthreads();
@@ -143,11 +143,15 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
                                  void* stream) {
   if (!P || !v_pts || !o_pt || B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  const size_t lds = ((size_t)N * VPS + (size_t)ROWS_PER_BLOCK * N) * sizeof(float);
-  if (lds > 160 * 1024) return DFOLD_EINVAL;
-  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  // rows per block: as many as fit next to the value-point table in ~76 KiB (two blocks per CU), at most 64
+  int rows = (int)((76 * 1024 - (long)N * VPS * 4) / ((long)N * 4));
+  if (rows > 64) rows = 64;
+  if (rows < 4) rows = (int)((160 * 1024 - (long)N * VPS * 4) / ((long)N * 4));
+  if (rows < 1) return DFOLD_EINVAL;
+  const size_t lds = ((size_t)N * VPS + (size_t)rows * N) * sizeof(float);
+  dim3 grid((N + rows - 1) / rows, H, B * F);
   hipFuncSetAttribute((const void*)ipa_opt_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d);
+  DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d, rows);
   return dfold_check_launch();
 }
 

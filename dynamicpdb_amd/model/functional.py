@@ -145,6 +145,35 @@ class LinearGLNFn(Function):
         return (dx.view(ctx.xshape) if dx is not None else None, dW, db, None)
 
 
+class EmbedInFn(Function):
+    """h = SiLU(x W^T + b) for the k <= 16 wide embedder inputs (src/model/ipa_pytorch_dynamic.py:757-796, layers 0-1).
+    x fp32 [..., k] -> bf16 [..., 256]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        k = weight.shape[1]
+        x2d = x.reshape(-1, k).contiguous().float()
+        out = torch.empty((x2d.shape[0], weight.shape[0]), dtype=BF16, device=x.device)
+        check(_lib.lib().dfold_embed_in_fwd(_p(x2d), _p(weight.detach()), _p(bias.detach()), _p(out), c_int64(x2d.shape[0]),
+                                            c_int32(k), c_int32(weight.shape[0]), stream()), "dfold_embed_in_fwd")
+        ctx.save_for_backward(x2d, weight, bias)
+        ctx.xshape = x.shape
+        return out.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, weight, bias = ctx.saved_tensors
+        k = weight.shape[1]
+        g2d = g.reshape(-1, weight.shape[0]).contiguous()
+        dW = torch.zeros(weight.shape, dtype=torch.float32, device=g.device)
+        db = torch.zeros(bias.shape, dtype=torch.float32, device=g.device)
+        dx = torch.empty_like(x2d) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().dfold_embed_in_bwd(_p(x2d), _p(weight.detach()), _p(bias.detach()), _p(g2d), _p(dW), _p(db), _p(dx),
+                                            c_int64(x2d.shape[0]), c_int32(k), c_int32(weight.shape[0]), stream()),
+              "dfold_embed_in_bwd")
+        return (dx.view(ctx.xshape) if dx is not None else None, dW, db)
+
+
 def ctypes_float(v):
     import ctypes
     return ctypes.c_float(v)

@@ -231,7 +231,7 @@ class DFOLDIpaScore(nn.Module):
     @staticmethod
     def _embed(seq, x):
         """Linear-SiLU-Linear-MyLayerNorm-SiLU (:757-796); x fp32 [B,F',N,k] -> bf16 [B,F',N,d]."""
-        h = Fn.silu(Fn.linear(x, seq[0].weight, seq[0].bias)).to(BF16)     # k <= 14: negligible work
+        h = F_.EmbedInFn.apply(x, seq[0].weight, seq[0].bias)              # k <= 14: VALU kernel
         return F_.linear_gln(h, seq[2].weight, seq[2].bias, True)
 
     @staticmethod

@@ -1,0 +1,361 @@
+"""Drop-in triangle pair operators (reference: vendored OpenFold modules
+openfold/model/triangular_multiplicative_update.py:26-126 and openfold/model/triangular_attention.py:31-139 with
+Attention openfold/model/primitives.py:299-448).  Same class names, constructor arguments, forward signatures and
+state_dict keys; forward and backward run on the HIP engine (MFMA contractions + the row/pointwise kernels of
+csrc/triangle.hip).  Inputs are [N, N, c] pair tensors (a leading batch axis is looped)."""
+import math
+from ctypes import c_int32, c_int64
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import _lib, ops
+from .._lib import check, stream
+from ..ops import BF16, _p, gemm, rows_plain
+from .functional import CACHE, ctypes_float
+
+
+# ------------------------------------------------------------------------------------------------
+# small launch helpers
+# ------------------------------------------------------------------------------------------------
+
+def _row_ln_fwd(x, gamma, beta, eps=1e-5):
+    R, C = x.shape
+    y = torch.empty((R, C), dtype=BF16, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().dfold_row_ln_fwd(_p(x), c_int32(1 if x.dtype == BF16 else 0), _p(gamma), _p(beta), _p(y), _p(stats),
+                                      c_int64(R), c_int32(C), ctypes_float(eps), stream()), "dfold_row_ln_fwd")
+    return y, stats
+
+
+def _row_ln_bwd(x, stats, gamma, g, dx_bf16):
+    R, C = x.shape
+    dx = torch.empty((R, C), dtype=BF16 if dx_bf16 else torch.float32, device=x.device)
+    dgamma = torch.zeros(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.zeros(C, dtype=torch.float32, device=x.device)
+    check(_lib.lib().dfold_row_ln_bwd(_p(x), c_int32(1 if x.dtype == BF16 else 0), _p(stats), _p(gamma), _p(g), _p(dx),
+                                      c_int32(1 if dx_bf16 else 0), _p(dgamma), _p(dbeta), c_int64(R), c_int32(C), stream()),
+          "dfold_row_ln_bwd")
+    return dx, dgamma, dbeta
+
+
+def _cat_w(params):
+    return torch.cat([CACHE.w(p) for p in params], 0).contiguous()
+
+
+def _linear_grads(x2d, g2d):
+    """dW fp32 [N,K], db fp32 [N] of y = x W^T + b from x bf16 [R,K], g bf16 [R,N] (split-K reduction over R)."""
+    R, K = x2d.shape
+    N = g2d.shape[1]
+    gT = ops.transpose_bf16(g2d, R, N)
+    xT = ops.transpose_bf16(x2d, R, K)
+    dW = ops.gemm_reduce_rows(gT, xT, N, K, R)
+    db = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    ops.colsum_bf16(g2d, db, R, N, N)
+    return dW, db
+
+
+# ------------------------------------------------------------------------------------------------
+# triangle multiplicative update
+# ------------------------------------------------------------------------------------------------
+
+def _to_planes(ab, N, outgoing):
+    """ab bf16 [N*N][C2] -> planes bf16 [C2][N][N] with plane[c][i][k] = ab[(i,k)][c] (outgoing) or ab[(k,i)][c]."""
+    R, C2 = ab.shape
+    if outgoing:
+        return ops.transpose_bf16(ab, R, C2)
+    out = torch.empty((C2, R), dtype=BF16, device=ab.device)
+    return ops.transpose_bf16(ab, N, C2, ld_src=N * C2, out=out, nbatch=N, nb1=1, bs_src=(C2, 0), bs_dst=(N, 0), ld_dst=R)
+
+
+def _from_planes(planes, N, outgoing):
+    C2, R = planes.shape
+    if outgoing:
+        return ops.transpose_bf16(planes, C2, R)
+    out = torch.empty((R, C2), dtype=BF16, device=planes.device)
+    return ops.transpose_bf16(planes, C2, N, ld_src=R, out=out, nbatch=N, nb1=1, bs_src=(N, 0), bs_dst=(C2, 0), ld_dst=N * C2)
+
+
+class TriangleMultiplicationFn(Function):
+    """z fp32 [N,N,c_z], mask fp32 [N,N] -> fp32 [N,N,c_z]   (AF2 Alg. 11 / 12)"""
+
+    @staticmethod
+    def forward(ctx, z, mask, outgoing, g_in, b_in, w_ap, b_ap, w_ag, b_ag, w_bp, b_bp, w_bg, b_bg, w_g, b_g, w_z, b_z,
+                g_out, b_out):
+        L = _lib.lib()
+        N, cz = z.shape[0], z.shape[-1]
+        c = w_ap.shape[0]
+        R = N * N
+        dev = z.device
+        zf = z.reshape(R, cz).contiguous().float()
+        maskf = mask.reshape(R).contiguous().float()
+        zn, st_in = _row_ln_fwd(zf, g_in.detach(), b_in.detach())
+        wcat = _cat_w([w_ap, w_ag, w_bp, w_bg, w_g])                                   # [4c+cz, cz]
+        bcat = torch.cat([b_ap, b_ag, b_bp, b_bg, b_g]).detach().float().contiguous()
+        P5 = wcat.shape[0]
+        proj = torch.empty((R, P5), dtype=BF16, device=dev)
+        gemm(zn, wcat, proj, R, P5, cz, a_rows=rows_plain(cz), c_rows=rows_plain(P5), ldb=cz, bias=bcat)
+        ab = torch.empty((R, 2 * c), dtype=BF16, device=dev)
+        check(L.dfold_trimul_gate_fwd(_p(proj), _p(maskf), _p(ab), c_int64(R), c_int32(c), stream()), "dfold_trimul_gate_fwd")
+        planes = _to_planes(ab, N, outgoing)                                           # [2c][N][N]
+        xp = torch.empty((c, N, N), dtype=BF16, device=dev)
+        gemm(planes, planes, xp, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
+             sa=(R, 0), sb=(R, 0), sc=(R, 0), b_off=c * R)                            # x_c = a_c b_c^T   (:113-118)
+        x = ops.transpose_bf16(xp.view(c, R), c, R)                                    # [R][c]
+        xn, st_out = _row_ln_fwd(x, g_out.detach(), b_out.detach())
+        y = torch.empty((R, cz), dtype=torch.float32, device=dev)
+        gemm(xn, CACHE.w(w_z), y, R, cz, c, a_rows=rows_plain(c), c_rows=rows_plain(cz), ldb=c, bias=b_z.detach())
+        out = torch.empty((R, cz), dtype=torch.float32, device=dev)
+        check(L.dfold_gate_mul_fwd(_p(y), _p(proj, 4 * c), _p(out), c_int64(R), c_int32(cz), c_int64(P5), stream()),
+              "dfold_gate_mul_fwd")
+        ctx.save_for_backward(zf, maskf, zn, st_in, proj, planes, x, xn, st_out, y, g_in, g_out, w_ap, w_ag, w_bp, w_bg,
+                              w_g, w_z)
+        ctx.dims = (N, cz, c, outgoing, z.shape)
+        return out.view(z.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        (zf, maskf, zn, st_in, proj, planes, x, xn, st_out, y, g_in, g_out, w_ap, w_ag, w_bp, w_bg, w_g, w_z) = ctx.saved_tensors
+        N, cz, c, outgoing, zshape = ctx.dims
+        R, dev = N * N, zf.device
+        P5 = proj.shape[1]
+        dout = dout.reshape(R, cz).contiguous().float()
+        dy = torch.empty((R, cz), dtype=BF16, device=dev)
+        dproj = torch.empty((R, P5), dtype=BF16, device=dev)
+        check(L.dfold_gate_mul_bwd(_p(y), _p(proj, 4 * c), _p(dout), _p(dy), _p(dproj, 4 * c), c_int64(R), c_int32(cz),
+                                   c_int64(P5), stream()), "dfold_gate_mul_bwd")
+        dw_z, db_z = _linear_grads(xn, dy)
+        dxn = torch.empty((R, c), dtype=BF16, device=dev)
+        gemm(dy, CACHE.wt(w_z), dxn, R, c, cz, a_rows=rows_plain(cz), c_rows=rows_plain(c), ldb=cz)
+        dx, dg_out, db_out = _row_ln_bwd(x, st_out, g_out.detach(), dxn, dx_bf16=True)
+        dxp = ops.transpose_bf16(dx, R, c)                                             # [c][N][N]
+        planesT = ops.transpose_bf16(planes, N, N, nbatch=2 * c, nb1=1, bs_src=(R, 0))  # [2c][k][i|j]
+        dxpT = ops.transpose_bf16(dxp, N, N, nbatch=c, nb1=1, bs_src=(R, 0))
+        dplanes = torch.empty((2 * c, R), dtype=BF16, device=dev)
+        # da_c[i,k] = sum_j dx_c[i,j] b_c[j,k];   db_c[j,k] = sum_i dx_c[i,j] a_c[i,k]
+        gemm(dxp, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
+             sa=(R, 0), sb=(R, 0), sc=(R, 0), b_off=c * R)
+        gemm(dxpT, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
+             sa=(R, 0), sb=(R, 0), sc=(R, 0), c_off=c * R)
+        dab = _from_planes(dplanes, N, outgoing)
+        check(L.dfold_trimul_gate_bwd(_p(proj), _p(maskf), _p(dab), _p(dproj), c_int64(R), c_int32(c), stream()),
+              "dfold_trimul_gate_bwd")
+        dwcat, dbcat = _linear_grads(zn, dproj)
+        wcatT = ops.transpose_bf16(_cat_w([w_ap, w_ag, w_bp, w_bg, w_g]), P5, cz)      # [cz][P5]
+        dzn = torch.empty((R, cz), dtype=BF16, device=dev)
+        gemm(dproj, wcatT, dzn, R, cz, P5, a_rows=rows_plain(P5), c_rows=rows_plain(cz), ldb=P5)
+        dz, dg_in, db_in = _row_ln_bwd(zf, st_in, g_in.detach(), dzn, dx_bf16=False)
+        sp = lambda t, i: t[i * c:(i + 1) * c] if i < 4 else t[4 * c:]
+        return (dz.view(zshape), None, None, dg_in, db_in,
+                sp(dwcat, 0), sp(dbcat, 0), sp(dwcat, 1), sp(dbcat, 1), sp(dwcat, 2), sp(dbcat, 2), sp(dwcat, 3), sp(dbcat, 3),
+                sp(dwcat, 4), sp(dbcat, 4), dw_z, db_z, dg_out, db_out)
+
+
+class TriangleMultiplicativeUpdate(nn.Module):
+    def __init__(self, c_z, c_hidden, _outgoing=True):
+        super().__init__()
+        self.c_z, self.c_hidden, self._outgoing = c_z, c_hidden, _outgoing
+        if c_z % 8 or c_hidden % 8:
+            raise ValueError("c_z and c_hidden must be multiples of 8")
+        self.linear_a_p = nn.Linear(c_z, c_hidden)
+        self.linear_a_g = nn.Linear(c_z, c_hidden)
+        self.linear_b_p = nn.Linear(c_z, c_hidden)
+        self.linear_b_g = nn.Linear(c_z, c_hidden)
+        self.linear_g = nn.Linear(c_z, c_z)
+        self.linear_z = nn.Linear(c_hidden, c_z)
+        self.layer_norm_in = nn.LayerNorm(c_z)
+        self.layer_norm_out = nn.LayerNorm(c_hidden)
+
+    def _one(self, z, mask):
+        return TriangleMultiplicationFn.apply(
+            z, mask, self._outgoing, self.layer_norm_in.weight, self.layer_norm_in.bias,
+            self.linear_a_p.weight, self.linear_a_p.bias, self.linear_a_g.weight, self.linear_a_g.bias,
+            self.linear_b_p.weight, self.linear_b_p.bias, self.linear_b_g.weight, self.linear_b_g.bias,
+            self.linear_g.weight, self.linear_g.bias, self.linear_z.weight, self.linear_z.bias,
+            self.layer_norm_out.weight, self.layer_norm_out.bias)
+
+    def forward(self, z, mask=None):
+        if not z.is_cuda:
+            raise RuntimeError("dynamicpdb_amd triangle operators need an MI355X device tensor (no CPU fallback)")
+        if mask is None:
+            mask = z.new_ones(z.shape[:-1])
+        if z.dim() == 3:
+            return self._one(z, mask)
+        lead = z.shape[:-3]
+        zs, ms = z.reshape((-1,) + z.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
+        return torch.stack([self._one(zs[i], ms[i]) for i in range(zs.shape[0])]).reshape(lead + z.shape[-3:])
+
+
+class TriangleMultiplicationOutgoing(TriangleMultiplicativeUpdate):
+    def __init__(self, c_z, c_hidden):
+        super().__init__(c_z, c_hidden, _outgoing=True)
+
+
+class TriangleMultiplicationIncoming(TriangleMultiplicativeUpdate):
+    def __init__(self, c_z, c_hidden):
+        super().__init__(c_z, c_hidden, _outgoing=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# triangle attention
+# ------------------------------------------------------------------------------------------------
+
+class TriangleAttentionFn(Function):
+    """x fp32 [I,J,c_in] (already transposed for the ending node), mask [I,J] -> fp32 [I,J,c_in]   (AF2 Alg. 13 / 14)
+    logits[i,h,q,k] = q_{iqh}.k_{ikh}/sqrt(c) + inf*(mask[i,k]-1) + tri[h,q,k], tri = Linear_nobias(LN(x))"""
+
+    @staticmethod
+    def forward(ctx, x, mask, H, inf, g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o):
+        L = _lib.lib()
+        I, J, cin = x.shape
+        if I != J:
+            raise ValueError("triangle attention expects a square pair tensor")
+        N, R, dev = I, I * J, x.device
+        HC = w_q.shape[0]
+        C = HC // H
+        xf = x.reshape(R, cin).contiguous().float()
+        maskf = mask.reshape(R).contiguous().float()
+        xn, st = _row_ln_fwd(xf, g_ln.detach(), b_ln.detach())
+        wcat = _cat_w([w_q, w_k, w_v, w_g])                                           # [4HC, cin]
+        bcat = torch.cat([torch.zeros(3 * HC, device=dev), b_g.detach().float()]).contiguous()
+        proj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)                        # [q | k | v | g]
+        gemm(xn, wcat, proj, R, 4 * HC, cin, a_rows=rows_plain(cin), c_rows=rows_plain(4 * HC), ldb=cin, bias=bcat)
+        # triangle bias tri[h][q][k] = w_tri[h] . xn[(q,k)]  -> rows h (M = H), columns = pair cells
+        tri = torch.empty((H, R), dtype=torch.float32, device=dev)
+        gemm(CACHE.w(w_tri), xn, tri, H, R, cin, a_rows=rows_plain(cin), c_rows=rows_plain(R), ldb=cin)
+        # S[i,h,q,k] = q.k / sqrt(C): batch (i,h), rows q (stride 4HC), K = C
+        P = torch.empty((I, H, N, N), dtype=torch.float32, device=dev)
+        ld = 4 * HC
+        gemm(proj, proj, P, N, N, C, a_rows=rows_plain(ld), c_rows=rows_plain(N), ldb=ld, nbatch=I * H, nb1=H,
+             sa=(N * ld, C), sb=(N * ld, C), sc=(H * N * N, N * N), b_off=HC, alpha=1.0 / math.sqrt(C))
+        Pb = torch.empty((I, H, N, N), dtype=BF16, device=dev)
+        check(L.dfold_triatt_softmax_fwd(_p(P), _p(maskf), _p(tri), _p(Pb), c_int32(I), c_int32(H), c_int32(N),
+                                         ctypes_float(inf), stream()), "dfold_triatt_softmax_fwd")
+        vT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=I * H, nb1=H, bs_src=(N * ld, C), src_off=2 * HC)  # [I,H,C,N]
+        o = torch.empty((R, HC), dtype=torch.float32, device=dev)                      # [i,q,h,c]
+        gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=I * H, nb1=H,
+             sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * HC, C))
+        og = torch.empty((R, HC), dtype=torch.float32, device=dev)
+        check(L.dfold_gate_mul_fwd(_p(o), _p(proj, 3 * HC), _p(og), c_int64(R), c_int32(HC), c_int64(ld), stream()),
+              "dfold_gate_mul_fwd")
+        ogb = ops.cast_bf16(og)
+        out = torch.empty((R, cin), dtype=torch.float32, device=dev)
+        gemm(ogb, CACHE.w(w_o), out, R, cin, HC, a_rows=rows_plain(HC), c_rows=rows_plain(cin), ldb=HC, bias=b_o.detach())
+        ctx.save_for_backward(xf, xn, st, proj, P, Pb, o, ogb, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o)
+        ctx.dims = (N, cin, H, C, x.shape)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        xf, xn, st, proj, P, Pb, o, ogb, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o = ctx.saved_tensors
+        N, cin, H, C, xshape = ctx.dims
+        I, R, HC, dev = N, N * N, H * C, xf.device
+        ld = 4 * HC
+        dob = ops.cast_bf16(dout.reshape(R, cin).contiguous().float())
+        dw_o, db_o = _linear_grads(ogb, dob)
+        dog = torch.empty((R, HC), dtype=torch.float32, device=dev)
+        gemm(dob, CACHE.wt(w_o), dog, R, HC, cin, a_rows=rows_plain(cin), c_rows=rows_plain(HC), ldb=cin)
+        dproj = torch.empty((R, ld), dtype=BF16, device=dev)
+        do = torch.empty((R, HC), dtype=BF16, device=dev)
+        check(L.dfold_gate_mul_bwd(_p(o), _p(proj, 3 * HC), _p(dog), _p(do), _p(dproj, 3 * HC), c_int64(R), c_int32(HC),
+                                   c_int64(ld), stream()), "dfold_gate_mul_bwd")
+        nb = I * H
+        # dP = do v^T ; dS = softmax bwd ; dtri = sum_i dS
+        dP = torch.empty((I, H, N, N), dtype=torch.float32, device=dev)
+        gemm(do, proj, dP, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=ld, nbatch=nb, nb1=H,
+             sa=(N * HC, C), sb=(N * ld, C), sc=(H * N * N, N * N), b_off=2 * HC)
+        dSb = torch.empty((I, H, N, N), dtype=BF16, device=dev)
+        check(L.dfold_triatt_softmax_bwd(_p(P), _p(dP), _p(dSb), c_int64(I * H * N), c_int32(N), stream()),
+              "dfold_triatt_softmax_bwd")
+        dtri = torch.empty((H, R), dtype=torch.float32, device=dev)
+        check(L.dfold_sum_leading(_p(dP), _p(dtri), c_int32(I), c_int64(H * N * N), c_int64(H * N * N), stream()),
+              "dfold_sum_leading")
+        alpha = 1.0 / math.sqrt(C)
+        # dq = alpha dS k ; dk = alpha dS^T q ; dv = P^T do   (written straight into the q|k|v column blocks of dproj)
+        kT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=nb, nb1=H, bs_src=(N * ld, C), src_off=HC)
+        gemm(dSb, kT, dproj, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(ld), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * ld, C), alpha=alpha)
+        dSbT = ops.transpose_bf16(dSb, N, N, nbatch=nb, nb1=1, bs_src=(N * N, 0))
+        qT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=nb, nb1=H, bs_src=(N * ld, C))
+        gemm(dSbT, qT, dproj, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(ld), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * ld, C), c_off=HC, alpha=alpha)
+        PbT = ops.transpose_bf16(Pb, N, N, nbatch=nb, nb1=1, bs_src=(N * N, 0))
+        doT = ops.transpose_bf16(do, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
+        gemm(PbT, doT, dproj, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(ld), ldb=N, nbatch=nb, nb1=H,
+             sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * ld, C), c_off=2 * HC)
+        dwcat, dbcat = _linear_grads(xn, dproj)
+        # dxn = dproj Wcat + dtri^T w_tri
+        wcatT = ops.transpose_bf16(_cat_w([w_q, w_k, w_v, w_g]), ld, cin)
+        dxn32 = torch.empty((R, cin), dtype=torch.float32, device=dev)
+        gemm(dproj, wcatT, dxn32, R, cin, ld, a_rows=rows_plain(ld), c_rows=rows_plain(cin), ldb=ld)
+        dtri_b = ops.cast_bf16(dtri)                                                   # [H][R]
+        H8 = (H + 7) // 8 * 8
+        dtriT = torch.zeros((R, H8), dtype=BF16, device=dev)
+        ops.transpose_bf16(dtri_b, H, R, out=dtriT, ld_dst=H8, bs_dst=(0, 0))
+        gemm(dtriT, CACHE.wt(w_tri), dxn32, R, cin, H8, a_rows=rows_plain(H8), c_rows=rows_plain(cin), ldb=H8,
+             flags=ops.GEMM_ACCUM)
+        xnT = ops.transpose_bf16(xn, R, cin)
+        dw_tri = ops.gemm_reduce_rows(dtri_b, xnT, H, cin, R)
+        dxn = ops.cast_bf16(dxn32)
+        dx, dg_ln, db_ln = _row_ln_bwd(xf, st, g_ln.detach(), dxn, dx_bf16=False)
+        return (dx.view(xshape), None, None, None, dg_ln, db_ln, dw_tri, dwcat[:HC], dwcat[HC:2 * HC], dwcat[2 * HC:3 * HC],
+                dwcat[3 * HC:], dbcat[3 * HC:], dw_o, db_o)
+
+
+class _Attention(nn.Module):
+    """parameter container with the reference's names (openfold/model/primitives.py:299-361)"""
+
+    def __init__(self, c_q, c_hidden, no_heads):
+        super().__init__()
+        hc = c_hidden * no_heads
+        self.linear_q = nn.Linear(c_q, hc, bias=False)
+        self.linear_k = nn.Linear(c_q, hc, bias=False)
+        self.linear_v = nn.Linear(c_q, hc, bias=False)
+        self.linear_o = nn.Linear(hc, c_q)
+        self.linear_g = nn.Linear(c_q, hc)
+
+
+class TriangleAttention(nn.Module):
+    def __init__(self, c_in, c_hidden, no_heads, starting=True, inf=1e9):
+        super().__init__()
+        self.c_in, self.c_hidden, self.no_heads, self.starting, self.inf = c_in, c_hidden, no_heads, starting, inf
+        self.layer_norm = nn.LayerNorm(c_in)
+        self.linear = nn.Linear(c_in, no_heads, bias=False)
+        self.mha = _Attention(c_in, c_hidden, no_heads)
+
+    def _one(self, x, mask):
+        m = self.mha
+        return TriangleAttentionFn.apply(x, mask, self.no_heads, self.inf, self.layer_norm.weight, self.layer_norm.bias,
+                                         self.linear.weight, m.linear_q.weight, m.linear_k.weight, m.linear_v.weight,
+                                         m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
+
+    def forward(self, x, mask=None, chunk_size=None, use_memory_efficient_kernel=False, use_lma=False, inplace_safe=False):
+        if not x.is_cuda:
+            raise RuntimeError("dynamicpdb_amd triangle operators need an MI355X device tensor (no CPU fallback)")
+        if mask is None:
+            mask = x.new_ones(x.shape[:-1])
+        if not self.starting:
+            x, mask = x.transpose(-2, -3), mask.transpose(-1, -2)
+        if x.dim() == 3:
+            y = self._one(x.contiguous(), mask.contiguous())
+        else:
+            lead = x.shape[:-3]
+            xs, ms = x.reshape((-1,) + x.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
+            y = torch.stack([self._one(xs[i].contiguous(), ms[i].contiguous()) for i in range(xs.shape[0])])
+            y = y.reshape(lead + x.shape[-3:])
+        if not self.starting:
+            y = y.transpose(-2, -3)
+        return y
+
+
+class TriangleAttentionStartingNode(TriangleAttention):
+    def __init__(self, c_in, c_hidden, no_heads, inf=1e9):
+        super().__init__(c_in, c_hidden, no_heads, starting=True, inf=inf)
+
+
+class TriangleAttentionEndingNode(TriangleAttention):
+    def __init__(self, c_in, c_hidden, no_heads, inf=1e9):
+        super().__init__(c_in, c_hidden, no_heads, starting=False, inf=inf)

@@ -136,6 +136,43 @@ int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, 
                         float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Triangle pair operators (openfold/model/triangular_multiplicative_update.py:26-126 TriangleMultiplication
+ * Outgoing/Incoming; openfold/model/triangular_attention.py:31-139 TriangleAttentionStarting/EndingNode with
+ * Attention / _attention openfold/model/primitives.py:219-243,299-448; LayerNorm primitives.py:180-198).
+ * Row / pointwise passes; the projections, the ik,jk->ij contraction and the q.k / a.v products use dfold_gemm_bf16.
+ * ---------------------------------------------------------------------------------------------- */
+/* y = LayerNorm_C(x) * gamma + beta (biased variance, eps inside sqrt); x fp32|bf16 [R][C]; stats[r] = {mean, rstd} */
+int dfold_row_ln_fwd(const void* x, int32_t x_is_bf16, const float* gamma, const float* beta, void* y_bf16, float* stats,
+                     int64_t R, int32_t C, float eps, void* stream);
+/* dx (fp32|bf16), dgamma += , dbeta += (fp32 atomics; caller zeroes) from g = dL/dy (bf16) */
+int dfold_row_ln_bwd(const void* x, int32_t x_is_bf16, const float* stats, const float* gamma, const void* g_bf16, void* dx,
+                     int32_t dx_is_bf16, float* dgamma, float* dbeta, int64_t R, int32_t C, void* stream);
+/* proj bf16 [R][5c] = [a_p|a_g|b_p|b_g|g] -> ab bf16 [R][2c]: a = a_p*sigmoid(a_g)*mask[r], b likewise (:97-104) */
+int dfold_trimul_gate_fwd(const void* proj, const float* mask, void* ab, int64_t R, int32_t c, void* stream);
+int dfold_trimul_gate_bwd(const void* proj, const float* mask, const void* dab, void* dproj, int64_t R, int32_t c, void* stream);
+/* out = y * sigmoid(g): y fp32 [R][c], g bf16 with row stride ldg (:122-124; primitives.py:385-390) */
+int dfold_gate_mul_fwd(const float* y, const void* g, float* out, int64_t R, int32_t c, int64_t ldg, void* stream);
+int dfold_gate_mul_bwd(const float* y, const void* g, const float* dout, void* dy_bf16, void* dg_bf16, int64_t R, int32_t c,
+                       int64_t ldg, void* stream);
+/* S fp32 [I][H][N][N] -> P in place (+bf16 copy): softmax_k(S + inf*(mask[i,k]-1) + tri[h,q,k]) (triangular_attention.py:105-113) */
+int dfold_triatt_softmax_fwd(float* S, const float* mask, const float* tri, void* P_bf16, int32_t I, int32_t H, int32_t N,
+                             float inf, void* stream);
+/* dP -> dS = P*(dP - sum_k P dP) in place (+bf16 copy) */
+int dfold_triatt_softmax_bwd(const float* P, float* dP, void* dS_bf16, int64_t rows, int32_t N, void* stream);
+/* out[e] = sum_{i<I} x[i*stride + e], e < n (fp32) */
+int dfold_sum_leading(const float* x, float* out, int32_t I, int64_t n, int64_t stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * First layer of the feature embedders (force/vel/index/rigid/angle_embeder[0:2], src/model/ipa_pytorch_dynamic.py:
+ * 757-796): h = SiLU(x W^T + b), x fp32 [P,k] (k <= 16), W fp32 [256,k], h bf16 [P,256].  Backward accumulates
+ * dW / db with fp32 atomics (caller zeroes them); dx (fp32 [P,k]) may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_embed_in_fwd(const float* x, const float* W, const float* b, void* out_bf16, int64_t P, int32_t k, int32_t D,
+                       void* stream);
+int dfold_embed_in_bwd(const float* x, const float* W, const float* b, const void* g_bf16, float* dW, float* db, float* dx,
+                       int64_t P, int32_t k, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * IGSO(3) score series (SO3Diffuser.torch_score src/data/so3_diffuser.py:274-305, igso3_expansion :9-49,
  * score :71-117): sc[p] = dsig(omega_p)/(f(omega_p)+1e-4) with the reference's fp32-trig / fp64-envelope
  * mixed precision, plus dsc = d sc / d omega for the backward.  env fp64 [windows][L] = (2l+1)exp(-l(l+1)s^2/2);
