@@ -56,7 +56,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
 
     def timed_gemm(*a, **kw):
         rows = kw.get("a_rows")
-        is_conv = rows is not None and rows.mode == 1 and kw.get("nseg", 1) == 25
+        is_conv = rows is not None and rows.mode == 1 and kw.get("seg_div_mid", 0) == 5
         if not is_conv:
             return orig(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

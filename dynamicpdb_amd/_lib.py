@@ -19,9 +19,10 @@ class RowMap(Structure):
 
 class GemmDesc(Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("bias", c_void_p),
-                ("R", c_void_p), ("R2", c_void_p), ("zeros", c_void_p), ("a_seg0", c_int64), ("a_seg_s1", c_int64),
-                ("a_seg_s2", c_int64), ("b_seg0", c_int64), ("b_seg_s1", c_int64), ("b_seg_s2", c_int64),
-                ("seg_div", c_int32), ("a_rows", RowMap), ("c_rows", RowMap), ("ldb", c_int64),
+                ("R", c_void_p), ("R2", c_void_p), ("zeros", c_void_p), ("a_seg0", c_int64), ("a_seg_s0", c_int64),
+                ("a_seg_s1", c_int64), ("a_seg_s2", c_int64), ("b_seg0", c_int64), ("b_seg_s0", c_int64),
+                ("b_seg_s1", c_int64), ("b_seg_s2", c_int64), ("seg_div", c_int32), ("seg_div_mid", c_int32),
+                ("a_rows", RowMap), ("c_rows", RowMap), ("ldb", c_int64),
                 ("sa0", c_int64), ("sa1", c_int64), ("sb0", c_int64), ("sb1", c_int64), ("sc0", c_int64),
                 ("sc1", c_int64), ("M", c_int32), ("N", c_int32), ("nseg", c_int32), ("seglen", c_int32),
                 ("nbatch", c_int32), ("nb1", c_int32), ("flags", c_int32), ("alpha", c_float)]

@@ -35,9 +35,11 @@ struct GemmParams {
   const bf16_t* R;
   const bf16_t* R2;
   const bf16_t* zeros;
-  long a_seg0, a_seg_s1, a_seg_s2;  // A offset of K segment g: a_seg0 + (g / seg_div) * a_seg_s1 + (g % seg_div) * a_seg_s2
-  long b_seg0, b_seg_s1, b_seg_s2;
-  int seg_div;
+  // element offset of K segment g = (hi, mid, lo), lo = g % seg_div, mid = (g / seg_div) % seg_div_mid, hi = the rest:
+  //   seg0 + hi * seg_s0 + mid * seg_s1 + lo * seg_s2
+  long a_seg0, a_seg_s0, a_seg_s1, a_seg_s2;
+  long b_seg0, b_seg_s0, b_seg_s1, b_seg_s2;
+  int seg_div, seg_div_mid;
   RowMap am, cm;
   long ldb;
   long sa0, sa1, sb0, sb1, sc0, sc1;
@@ -49,7 +51,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Shared epilogue: 2x2 MFMA 32x32 accumulator tiles of one wave -> C (C/D layout: col = lane&31,
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5)).
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], long mbase, int nbase, long coff,
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NJ], long mbase, int nbase, long coff,
                                               int lane) {
   const int fl = p.flags;
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -61,7 +64,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       if (m >= p.M) continue;
       const long ro = row_off(p.cm, m) + coff;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = nbase + j * 32 + frow;
         if (n >= p.N) continue;
         float v = acc[i][j][e] * p.alpha;
@@ -125,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParam
 
   // K-step cursor of the NEXT tile to stage (stages are issued in increasing step order): segment (hi, lo) and
   // offset kk inside it -- pure scalar arithmetic, no table loads (a VMEM load here would force vmcnt(0)).
-  int st_hi = 0, st_lo = 0, st_kk = 0;
+  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0;
   auto stage = [&](int buf, int) {
-    const long ao = p.a_seg0 + st_hi * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
-    const long bo = p.b_seg0 + st_hi * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
+    const long ao = p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
+    const long bo = p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
     const int kk = st_kk;
     const bool kin = (kk + kofs) < p.seglen;
     st_kk += BK;
@@ -136,7 +139,10 @@ __global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParam
       st_kk = 0;
       if (++st_lo == p.seg_div) {
         st_lo = 0;
-        ++st_hi;
+        if (++st_mid == p.seg_div_mid) {
+          st_mid = 0;
+          ++st_hi;
+        }
       }
     }
     char* la = lds + buf * 2 * TILE_BYTES;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void dfold_mfma_gemm_kernel(const GemmParam
     }
   }
 
-  gemm_epilogue(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+  gemm_epilogue<2>(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
 }
 
 
@@ -240,10 +246,10 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 
   // K-step cursor of the NEXT tile to stage (stages are issued in increasing step order): segment (hi, lo) and
   // offset kk inside it -- pure scalar arithmetic, no table loads (a VMEM load here would force vmcnt(0)).
-  int st_hi = 0, st_lo = 0, st_kk = 0;
+  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0;
   auto stage = [&](int buf, int) {
-    const long ao = p.a_seg0 + st_hi * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
-    const long bo = p.b_seg0 + st_hi * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
+    const long ao = p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk;
+    const long bo = p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk;
     const int kk = st_kk;
     const bool kin = (kk + kofs) < p.seglen;
     st_kk += BK;
@@ -251,7 +257,10 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
       st_kk = 0;
       if (++st_lo == p.seg_div) {
         st_lo = 0;
-        ++st_hi;
+        if (++st_mid == p.seg_div_mid) {
+          st_mid = 0;
+          ++st_hi;
+        }
       }
     }
     char* la = lds2 + buf * STAGE2_BYTES;
@@ -315,7 +324,298 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
     cur = cur + 1 == NSTAGE2 ? 0 : cur + 1;
   }
 
-  gemm_epilogue(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+  gemm_epilogue<2>(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Conv-tower variant: 256(M) x 320(N) x 64 tile -- 640 and 1280 output channels tile exactly (no padding waste),
+// 8 waves as 4(M) x 2(N), each wave 64 x 160 = 2 x 5 MFMA 32x32x16 tiles (160 accumulator registers).
+// Per K16 step a wave reads 7 fragments for 10 MFMAs (0.7 ds_read_b128 per MFMA vs 1.0 in the 64x64 wave tile) and a
+// K step moves 72 KiB HBM/L2 -> LDS for 10.5 MFLOP (vs 48 KiB for 4.2): the LDS port stops being the limiter.
+// Two LDS stages (2 x 72 KiB): wait tile s, barrier, launch the LDS-DMA of tile s+1, run 40 MFMAs per wave on tile s.
+// ------------------------------------------------------------------------------------------------
+#define BM3 256
+#define BN3 320
+#define A3_BYTES (BM3 * BK * 2)
+#define B3_BYTES (BN3 * BK * 2)
+#define STAGE3_BYTES (A3_BYTES + B3_BYTES)
+
+template <int ROLE>
+__global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  const int tiles_n = (p.N + BN3 - 1) / BN3;
+  const int m0 = (lid / tiles_n) * BM3, n0 = (lid % tiles_n) * BN3;
+  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+  const char* A = (const char*)(p.A + z0 * p.sa0 + z1 * p.sa1);
+  const char* B = (const char*)(p.B + z0 * p.sb0 + z1 * p.sb1);
+  const long coff = z0 * p.sc0 + z1 * p.sc1;
+
+  // Per-lane staging offsets are 32-bit byte offsets from the (wave-uniform) operand base, so every LDS-DMA is
+  // "SGPR base + VGPR offset" and 9 registers hold all row addresses.  Rows past M / N are clamped (their products
+  // are never stored); the host only dispatches here when seglen % 64 == 0, so there is no K tail to zero.
+  const int cphys = lane & 7;
+  const int rsub = lane >> 3;
+  const int clog = cphys ^ ((((w & 1) << 2) + (lane >> 4)) & 7);
+  const int kofs = clog * 8;
+  unsigned aoff[4], boff[5];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    long m = (long)m0 + (t * 8 + w) * 8 + rsub;
+    if (m >= p.M) m = p.M - 1;
+    aoff[t] = (unsigned)((row_off(p.am, m) + kofs) * 2);
+  }
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    long n = (long)n0 + (t * 8 + w) * 8 + rsub;
+    if (n >= p.N) n = p.N - 1;
+    boff[t] = (unsigned)((n * p.ldb + kofs) * 2);
+  }
+  const int nsteps = p.nseg * (p.seglen / BK);
+
+  // Tile cursor: (sa_cur, sb_cur) = operand bases of the tile staged next; advanced branch-free so that the DMA
+  // issue has no control flow around it (the scheduler can then spread the 9 pieces between MFMAs).  After the
+  // last tile the cursor stays put: the final, unused prefetch re-reads valid memory into the idle buffer.
+  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0, st_left = nsteps;
+  auto stage = [&](int buf) {
+    const char* sa = A + (p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk) * 2;
+    const char* sb = B + (p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk) * 2;
+    const bool adv = st_left > 1;
+    st_left -= adv ? 1 : 0;
+    int kk = st_kk + BK, lo = st_lo, mid = st_mid, hi = st_hi;
+    const bool w0 = kk >= p.seglen;
+    kk = w0 ? 0 : kk;
+    lo += w0 ? 1 : 0;
+    const bool w1 = lo == p.seg_div;
+    lo = w1 ? 0 : lo;
+    mid += w1 ? 1 : 0;
+    const bool w2 = mid == p.seg_div_mid;
+    mid = w2 ? 0 : mid;
+    hi += w2 ? 1 : 0;
+    st_kk = adv ? kk : st_kk;
+    st_lo = adv ? lo : st_lo;
+    st_mid = adv ? mid : st_mid;
+    st_hi = adv ? hi : st_hi;
+    char* la = lds3 + buf * STAGE3_BYTES;
+    char* lb = la + A3_BYTES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (lane >> 1) & 7;
+  const int fhalf = lane >> 5;
+  const int fa = (wm * 64 + frow) * 128;
+  const int fb = A3_BYTES + (wn * 160 + frow) * 128;
+
+  stage(0);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* la = lds3 + (s & 1) * STAGE3_BYTES + fa;
+    const char* lb = lds3 + (s & 1) * STAGE3_BYTES + fb;
+    // Register double-buffered fragments (the ds_read_b128 of K16 block k4+1 fly under the MFMAs of k4) and the 9
+    // LDS-DMA pieces of the NEXT tile are spread one per two MFMAs, so their issue cost (address VALU + ~60-100
+    // cycles each) hides in the matrix-pipe gaps instead of serialising at the top of the step.
+    bf16x8 af[2][2], bfr[2][5];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int ch = ((kb * 2 + fhalf) ^ fsw) << 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[kb][i] = *(const bf16x8*)(la + i * 32 * 128 + ch);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) bfr[kb][j] = *(const bf16x8*)(lb + j * 32 * 128 + ch);
+    }
+    stage((s + 1) & 1);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k4 & 1][i], bfr[k4 & 1][j], acc[i][j], 0, 0, 0);
+      if (k4 < 2) {
+        const int ch = (((k4 + 2) * 2 + fhalf) ^ fsw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[k4 & 1][i] = *(const bf16x8*)(la + i * 32 * 128 + ch);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bfr[k4 & 1][j] = *(const bf16x8*)(lb + j * 32 * 128 + ch);
+      }
+    }
+    // pinned issue order
+    __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+  }
+  gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Deep-prefetch form of the 256 x 320 kernel: K step 32, FOUR 36-KiB LDS slots used as a ring.  The LDS-DMA of
+// tiles s+1 and s+2 stays in flight across the barrier of step s (counted s_waitcnt vmcnt, raw s_barrier) and the
+// DMA of tile s+3 is launched right after it, so a loaded-memory-system latency of 2-3 K steps is hidden.
+// LDS rows are 64 B (4 chunks of 16 B): physical chunk = logical ^ ((row >> 2) & 3) -> conflict-free ds_read_b128.
+// Per K step a wave issues 2 (A) + 3|2 (B) DMA pieces, 14 ds_read_b128 and 20 MFMAs.
+// ------------------------------------------------------------------------------------------------
+#define BK4 32
+#define A4_BYTES (BM3 * BK4 * 2)  // 16 KiB
+#define B4_BYTES (BN3 * BK4 * 2)  // 20 KiB
+#define SLOT4_BYTES (A4_BYTES + B4_BYTES)
+#define NSLOT4 4
+
+template <int ROLE>
+__global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320r_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds4[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  const int tiles_n = (p.N + BN3 - 1) / BN3;
+  const int m0 = (lid / tiles_n) * BM3, n0 = (lid % tiles_n) * BN3;
+  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+  const char* A = (const char*)(p.A + z0 * p.sa0 + z1 * p.sa1);
+  const char* B = (const char*)(p.B + z0 * p.sb0 + z1 * p.sb1);
+  const long coff = z0 * p.sc0 + z1 * p.sc1;
+
+  const int rsub = lane >> 2;                          // row inside a 16-row DMA piece
+  const int kofs = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;  // logical k chunk fetched by this lane
+  const bool b3 = w < 4;                               // waves 0-3 move three B pieces per tile, waves 4-7 two
+  unsigned aoff[2], boff[3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long m = (long)m0 + (t * 8 + w) * 16 + rsub;
+    if (m >= p.M) m = p.M - 1;
+    aoff[t] = (unsigned)((row_off(p.am, m) + kofs) * 2);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    long n = (long)n0 + (t * 8 + w) * 16 + rsub;
+    if (n >= p.N) n = p.N - 1;
+    boff[t] = (unsigned)((n * p.ldb + kofs) * 2);
+  }
+  const int nsteps = p.nseg * (p.seglen / BK4);
+
+  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0;
+  auto stage = [&](int slot) {
+    const char* sa = A + (p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk) * 2;
+    const char* sb = B + (p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk) * 2;
+    st_kk += BK4;
+    if (st_kk >= p.seglen) {
+      st_kk = 0;
+      if (++st_lo == p.seg_div) {
+        st_lo = 0;
+        if (++st_mid == p.seg_div_mid) {
+          st_mid = 0;
+          ++st_hi;
+        }
+      }
+    }
+    char* la = lds4 + slot * SLOT4_BYTES;
+    char* lb = la + A4_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+    if (b3) __builtin_amdgcn_global_load_lds((const void*)(sb + boff[2]), (lds_ptr_t)(lb + (16 + w) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fsw = (lane >> 2) & 3;
+  const int fhalf = lane >> 5;
+  const int fa = (wm * 64 + frow) * 64;
+  const int fb = A4_BYTES + (wn * 160 + frow) * 64;
+  const int ch0 = ((0 + fhalf) ^ fsw) << 4, ch1 = ((2 + fhalf) ^ fsw) << 4;
+
+  // prologue: tiles 0..2 in flight
+  stage(0);
+  if (nsteps > 1) stage(1);
+  if (nsteps > 2) stage(2);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // tile s must have landed; later tiles (5 or 4 pieces each for this wave) may stay in flight
+    const int ahead = nsteps - 1 - s;   // tiles issued after tile s
+    if (ahead >= 2) {
+      if (b3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (ahead == 1) {
+      if (b3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 3 < nsteps) stage((slot + 3) & 3);
+    const char* la = lds4 + slot * SLOT4_BYTES + fa;
+    const char* lb = lds4 + slot * SLOT4_BYTES + fb;
+    bf16x8 af[2][2], bfr[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[0][i] = *(const bf16x8*)(la + i * 32 * 64 + ch0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) bfr[0][j] = *(const bf16x8*)(lb + j * 32 * 64 + ch0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[1][i] = *(const bf16x8*)(la + i * 32 * 64 + ch1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) bfr[1][j] = *(const bf16x8*)(lb + j * 32 * 64 + ch1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kb][i], bfr[kb][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+    slot = (slot + 1) & 3;
+  }
+  gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
+}
+
+static long row_off_host(const RowMap& r, long m) {
+  if (r.mode == 0) return r.base + m * r.ld;
+  const long wf = m / r.n, n = m - wf * r.n, w = wf / r.f, f = wf - w * r.f;
+  return r.base + (((w * r.fp + f) * r.wp) + n) * r.ld;
 }
 
 static RowMap to_rowmap(const dfold_rowmap* r) {
@@ -328,7 +628,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C || !d->zeros) return DFOLD_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->nseg <= 0 || d->seglen <= 0 || d->nbatch <= 0) return DFOLD_EINVAL;
   if ((d->seglen & 7) || (d->ldb & 7) || (d->a_rows.ld & 7) || (d->a_rows.base & 7)) return DFOLD_EINVAL;  // 16-B chunks
-  if ((d->a_seg0 | d->a_seg_s1 | d->a_seg_s2 | d->b_seg0 | d->b_seg_s1 | d->b_seg_s2) & 7) return DFOLD_EINVAL;
+  if ((d->a_seg0 | d->a_seg_s0 | d->a_seg_s1 | d->a_seg_s2 | d->b_seg0 | d->b_seg_s0 | d->b_seg_s1 | d->b_seg_s2) & 7) return DFOLD_EINVAL;
   if ((d->flags & DFOLD_GEMM_BIAS) && !d->bias) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) && !d->R) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
@@ -337,23 +637,62 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   GemmParams p;
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.C2 = d->C2;
   p.bias = d->bias; p.R = (const bf16_t*)d->R; p.R2 = (const bf16_t*)d->R2; p.zeros = (const bf16_t*)d->zeros;
-  p.a_seg0 = d->a_seg0; p.a_seg_s1 = d->a_seg_s1; p.a_seg_s2 = d->a_seg_s2;
-  p.b_seg0 = d->b_seg0; p.b_seg_s1 = d->b_seg_s1; p.b_seg_s2 = d->b_seg_s2;
+  p.a_seg0 = d->a_seg0; p.a_seg_s0 = d->a_seg_s0; p.a_seg_s1 = d->a_seg_s1; p.a_seg_s2 = d->a_seg_s2;
+  p.b_seg0 = d->b_seg0; p.b_seg_s0 = d->b_seg_s0; p.b_seg_s1 = d->b_seg_s1; p.b_seg_s2 = d->b_seg_s2;
   p.seg_div = d->seg_div > 0 ? d->seg_div : 1;
+  p.seg_div_mid = d->seg_div_mid > 0 ? d->seg_div_mid : 0x7fffffff;
   p.am = to_rowmap(&d->a_rows); p.cm = to_rowmap(&d->c_rows);
   p.ldb = d->ldb;
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
-  const int role = (d->a_rows.mode == 1 && d->nseg == 25) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
+  const int role = (d->a_rows.mode == 1 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
   const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
   const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);
   static int variant = -1;   // DFOLD_GEMM_VARIANT=128 forces the 128x128 kernel (A/B measurements)
   if (variant < 0) {
     const char* e = getenv("DFOLD_GEMM_VARIANT");
-    variant = (e && atoi(e) == 128) ? 128 : 256;
+    variant = e ? atoi(e) : 256;   // 128: 128x128 only; 2560: no 256x320 kernel; default: all variants
   }
-  if (variant == 256 && d->M >= 1024 && steps >= 4 && tiles256 * d->nbatch >= 192) {
+  const long tiles320 = (long)((d->M + BM3 - 1) / BM3) * ((d->N + BN3 - 1) / BN3);
+  const long a_extent = row_off_host(p.am, d->M - 1) + d->a_rows.ld;   // elements spanned by the A rows of one batch
+  if (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && d->M >= 2048 && steps >= 4 &&
+      tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      attr3_done = true;
+    }
+    dim3 grid3((unsigned)tiles320, d->nbatch, 1);
+    if (variant == 3200) {  // DFOLD_GEMM_VARIANT=3200: 4-slot ring, K step 32 (measured slower than the 2-stage K-64 form)
+      static bool attr4_done = false;
+      if (!attr4_done) {
+        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
+        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
+        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
+        attr4_done = true;
+      }
+      const size_t lds4b = NSLOT4 * SLOT4_BYTES;
+      if (role == 1)
+        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<1>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
+      else if (role == 2)
+        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<2>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
+      else
+        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<0>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
+      return dfold_check_launch();
+    }
+    const size_t lds = 2 * STAGE3_BYTES;
+    if (role == 1)
+      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<1>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+    else if (role == 2)
+      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<2>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+    else
+      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<0>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+    return dfold_check_launch();
+  }
+  if (variant >= 256 && d->M >= 1024 && steps >= 4 && tiles256 * d->nbatch >= 192) {
     static bool attr_done = false;
     if (!attr_done) {
       hipFuncSetAttribute((const void*)dfold_mfma_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2_BYTES);
@@ -373,9 +712,9 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   }
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   dim3 grid(tiles, d->nbatch, 1);
-  if (d->a_rows.mode == 1 && d->nseg == 25)
+  if (role == 1)
     DFOLD_LAUNCH(dfold_mfma_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (d->nbatch == 25 && d->nb1 == 5)
+  else if (role == 2)
     DFOLD_LAUNCH(dfold_mfma_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else
     DFOLD_LAUNCH(dfold_mfma_gemm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -47,7 +47,7 @@ def seg_table(values, device):
 
 
 def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
-         a_seg=None, b_seg=None, seg_div=1, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
+         a_seg=None, b_seg=None, seg_div=1, seg_div_mid=0, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
          a_off=0, b_off=0, c_off=0):
     """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
     assert A.dtype == BF16 and B.dtype == BF16
@@ -63,11 +63,14 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.bias, d.R, d.R2 = _p(bias), _p(R, c_off), _p(R2, c_off)
     d.zeros = _p(zeros_page(A.device))
     # K-segment offsets (seg0, s1, s2): seg0 + (g // seg_div)*s1 + (g % seg_div)*s2; default = contiguous K
+    # (seg0, s_mid, s_lo) or (seg0, s_hi, s_mid, s_lo)
     a_seg = a_seg or (0, seglen * seg_div, seglen)
     b_seg = b_seg or (0, seglen * seg_div, seglen)
-    d.a_seg0, d.a_seg_s1, d.a_seg_s2 = a_seg
-    d.b_seg0, d.b_seg_s1, d.b_seg_s2 = b_seg
-    d.seg_div = seg_div
+    a_seg = a_seg if len(a_seg) == 4 else (a_seg[0], 0, a_seg[1], a_seg[2])
+    b_seg = b_seg if len(b_seg) == 4 else (b_seg[0], 0, b_seg[1], b_seg[2])
+    d.a_seg0, d.a_seg_s0, d.a_seg_s1, d.a_seg_s2 = a_seg
+    d.b_seg0, d.b_seg_s0, d.b_seg_s1, d.b_seg_s2 = b_seg
+    d.seg_div, d.seg_div_mid = seg_div, seg_div_mid
     d.a_rows, d.c_rows = a_rows, c_rows
     d.ldb = ldb
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
@@ -195,9 +198,10 @@ class Grid:
     def rows_center(self, C, ch_off=0):  # the cell itself
         return rows_grid(C, self.N, self.F, self.Fp, self.Wp, (2 * self.Wp + 2) * C + ch_off)
 
-    def tap_offsets(self, C):
-        """K segment g = 5*df + dn of the implicit GEMM reads the cell at (+df rows, +dn columns)."""
-        return (0, self.Wp * C, C)
+    def tap_offsets(self, C, ck=64):
+        """K segment (chunk, df, dn) of the implicit GEMM: ck channels starting at chunk*ck of the cell at (+df rows,
+        +dn columns).  Channel chunk OUTERMOST: the 25 shifted re-reads of one activation chunk stay in the XCD's L2."""
+        return (0, ck, self.Wp * C, C)
 
     def seg_shifted(self):
         """wgrad K segment = window w of a transposed [c][w][f'][n] copy, starting at padded frame row 0 ..."""
@@ -221,8 +225,10 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         R = relu_mask
     if pre_resid_out is not None:
         C2, R2 = pre_resid_out, None
-    return gemm(x, wf, out, g.M, CO, CI, nseg=25, a_rows=g.rows_in(CI), c_rows=g.rows_center(CO), ldb=25 * CI,
-                bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI), seg_div=5, flags=flags)
+    ck = 64 if CI % 64 == 0 else CI            # K chunk per segment (one MFMA K step when channels allow)
+    return gemm(x, wf, out, g.M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI), c_rows=g.rows_center(CO),
+                ldb=25 * CI, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
+                seg_div=5, seg_div_mid=5, flags=flags)
 
 
 def grid_transpose_shift(g, x, C, d0, nd, out):

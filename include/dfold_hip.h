@@ -64,11 +64,14 @@ typedef struct {
   const void* R;        /* bf16, see flags */
   const void* R2;       /* bf16 mask for C2 */
   const void* zeros;    /* >= 16 bytes of zeros, 16-B aligned (source for out-of-range tile cells) */
-  /* element offset added to every A (B) row for K segment g:  seg0 + (g / seg_div)*seg_s1 + (g % seg_div)*seg_s2
-     (conv taps: g = 5*df + dn -> (df*Wp + dn)*C;  plain contiguous K: seg_s1 = seglen, seg_div = 1) */
-  int64_t a_seg0, a_seg_s1, a_seg_s2;
-  int64_t b_seg0, b_seg_s1, b_seg_s2;
-  int32_t seg_div;
+  /* element offset added to every A (B) row for K segment g = (hi, mid, lo), lo = g % seg_div,
+     mid = (g / seg_div) % seg_div_mid (seg_div_mid <= 0: unbounded), hi = the rest:
+         seg0 + hi*seg_s0 + mid*seg_s1 + lo*seg_s2
+     conv implicit GEMM: hi = 64-channel chunk, mid = df, lo = dn (channel-chunk-outer order keeps the 25 shifted
+     re-reads of an activation chunk in the XCD's L2); plain contiguous K: seg_s1 = seglen, seg_div = 1 */
+  int64_t a_seg0, a_seg_s0, a_seg_s1, a_seg_s2;
+  int64_t b_seg0, b_seg_s0, b_seg_s1, b_seg_s2;
+  int32_t seg_div, seg_div_mid;
   dfold_rowmap a_rows, c_rows;
   int64_t ldb;
   int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements): batch z -> (z / nb1, z % nb1) */

@@ -22,7 +22,8 @@ def _rand_bf16(shape, dev, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1024, 640, 1280), (77, 6, 1280), (4096, 40, 128),
-                                   (16384, 384, 520), (16500, 700, 256)])   # the last two run the 256x128 3-stage kernel
+                                   (16384, 384, 520), (16500, 700, 256),    # 256x128 3-stage kernel
+                                   (32768, 640, 520), (16500, 1280, 192)])  # 256x320 conv-tower kernel
 def test_gemm_plain(dev, M, N, K):
     from dynamicpdb_amd import ops
     a, b = _rand_bf16((M, K), dev, 1), _rand_bf16((N, K), dev, 2)
@@ -72,7 +73,12 @@ def test_splitk_reduce_rows(dev):
 def test_conv_fwd_large_grid_vs_torch(dev):
     """implicit-GEMM conv on a grid large enough for the 256x128 3-stage kernel, vs torch conv2d (fp64)"""
     from dynamicpdb_amd import ops
-    Wn, F, N, CI, CO = 6, 8, 128, 64, 512
+    _conv_case(dev, 6, 8, 128, 64, 512)       # 256x128 kernel
+    _conv_case(dev, 8, 16, 128, 64, 640)      # 256x320 kernel
+
+
+def _conv_case(dev, Wn, F, N, CI, CO):
+    from dynamicpdb_amd import ops
     torch.manual_seed(3)
     w = (torch.randn(CO, CI, 5, 5, device=dev) / np.sqrt(25 * CI))
     bias = 0.1 * torch.randn(CO, device=dev)
