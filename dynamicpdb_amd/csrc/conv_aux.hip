@@ -104,11 +104,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_unpack_kernel(const float* __r
   }
 }
 
+// transposed accumulator layout dWgT fp32 [CI][25][CO] -> G fp32 [CO][CI][25]; block = 16 ci x 32 co
+__global__ __launch_bounds__(256) void conv_wgrad_unpack_t_kernel(const float* __restrict__ dWgT, float* __restrict__ G,
+                                                                  int CO, int CI, int accumulate) {
+  __shared__ float t[16][25][33];
+  const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 32;
+  for (int e = threadIdx.x; e < 16 * 25 * 32; e += 256) {
+    const int co = e & 31, tap = (e >> 5) % 25, ci = e / (32 * 25);
+    if (ci0 + ci < CI && co0 + co < CO) t[ci][tap][co] = dWgT[((long)(ci0 + ci) * 25 + tap) * CO + co0 + co];
+  }
+  __syncthreads();
+  const int cw = min(16, CI - ci0);
+  for (int co = 0; co < 32 && co0 + co < CO; ++co) {
+    float* dst = G + ((long)(co0 + co) * CI + ci0) * 25;
+    for (int e = threadIdx.x; e < cw * 25; e += 256) {
+      const float v = t[e / 25][e % 25][co];
+      dst[e] = accumulate ? dst[e] + v : v;
+    }
+  }
+}
+
 extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, int32_t accumulate,
-                                       void* stream) {
+                                       int32_t transposed, void* stream) {
   if (!dWg || !G || CO <= 0 || CI <= 0) return DFOLD_EINVAL;
-  dim3 grid((CI + 63) / 64, CO);
-  DFOLD_LAUNCH(conv_wgrad_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
+  if (transposed) {
+    dim3 grid((CI + 15) / 16, (CO + 31) / 32);
+    DFOLD_LAUNCH(conv_wgrad_unpack_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
+  } else {
+    dim3 grid((CI + 63) / 64, CO);
+    DFOLD_LAUNCH(conv_wgrad_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, dWg, G, CO, CI, accumulate);
+  }
   return dfold_check_launch();
 }
 

@@ -350,8 +350,27 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
   const int tiles_n = (p.N + BN3 - 1) / BN3;
-  const int m0 = (lid / tiles_n) * BM3, n0 = (lid % tiles_n) * BN3;
-  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
+  int m0, n0, z0, z1;
+  if (ROLE == 2) {
+    // conv wgrad: 1-D grid over (n tile, dn, df, m tile), m tile fastest.  The ~31 consecutive ids that the XCD map
+    // puts on one XCD then share ONE column-shifted operand copy (dn) of one n panel and the 5 m panels, and the 5
+    // row shifts (df) of a panel touch the same cache lines a few K steps apart: operands stream from HBM about
+    // once per XCD instead of once per workgroup.
+    const int tiles_m = (p.M + BM3 - 1) / BM3;
+    int r = lid;
+    m0 = (r % tiles_m) * BM3;
+    r /= tiles_m;
+    z0 = r % 5;   // df
+    r /= 5;
+    z1 = r % 5;   // dn
+    n0 = (r / 5) * BN3;
+  } else {
+    m0 = (lid / tiles_n) * BM3;
+    n0 = (lid % tiles_n) * BN3;
+    const int z = blockIdx.y;
+    z0 = z / p.nb1;
+    z1 = z - z0 * p.nb1;
+  }
   const char* A = (const char*)(p.A + z0 * p.sa0 + z1 * p.sa1);
   const char* B = (const char*)(p.B + z0 * p.sb0 + z1 * p.sb1);
   const long coff = z0 * p.sc0 + z1 * p.sc1;
@@ -656,7 +675,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   }
   const long tiles320 = (long)((d->M + BM3 - 1) / BM3) * ((d->N + BN3 - 1) / BN3);
   const long a_extent = row_off_host(p.am, d->M - 1) + d->a_rows.ld;   // elements spanned by the A rows of one batch
-  if (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && d->M >= 2048 && steps >= 4 &&
+  if (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && (d->M >= 2048 || role == 2) && steps >= 4 &&
       tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
     static bool attr3_done = false;
     if (!attr3_done) {
@@ -687,7 +706,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     if (role == 1)
       DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<1>, grid3, dim3(512), lds, (hipStream_t)stream, p);
     else if (role == 2)
-      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<2>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<2>, dim3((unsigned)(tiles320 * 25), 1, 1), dim3(512), lds, (hipStream_t)stream, p);
     else
       DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<0>, grid3, dim3(512), lds, (hipStream_t)stream, p);
     return dfold_check_launch();

@@ -239,8 +239,11 @@ def grid_transpose_shift(g, x, C, d0, nd, out):
 
 
 def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True):
-    """dwg fp32 [CO][25][CI] (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.
-    The narrower operand gets the 5 column-shifted transposed copies, the wider one a single copy."""
+    """dW (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.  The narrower operand gets the 5
+    column-shifted transposed copies, the wider one a single copy; the WIDER operand is always the GEMM's M side
+    (1280 = 5 x 256 rows, the narrow 640 = 2 x 320 columns: both tile exactly), so
+      CI <= CO: dwg fp32 [CO][25][CI]            (gy rows x shifted-x columns)
+      CI >  CO: dwg fp32 [CI][25][CO] TRANSPOSED (x rows x shifted-gy columns, taps flipped)."""
     CI, CO = x.shape[-1], gy.shape[-1]
     plane, N, F = g.plane, g.N, g.F
     fl = GEMM_ACCUM if accumulate else 0
@@ -250,12 +253,12 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True):
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
              a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
-    else:          # shift gy, taps flipped
+    else:          # shift gy, taps flipped, transposed accumulator
         tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)))
         tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
-        gemm(tS, tU, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
-             a_seg=g.seg_shifted(), b_seg=g.seg_center(), nbatch=25, nb1=5, sa=(N, CO * plane),
-             sc=(-5 * CI, -CI), c_off=24 * CI, flags=fl)
+        gemm(tU, tS, dwg, CI, CO, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CO), ldb=plane,
+             a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CO * plane),
+             sc=(-5 * CO, -CO), c_off=24 * CO, flags=fl)
     return dwg
 
 
@@ -290,7 +293,8 @@ class ConvTower:
         dev = weights[0].device
         self.wf = [torch.empty((w.shape[0], 25, w.shape[1]), dtype=BF16, device=dev) for w in weights]
         self.wd = [torch.empty((w.shape[1], 25, w.shape[0]), dtype=BF16, device=dev) for w in weights]
-        self.dwg = [torch.zeros((w.shape[0], 25, w.shape[1]), dtype=torch.float32, device=dev) for w in weights]
+        # fp32 gradient accumulators in GEMM layout: [CO][25][CI], or TRANSPOSED [CI][25][CO] when CI > CO (conv5x5_wgrad)
+        self.dwg = [torch.zeros((max(w.shape[:2]), 25, min(w.shape[:2])), dtype=torch.float32, device=dev) for w in weights]
         self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
         self.ws = Workspace(dev)
         self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
@@ -310,7 +314,7 @@ class ConvTower:
         for w, dwg, db in zip(self.weights, self.dwg, self.db):
             gw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
             check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(gw), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
-                                            stream()), "dfold_conv_wgrad_unpack")
+                                            c_int32(1 if w.shape[1] > w.shape[0] else 0), stream()), "dfold_conv_wgrad_unpack")
             out += [gw, db.clone()]
         self.zero_grad()
         return out
@@ -372,5 +376,5 @@ class ConvTower:
             if w.grad is None:
                 w.grad = torch.zeros_like(w)
             check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(w.grad), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
-                                            stream()), "dfold_conv_wgrad_unpack")
+                                            c_int32(1 if w.shape[1] > w.shape[0] else 0), stream()), "dfold_conv_wgrad_unpack")
             b.grad = db.clone()

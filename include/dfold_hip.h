@@ -89,8 +89,9 @@ int dfold_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, void* strea
 int dfold_cast_bf16_f32(const void* src_bf16, float* dst, int64_t n, void* stream);
 /* W fp32 [CO][CI][5][5] (nn.Conv2d OIHW, :669-690) -> Wf bf16 [CO][25][CI], Wd bf16 [CI][25][CO] (taps flipped) */
 int dfold_conv_weight_pack(const float* W, void* Wf, void* Wd, int32_t CO, int32_t CI, void* stream);
-/* dWg fp32 [CO][25][CI] -> G fp32 [CO][CI][5][5]; accumulate != 0: G += */
-int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, int32_t accumulate, void* stream);
+/* dWg fp32 [CO][25][CI] (transposed != 0: [CI][25][CO]) -> G fp32 [CO][CI][5][5]; accumulate != 0: G += */
+int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, int32_t accumulate, int32_t transposed,
+                            void* stream);
 /* X bf16 [W][Fp][Wp][C] -> T bf16 [nd][C][W][Fp][N], T[d][c][w][f][n] = X[w][f][n+d0+d][c] */
 int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, int32_t Wp, int32_t C, int32_t N,
                                int32_t d0, int32_t nd, void* stream);

@@ -108,9 +108,22 @@ def quat_to_rotvec(quat, eps=1e-6):
 # ----------------------------------------------------------------------------
 
 
+# Optional emulation of the engine's storage precision (bf16 operands into every dense contraction, fp32
+# accumulate).  Used by the GPU gradient-parity test to separate kernel defects from the ReLU-mask flips that any
+# reduced-precision activation storage causes ("gradient parity note").  Off = the reference's fp32 math.
+EMULATE_BF16_OPERANDS = False
+
+
+def _q(x):
+    """round-trip through bf16 with a straight-through gradient"""
+    if not EMULATE_BF16_OPERANDS:
+        return x
+    return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
+
+
 def linear(P, name, x):
     b = P.get(name + ".bias")
-    return F.linear(x, P[name + ".weight"].to(x.dtype), None if b is None else b.to(x.dtype))
+    return F.linear(_q(x), _q(P[name + ".weight"].to(x.dtype)), None if b is None else b.to(x.dtype))
 
 
 def my_layer_norm(x, eps=1e-4):
@@ -135,9 +148,9 @@ def convnet(P, name, x):
     for i in (1, 2, 3, 4):
         w0, b0 = P[f"{name}.conv{i}.0.weight"].to(x.dtype), P[f"{name}.conv{i}.0.bias"].to(x.dtype)
         w2, b2 = P[f"{name}.conv{i}.2.weight"].to(x.dtype), P[f"{name}.conv{i}.2.bias"].to(x.dtype)
-        y = F.relu(F.conv2d(h, w0, b0, padding=2))
-        y = F.relu(F.conv2d(y, w2, b2, padding=2))
-        h = y + h
+        y = F.relu(F.conv2d(_q(h), _q(w0), b0, padding=2))
+        y = F.relu(F.conv2d(_q(y), _q(w2), b2, padding=2))
+        h = y + _q(h)
     return h.squeeze(0).permute(1, 2, 0)
 
 

@@ -25,3 +25,23 @@ rows.sort(reverse=True)
 for r in rows: print("%.4f %.4f %-60s %.3e" % r)
 for k in ("angles","unorm_angles","rigid_update","rot_score","trans_score"):
     print(k, rel_l2(out[k], g["out_"+k]))
+
+# same comparison against the oracle with bf16-operand emulation (separates kernel defects from ReLU-mask flips)
+from oracle import dfold_oracle as O
+from dynamicpdb_amd import synthetic
+O.EMULATE_BF16_OPERANDS = True
+Pq = {k: v.clone().requires_grad_(True) for k, v in synthetic.seeded_state_dict(seed_w).items()}
+wc = {k: v.cpu() for k, v in w.items()}
+outq = O.full_score_network(Pq, O.Schedules(), wc)
+lq, _ = O.loss_fn(outq, wc)
+lq.backward()
+rows = []
+for name, p in P.items():
+    if p.grad is None or Pq[name].grad is None: continue
+    a, b = p.grad.double().cpu(), Pq[name].grad.double()
+    if float(b.norm()) < 1e-6: continue
+    rows.append((float((a - b).norm() / b.norm()), name))
+rows.sort(reverse=True)
+print("vs bf16-emulating oracle: loss", float(loss), float(lq))
+for r in rows[:12]: print("%.4f %s" % r)
+print("median %.4f" % sorted(r[0] for r in rows)[len(rows)//2])
