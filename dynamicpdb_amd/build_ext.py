@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(CSRC, "libdfold_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
+         # the 2x5-tile GEMM epilogue must unroll completely (160 accumulator registers indexed statically), else the
+         # accumulators are demoted to scratch
+         "-mllvm", "-pragma-unroll-threshold=100000", "-mllvm", "-unroll-threshold=2000"]
 
 
 def sources():

@@ -54,35 +54,55 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NJ], long mbase, int nbase, long coff,
                                               int lane) {
+  // Straight-line, fully unrolled (accumulators stay in registers): per accumulator row the side loads (residual /
+  // mask rows) are issued as one batch of NJ independent loads, bias values are loaded once per lane; stores are
+  // predicated instead of branching around the body (dependent load -> wait -> store chains made the epilogue
+  // latency-bound: ~110 us per 256x320 tile before).
   const int fl = p.flags;
   const int frow = lane & 31, fhalf = lane >> 5;
+  const bool has_r = (fl & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) != 0;
+  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
+  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
+  float bias_v[NJ];
+  bool nok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = nbase + j * 32 + frow;
+    nok[j] = n < p.N;
+    bias_v[j] = ((fl & DFOLD_GEMM_BIAS) && nok[j]) ? p.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const long m = mbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-      if (m >= p.M) continue;
-      const long ro = row_off(p.cm, m) + coff;
+      const bool mok = m < p.M;
+      const long ro = row_off(p.cm, mok ? m : 0) + coff + nbase + frow;
+      float rv[NJ], r2v[NJ], cv[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int n = nbase + j * 32 + frow;
-        if (n >= p.N) continue;
-        float v = acc[i][j][e] * p.alpha;
-        const long off = ro + n;
-        if (fl & DFOLD_GEMM_BIAS) v += p.bias[n];
+        const bool ok = mok && nok[j];
+        rv[j] = (has_r && ok) ? bf2f(p.R[ro + j * 32]) : 0.f;
+        r2v[j] = (c2_mask && ok) ? bf2f(p.R2[ro + j * 32]) : 0.f;
+        cv[j] = ((fl & DFOLD_GEMM_ACCUM) && ok) ? ((const float*)p.C)[ro + j * 32] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool ok = mok && nok[j];
+        const long off = ro + j * 32;
+        float v = acc[i][j][e] * p.alpha + bias_v[j];
         if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (p.C2 != nullptr && p.R2 == nullptr) ((bf16_t*)p.C2)[off] = f2bf(v);
-        if (fl & DFOLD_GEMM_RESID) v += bf2f(p.R[off]);
-        if (fl & DFOLD_GEMM_RELUMASK) v = bf2f(p.R[off]) > 0.f ? v : 0.f;
+        if (c2_pre && ok) ((bf16_t*)p.C2)[off] = f2bf(v);
+        if (fl & DFOLD_GEMM_RESID) v += rv[j];
+        if (fl & DFOLD_GEMM_RELUMASK) v = rv[j] > 0.f ? v : 0.f;
         if (fl & DFOLD_GEMM_OUT_BF16) {
-          ((bf16_t*)p.C)[off] = f2bf(v);
+          if (ok) ((bf16_t*)p.C)[off] = f2bf(v);
         } else if (fl & DFOLD_GEMM_ATOMIC) {
-          atomicAdd((float*)p.C + off, v);
+          if (ok) atomicAdd((float*)p.C + off, v);
         } else {
-          if (fl & DFOLD_GEMM_ACCUM) v += ((float*)p.C)[off];
-          ((float*)p.C)[off] = v;
+          if (ok) ((float*)p.C)[off] = v + cv[j];
         }
-        if (p.C2 != nullptr && p.R2 != nullptr) ((bf16_t*)p.C2)[off] = bf2f(p.R2[off]) > 0.f ? f2bf(v) : (bf16_t)0;
+        if (c2_mask && ok) ((bf16_t*)p.C2)[off] = r2v[j] > 0.f ? f2bf(v) : (bf16_t)0;
       }
     }
   }

@@ -66,7 +66,25 @@ def bench_tower(Wn, F, N, C=1280, iters=2):
     print(json.dumps(dict(op="tower fwd+bwd", frames_per_s=Wn * F / (t_f + t_b), note="one of 4 trunk blocks")), flush=True)
 
 
+def bench_epilogue(Wn=8, F=32, N=256):
+    """same output tile count, short vs long K: separates per-tile fixed cost (prologue + epilogue) from the K loop"""
+    g = ops.Grid(Wn, F, N, dev)
+    for CI, CO in ((64, 640), (128, 640), (1280, 640), (64, 1280), (640, 1280)):
+        x = g.alloc(CI)
+        g.interior(x).copy_(torch.randn(Wn, F, N, CI, device=dev).to(torch.bfloat16))
+        wf = (torch.randn(CO, 25, CI, device=dev) / np.sqrt(25 * CI)).to(torch.bfloat16)
+        bias = torch.zeros(CO, device=dev)
+        out, res = g.alloc(CO), g.alloc(CO)
+        t0 = timeit(lambda: ops.conv5x5_fwd(g, x, wf, bias, out, relu=True), iters=5, warm=2)
+        t1 = timeit(lambda: ops.conv5x5_fwd(g, x, wf, bias, out, relu=True, resid=res, pre_resid_out=res), iters=5, warm=2)
+        print(json.dumps(dict(op="conv epilogue probe", CI=CI, CO=CO, ms_plain=t0 * 1e3, ms_resid_c2=t1 * 1e3,
+                              tflops_issued=2 * g.M * CO * 25 * CI / t0 / 1e12)), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "epilogue":
+        bench_epilogue()
+        sys.exit(0)
     bench_gemm(4096, 4096, 4096)
     bench_gemm(8192, 8192, 8192)
     bench_gemm(65536, 640, 1280)
