@@ -16,6 +16,9 @@ from ..ops import BF16, GEMM_ACCUM, _p, c_int32, c_int64, gemm, rows_grid, rows_
 # ------------------------------------------------------------------------------------------------
 
 class WeightCache:
+    """bf16 (and transposed bf16) copies of fp32 parameters.  Entries are validated by object identity (weak reference)
+    plus (data_ptr, version): `id()` and device addresses are both recycled after a model is garbage collected."""
+
     def __init__(self):
         self._w, self._wt = {}, {}
 
@@ -23,27 +26,35 @@ class WeightCache:
     def _stamp(p):
         return (p.data_ptr(), p._version)
 
+    def _lookup(self, table, p):
+        e = table.get(id(p))
+        if e is not None and e[0]() is p and e[1] == self._stamp(p):
+            return e[2]
+        return None
+
+    def _store(self, table, p, value):
+        import weakref
+        key = id(p)
+        table[key] = (weakref.ref(p, lambda _r, t=table, k=key: t.pop(k, None)), self._stamp(p), value)
+        return value
+
     def w(self, p):
-        e = self._w.get(id(p))
-        if e is None or e[0] != self._stamp(p):
-            e = (self._stamp(p), ops.cast_bf16(p.detach()))
-            self._w[id(p)] = e
-        return e[1]
+        v = self._lookup(self._w, p)
+        return v if v is not None else self._store(self._w, p, ops.cast_bf16(p.detach()))
 
     def wt(self, p, pad_rows_to=8):
         """transposed bf16 copy [K][N8] (N zero-padded to a multiple of 8 so it can be a GEMM K axis)."""
-        e = self._wt.get(id(p))
-        if e is None or e[0] != self._stamp(p):
-            w = self.w(p)
-            N, K = w.shape
-            N8 = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
-            if N8 != N:
-                wp = torch.zeros((N8, K), dtype=BF16, device=w.device)
-                wp[:N].copy_(w)
-                w = wp
-            e = (self._stamp(p), ops.transpose_bf16(w, N8, K))
-            self._wt[id(p)] = e
-        return e[1]
+        v = self._lookup(self._wt, p)
+        if v is not None:
+            return v
+        w = self.w(p)
+        N, K = w.shape
+        N8 = (N + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+        if N8 != N:
+            wp = torch.zeros((N8, K), dtype=BF16, device=w.device)
+            wp[:N].copy_(w)
+            w = wp
+        return self._store(self._wt, p, ops.transpose_bf16(w, N8, K))
 
 
 CACHE = WeightCache()

@@ -69,9 +69,28 @@ def residue_tables(device):
     if t is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data", "residue_tables.npz")
         d = np.load(path)
-        t = {k: torch.tensor(d[k]).to(device) for k in d.files}
+        t = {k: torch.tensor(d[k]).to(device).contiguous() for k in d.files}
         _TABLES[device] = t
     return t
+
+
+def frames_to_atoms_hip(t7, angles, aatype):
+    """device path of frames_to_atoms: one HIP launch (csrc/atoms.hip); no gradient (the live loss does not use atoms)."""
+    from ctypes import c_int64
+    from .. import _lib
+    from ..ops import _p
+    T = residue_tables(t7.device)
+    lead = t7.shape[:-1]
+    P = t7.numel() // 7
+    t7c, ang = t7.detach().reshape(P, 7).float().contiguous(), angles.detach().reshape(P, 14).float().contiguous()
+    aa = aatype.reshape(P).long().contiguous()
+    a14 = torch.empty((P, 14, 3), dtype=torch.float32, device=t7.device)
+    a37 = torch.empty((P, 37, 3), dtype=torch.float32, device=t7.device)
+    _lib.check(_lib.lib().dfold_frames_to_atoms(_p(t7c), _p(ang), _p(aa), _p(T["default_frames"]), _p(T["atom14_group"]),
+                                                _p(T["atom14_mask"]), _p(T["atom14_pos"]), _p(T["atom37_to_atom14"]),
+                                                _p(T["atom37_mask"]), _p(a14), _p(a37), c_int64(P), _lib.stream()),
+               "dfold_frames_to_atoms")
+    return a14.view(lead + (14, 3)), a37.view(lead + (37, 3))
 
 
 def frames_to_atoms(t7, angles, aatype):

@@ -177,6 +177,16 @@ int dfold_embed_in_bwd(const float* x, const float* W, const float* b, const voi
                        int64_t P, int32_t k, int32_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backbone frame + 7 torsions -> atom14 / atom37 (feats.torsion_angles_to_frames openfold/utils/feats.py:165-228,
+ * all_atom.frames_to_atom14_pos src/data/all_atom.py:114-154, atom14_to_atom37 src/model/Dfold_network_dynamic.py:574-594).
+ * t7 fp32 [P][7], angles fp32 [P][7][2] (sin,cos), aatype int64 [P] in 0..20; residue tables as in residue_tables.npz.
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_frames_to_atoms(const float* t7, const float* angles, const int64_t* aatype, const float* default_frames,
+                          const int64_t* atom14_group, const float* atom14_mask, const float* atom14_pos,
+                          const int64_t* atom37_to_atom14, const float* atom37_mask, float* atom14, float* atom37, int64_t P,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * IGSO(3) score series (SO3Diffuser.torch_score src/data/so3_diffuser.py:274-305, igso3_expansion :9-49,
  * score :71-117): sc[p] = dsig(omega_p)/(f(omega_p)+1e-4) with the reference's fp32-trig / fp64-envelope
  * mixed precision, plus dsc = d sc / d omega for the backward.  env fp64 [windows][L] = (2l+1)exp(-l(l+1)s^2/2);
