@@ -103,6 +103,9 @@ class SE3Diffuser:
                 noise_scale=1.0, device=torch.device('cpu'), z_rot=None, z_trans=None):
         """One reverse-SDE step t -> t-dt (reference :160-215).  z_rot / z_trans optionally
         inject the normal draws (parity tests); default = numpy global RNG as upstream."""
+        if rigid_t.get_trans().is_cuda:      # device frames: one HIP launch, no host round trip
+            return Rigid.from_tensor_7(self.reverse_t7(rigid_t.to_tensor_7(), rot_score, trans_score, t, dt, diffuse_mask,
+                                                       center, noise_scale, z_rot, z_trans))
         trans_t, rot_t = _extract_trans_rots(rigid_t)
         rot_t_1 = rot_t if not self._diffuse_rot else self._so3_diffuser.reverse(
             rot_t=rot_t, score_t=rot_score, t=t, dt=dt, noise_scale=noise_scale, z=z_rot)
@@ -112,6 +115,42 @@ class SE3Diffuser:
             trans_t_1 = self._apply_mask(trans_t_1, trans_t, diffuse_mask[..., None])
             rot_t_1 = self._apply_mask(rot_t_1, rot_t, diffuse_mask[..., None])
         return _assemble_rigid(rot_t_1, trans_t_1, device)
+
+    def reverse_t7(self, rigids_t, rot_score, trans_score, t, dt, diffuse_mask=None, center=True, noise_scale=1.0,
+                   z_rot=None, z_trans=None):
+        """Device form of `reverse` on tensor_7 frames [..., N, 7] (one HIP launch, csrc/diffusion.hip).  The normal draws
+        default to numpy's global RNG in the reference's order (rotations first, se3_diffuser.py:184-190) so that a seeded
+        run consumes the same random stream as the reference; pass device tensors z_rot / z_trans to draw elsewhere."""
+        from ctypes import c_double, c_int32, c_int64
+        from .. import _lib
+        from ..ops import _p
+        if not np.isscalar(t):
+            raise ValueError(f'{t} must be a scalar.')
+        dev = rigids_t.device
+        t7 = rigids_t.detach().float().contiguous()
+        N = t7.shape[-2]
+        rows = t7.numel() // (7 * N)
+        shp3 = tuple(t7.shape[:-1]) + (3,)
+        if z_rot is None:
+            z_rot = np.random.normal(size=shp3)
+        if z_trans is None:
+            z_trans = np.random.normal(size=shp3)
+        as_dev = lambda x, dt_: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(device=dev, dtype=dt_).contiguous()
+        zr, zt = as_dev(z_rot, torch.float64), as_dev(z_trans, torch.float64)
+        rs, ts = as_dev(rot_score, torch.float64), as_dev(trans_score, torch.float32)
+        if not self._diffuse_rot:
+            rs, zr = torch.zeros_like(rs), torch.zeros_like(zr)
+        mask = as_dev(diffuse_mask, torch.float32) if diffuse_mask is not None else None
+        out = torch.empty_like(t7)
+        r3 = self._r3_diffuser
+        g_rot = float(self._so3_diffuser.diffusion_coef(t)) if self._diffuse_rot else 0.0
+        _lib.check(_lib.lib().dfold_se3_reverse(
+            _p(t7), _p(rs), _p(ts), _p(zr), _p(zt), _p(mask), _p(out), c_int64(rows), c_int32(N), c_double(g_rot),
+            c_double(float(r3.b_t(t))), c_double(float(dt)), c_double(float(noise_scale)),
+            c_double(float(r3._r3_conf.coordinate_scaling)), c_int32(1 if center else 0), _lib.stream()), "dfold_se3_reverse")
+        if not self._diffuse_trans:
+            out[..., 4:] = t7[..., 4:]
+        return out
 
     def sample_ref(self, n_samples: int, impute: Rigid = None, diffuse_mask=None, as_tensor_7=False):
         if impute is not None:

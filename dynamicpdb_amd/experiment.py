@@ -100,3 +100,67 @@ class Trainer:
         if step_optimizer:
             self.opt.step()
         return loss.detach(), aux
+
+
+def set_t_feats(diffuser, feats, t, like):
+    """Experiment._set_t_feats (train_DFOLD_dynamics.py:1408-1413) for a batch of windows sharing one t."""
+    rs, ts = diffuser.score_scaling(t)
+    feats['t'] = torch.full_like(like, float(t))
+    feats['rot_score_scaling'] = torch.full_like(like, float(rs))
+    feats['trans_score_scaling'] = torch.full_like(like, float(ts))
+    return feats
+
+
+def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, aux_traj=False, self_condition=True,
+                 noise_scale=1.0, cfg_drop_rate=0.0, cfg_gamma=2.0, z_draws=None):
+    """Reverse-diffusion sampler, device resident (reference Experiment.inference_fn, train_DFOLD_dynamics.py:1425-1547):
+    num_t model forwards; between them one dfold_se3_reverse launch instead of the reference's host round trip
+    (D2H, scipy, numpy RNG, H2D, CPU eigh).  `data_init` holds [B,F,N,..] (or reference-shaped [F,N,..]) device tensors
+    incl. the prior sample 'rigids_t'.  `z_draws`: optional iterable of (z_rot, z_trans) per reverse step (parity tests);
+    default = numpy global RNG in the reference's draw order.  Returns numpy trajectories flipped to start at t = 0."""
+    import numpy as np
+    model.eval()
+    feats = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_init.items()}
+    like = feats['t'].float() if 't' in feats else torch.ones(1, device=feats['rigids_t'].device)
+    reverse_steps = np.linspace(min_t, 1.0, num_t)[::-1]
+    dt = 1.0 / num_t
+    all_rigids, all_bb_prots, all_trans_0_pred, all_bb_0_pred = [], [], [], []
+    z_iter = iter(z_draws) if z_draws is not None else None
+    angles = None
+    with torch.no_grad():
+        if self_condition:
+            feats = set_t_feats(diffuser, feats, reverse_steps[0], like)
+            feats['sc_ca_t'] = model(feats)['rigids'][..., 4:]
+        for t in reverse_steps:
+            if t > min_t:
+                feats = set_t_feats(diffuser, feats, t, like)
+                model_out = model(feats)
+                rot_score, trans_score, rigid_pred = model_out['rot_score'], model_out['trans_score'], model_out['rigids']
+                if cfg_drop_rate > 0.01:
+                    unref = model(feats, drop_ref=True)['trans_score']
+                    trans_score = unref + cfg_gamma * (trans_score - unref)
+                feats['sc_ca_t'] = rigid_pred[..., 4:]
+                diffuse_mask = (1 - feats['fixed_mask'].float()) * feats['res_mask'].float()
+                zr, zt = next(z_iter) if z_iter is not None else (None, None)
+                feats['rigids_t'] = diffuser.reverse_t7(feats['rigids_t'], rot_score, trans_score, float(t), dt,
+                                                        diffuse_mask=diffuse_mask, center=center, noise_scale=noise_scale,
+                                                        z_rot=zr, z_trans=zt)
+            else:
+                model_out = model(feats)
+                rigid_pred = model_out['rigids']
+                feats['rigids_t'] = rigid_pred.clone()
+            fixed_mask = feats['fixed_mask'].float() * feats['res_mask'].float()
+            diffuse_mask = (1 - feats['fixed_mask'].float()) * feats['res_mask'].float()
+            angles = model_out['angles']
+            if aux_traj:
+                all_rigids.append(model_out['rigids'].cpu().numpy())
+                trans_pred_0 = diffuse_mask[..., None] * rigid_pred[..., 4:] + fixed_mask[..., None] * feats['rigids_t'][..., 4:]
+                all_trans_0_pred.append(trans_pred_0.cpu().numpy())
+                all_bb_0_pred.append(model_out['atom37'].cpu().numpy())
+            all_bb_prots.append(model_out['atom37'].cpu().numpy())
+    flip = lambda x: np.flip(np.stack(x), (0,))
+    ret = {'prot_traj': flip(all_bb_prots)}
+    if aux_traj:
+        ret.update(rigid_traj=flip(all_rigids), trans_traj=flip(all_trans_0_pred), psi_pred=angles,
+                   rigid_0_traj=flip(all_bb_0_pred))
+    return ret

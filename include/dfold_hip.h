@@ -195,6 +195,16 @@ int dfold_frames_to_atoms(const float* t7, const float* angles, const int64_t* a
 int dfold_igso3_series(const float* omega, const double* env, double* sc, double* dsc, int64_t P, int64_t per_window,
                        int32_t L, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * One reverse-SDE (denoise) step on tensor_7 frames (SE3Diffuser.reverse src/data/se3_diffuser.py:160-215,
+ * SO3Diffuser.reverse so3_diffuser.py:329-365, R3Diffuser.reverse r3_diffuser.py:106-157).  t7/out fp32 [rows][N][7]
+ * (rows = windows*frames; centring is per row), rot_score / z_rot / z_trans fp64 [rows][N][3], trans_score fp32,
+ * mask fp32 [rows][N] or NULL (0 = keep the frame), g_rot = SO3 diffusion coefficient at t, b_t = R3 beta(t).
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_se3_reverse(const float* t7, const double* rot_score, const float* trans_score, const double* z_rot,
+                      const double* z_trans, const float* mask, float* out, int64_t rows, int32_t N, double g_rot, double b_t,
+                      double dt, double noise_scale, double coordinate_scaling, int32_t center, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
