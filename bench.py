@@ -48,7 +48,7 @@ def make_batch(synthetic, diffuser, B, F, N, rank, dev):
 
 
 def conv_kernel_roofline(model, trainer, batch, B, F, N):
-    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_mfma_gemm_kernel<1>)
+    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_mfma_gemm320_kernel<1>)
     of ONE extra, instrumented step, measured with HIP events on the stream the kernels are launched on."""
     from dynamicpdb_amd import ops
     events = []
@@ -78,7 +78,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     achieved = flops / avg_s / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "dfold_mfma_gemm_kernel<1> (5x5 conv implicit GEMM fwd+dgrad)", "launches": len(ms),
+            "kernel": "dfold_mfma_gemm320_kernel<1> (5x5 conv implicit GEMM, forward + dgrad launches)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
 
 

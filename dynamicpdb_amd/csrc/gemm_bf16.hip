@@ -51,8 +51,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Shared epilogue: 2x2 MFMA 32x32 accumulator tiles of one wave -> C (C/D layout: col = lane&31,
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5)).
-template <int NJ>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][NJ], long mbase, int nbase, long coff,
+template <int NJ, int MI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[MI][NJ], long mbase, int nbase, long coff,
                                               int lane) {
   // Straight-line, fully unrolled (accumulators stay in registers): per accumulator row the side loads (residual /
   // mask rows) are issued as one batch of NJ independent loads, bias values are loaded once per lane; stores are
@@ -72,7 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     bias_v[j] = ((fl & DFOLD_GEMM_BIAS) && nok[j]) ? p.bias[n] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const long m = mbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
@@ -105,6 +105,73 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         if (c2_mask && ok) ((bf16_t*)p.C2)[off] = r2v[j] > 0.f ? f2bf(v) : (bf16_t)0;
       }
     }
+  }
+}
+
+// bf16 epilogue of the 256x320 kernel staged through LDS: the wave's 64x160 tile is written to LDS (two 32-row
+// halves, bias / ReLU applied, rounded to bf16), then streamed out in whole 16-byte chunks -- residual / mask rows are
+// read and C / C2 written as dwordx4 per lane (full 320-byte row segments per wave) instead of 2-byte scattered
+// accesses.  Requires N % 320 == 0 (no column tail) and 16-byte aligned rows; the pre-residual value is rounded to
+// bf16 before the residual add (C2 is exactly that value).
+#define EPI_ROWB 336  // 320 B of data + 16 B pad per staged row
+__device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x16 (&acc)[2][5], long mbase, int nbase,
+                                                       long coff, int lane, char* wave_lds) {
+  const int fl = p.flags;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
+  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
+  float bias_v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) bias_v[j] = (fl & DFOLD_GEMM_BIAS) ? p.bias[nbase + j * 32 + frow] : 0.f;
+  long* rowtab = (long*)(wave_lds + 32 * EPI_ROWB);  // 32 row offsets (-1 = row past M)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (lane < 32) {
+      const long m = mbase + i * 32 + lane;
+      rowtab[lane] = m < p.M ? row_off(p.cm, m) + coff + nbase : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float v = acc[i][j][e] * p.alpha + bias_v[j];
+        if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
+        *(bf16_t*)(wave_lds + r * EPI_ROWB + (j * 32 + frow) * 2) = f2bf(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int c = lane + 64 * k;          // chunk id: 32 rows x 20 chunks of 8 bf16
+      const int r = c / 20, c16 = c - r * 20;
+      const long ro = rowtab[r];
+      uint4 val = *(const uint4*)(wave_lds + r * EPI_ROWB + c16 * 16);
+      if (ro < 0) continue;
+      const long off = ro + c16 * 8;
+      if (c2_pre) *(uint4*)((bf16_t*)p.C2 + off) = val;
+      if (fl & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) {
+        const uint4 rr = *(const uint4*)(p.R + off);
+        const bf16_t* pr = (const bf16_t*)&rr;
+        bf16_t* pv = (bf16_t*)&val;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (fl & DFOLD_GEMM_RESID) pv[q] = f2bf(bf2f(pv[q]) + bf2f(pr[q]));
+          if (fl & DFOLD_GEMM_RELUMASK) pv[q] = bf2f(pr[q]) > 0.f ? pv[q] : (bf16_t)0;
+        }
+      }
+      *(uint4*)((bf16_t*)p.C + off) = val;
+      if (c2_mask) {
+        const uint4 r2 = *(const uint4*)(p.R2 + off);
+        const bf16_t* p2 = (const bf16_t*)&r2;
+        bf16_t* pv = (bf16_t*)&val;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pv[q] = bf2f(p2[q]) > 0.f ? pv[q] : (bf16_t)0;
+        *(uint4*)((bf16_t*)p.C2 + off) = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -516,7 +583,13 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
   }
-  gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
+  const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BN3) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
+  if (vec_ok) {
+    __syncthreads();   // every wave is done with the operand stages: reuse the LDS as per-wave output staging
+    gemm_epilogue_lds_bf16(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane, lds3 + w * (32 * EPI_ROWB + 256));
+  } else {
+    gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
+  }
 }
 
 
@@ -650,6 +723,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320r_kernel(const GemmP
   }
   gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
 }
+
 
 static long row_off_host(const RowMap& r, long m) {
   if (r.mode == 0) return r.base + m * r.ld;

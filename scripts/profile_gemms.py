@@ -23,9 +23,12 @@ orig = ops.gemm
 def timed(A, Bm, C, M, Nn, seglen, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = orig(A, Bm, C, M, Nn, seglen, **kw); e1.record()
-    ev.append(((M, Nn, seglen, kw.get("nseg", 1), kw.get("nbatch", 1)), e0, e1))
+    ev.append(((M, Nn, seglen, kw.get("nseg", 1), kw.get("nbatch", 1), C.dtype == torch.float32, kw.get("flags", 0)), e0, e1))
     return r
 ops.gemm = timed
+import dynamicpdb_amd.model.functional as _F, dynamicpdb_amd.model.triangle as _T
+_F.gemm = timed
+_T.gemm = timed
 e_all0, e_all1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e_all0.record(); trainer.update_fn(batch); e_all1.record()
 torch.cuda.synchronize()
@@ -35,6 +38,6 @@ for k, e0, e1 in ev:
 tot = sum(v[1] for v in agg.values())
 print("step %.1f ms, gemm total %.1f ms" % (e_all0.elapsed_time(e_all1), tot))
 for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    M, Nn, K, nseg, nb = k
+    M, Nn, K, nseg, nb, f32, flg = k
     fl = 2.0 * M * Nn * K * nseg * nb * n
-    print("M=%7d N=%6d K=%7d nseg=%3d nbatch=%5d calls=%3d  %8.2f ms  %7.1f TF/s" % (M, Nn, K, nseg, nb, n, ms, fl / ms / 1e9))
+    print("M=%7d N=%6d K=%7d nseg=%3d nbatch=%5d f32=%d flags=%3d calls=%3d  %8.2f ms  %7.1f TF/s" % (M, Nn, K, nseg, nb, f32, flg, n, ms, fl / ms / 1e9))
