@@ -24,19 +24,34 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// Wave64 reductions on the DPP path (VALU cross-lane moves: quad_perm, row_shr, row_bcast), result broadcast from
+// lane 63 with v_readlane -- ~6 dependent VALU ops instead of 6 dependent ds_bpermute round trips through the LDS
+// crossbar (which made kernels with dozens of reductions per row latency-bound).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov_f(float oldv, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov_f<0xb1>(0.f, v);        // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4e>(0.f, v);        // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x114>(0.f, v);       // row_shr 4
+  v += dpp_mov_f<0x118>(0.f, v);       // row_shr 8
+  v += dpp_mov_f<0x142, 0xa>(0.f, v);  // row_bcast 15 -> rows 1,3
+  v += dpp_mov_f<0x143, 0xc>(0.f, v);  // row_bcast 31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_mov_f<0xb1>(v, v));
+  v = fmaxf(v, dpp_mov_f<0x4e>(v, v));
+  v = fmaxf(v, dpp_mov_f<0x114>(v, v));
+  v = fmaxf(v, dpp_mov_f<0x118>(v, v));
+  v = fmaxf(v, dpp_mov_f<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_mov_f<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 

@@ -113,17 +113,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // read and C / C2 written as dwordx4 per lane (full 320-byte row segments per wave) instead of 2-byte scattered
 // accesses.  Requires N % 320 == 0 (no column tail) and 16-byte aligned rows; the pre-residual value is rounded to
 // bf16 before the residual add (C2 is exactly that value).
-#define EPI_ROWB 336  // 320 B of data + 16 B pad per staged row
-__device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x16 (&acc)[2][5], long mbase, int nbase,
+#define EPI_ROWB(NJ) ((NJ) * 64 + 16)  // NJ*64 B of data + 16 B pad per staged row
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x16 (&acc)[2][NJ], long mbase, int nbase,
                                                        long coff, int lane, char* wave_lds) {
+  constexpr int ROWB = EPI_ROWB(NJ);
+  constexpr int CPR = NJ * 4;  // 16-byte chunks per row
   const int fl = p.flags;
   const int frow = lane & 31, fhalf = lane >> 5;
   const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
   const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
-  float bias_v[5];
+  float bias_v[NJ];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) bias_v[j] = (fl & DFOLD_GEMM_BIAS) ? p.bias[nbase + j * 32 + frow] : 0.f;
-  long* rowtab = (long*)(wave_lds + 32 * EPI_ROWB);  // 32 row offsets (-1 = row past M)
+  for (int j = 0; j < NJ; ++j) bias_v[j] = (fl & DFOLD_GEMM_BIAS) ? p.bias[nbase + j * 32 + frow] : 0.f;
+  long* rowtab = (long*)(wave_lds + 32 * ROWB);  // 32 row offsets (-1 = row past M)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (lane < 32) {
@@ -134,20 +137,20 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
     for (int e = 0; e < 16; ++e) {
       const int r = (e & 3) + 8 * (e >> 2) + 4 * fhalf;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         float v = acc[i][j][e] * p.alpha + bias_v[j];
         if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
-        *(bf16_t*)(wave_lds + r * EPI_ROWB + (j * 32 + frow) * 2) = f2bf(v);
+        *(bf16_t*)(wave_lds + r * ROWB + (j * 32 + frow) * 2) = f2bf(v);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (wave-private region)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int c = lane + 64 * k;          // chunk id: 32 rows x 20 chunks of 8 bf16
-      const int r = c / 20, c16 = c - r * 20;
+    for (int k = 0; k < CPR / 2; ++k) {
+      const int c = lane + 64 * k;          // chunk id: 32 rows x CPR chunks of 8 bf16
+      const int r = c / CPR, c16 = c - r * CPR;
       const long ro = rowtab[r];
-      uint4 val = *(const uint4*)(wave_lds + r * EPI_ROWB + c16 * 16);
+      uint4 val = *(const uint4*)(wave_lds + r * ROWB + c16 * 16);
       if (ro < 0) continue;
       const long off = ro + c16 * 8;
       if (c2_pre) *(uint4*)((bf16_t*)p.C2 + off) = val;
@@ -411,7 +414,13 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
     cur = cur + 1 == NSTAGE2 ? 0 : cur + 1;
   }
 
-  gemm_epilogue<2>(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+  const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BN) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
+  if (vec_ok) {
+    __syncthreads();
+    gemm_epilogue_lds_bf16<2>(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane, lds2 + w * (32 * EPI_ROWB(2) + 256));
+  } else {
+    gemm_epilogue<2>(p, acc, (long)m0 + wm * 64, n0 + wn * 64, coff, lane);
+  }
 }
 
 
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BN3) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
   if (vec_ok) {
     __syncthreads();   // every wave is done with the operand stages: reuse the LDS as per-wave output staging
-    gemm_epilogue_lds_bf16(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane, lds3 + w * (32 * EPI_ROWB + 256));
+    gemm_epilogue_lds_bf16<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane, lds3 + w * (32 * EPI_ROWB(5) + 256));
   } else {
     gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
   }
