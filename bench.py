@@ -76,24 +76,35 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     avg_s = sum(ms) / len(ms) * 1e-3
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_conv.json")     # HBM-side bytes per launch from the committed PMC passes
+    if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
+        with open(pmc) as fh:
+            c = json.load(fh)
+        traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": "dfold_mfma_gemm320_kernel<1> (5x5 conv implicit GEMM, forward + dgrad launches)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
 
 
-def cpu_baseline(F, N, seed_w=0):
-    """The oracle (CPU port of the reference path) fwd + loss + bwd on host cores, bounded sample."""
+def cpu_baseline(F, N, seed_w=0, budget_s=60.0):
+    """The oracle (CPU port of the reference path) fwd + loss + bwd on host cores, bounded sample: 1 warm-up + up to 2
+    timed iterations of one window of F frames, stopping once `budget_s` of CPU work has been spent."""
     from oracle import dfold_oracle as O
     from dynamicpdb_amd import synthetic
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        cores = len(os.sched_getaffinity(0))      # cores this process may actually use (cgroup / affinity aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
     conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
     diffuser = SE3Diffuser(conf.diffuser)
     sd = synthetic.seeded_state_dict(seed_w)
     w = synthetic.synthetic_window(7, F, N, t=0.5, diffuser=diffuser)
-    times = []
+    times, t_start = [], time.time()
     for it in range(3):
         P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         t0 = time.time()
@@ -101,10 +112,14 @@ def cpu_baseline(F, N, seed_w=0):
         loss, _ = O.loss_fn(out, w)
         loss.backward()
         times.append(time.time() - t0)
-    t = min(times[1:])
-    return {"value": round(F / t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+loss+bwd, 1 window of {F} frames x N_res={N}, best of 2 after 1 warm-up "
-                      f"({t:.2f} s/iter, torch CPU threads={cores})"}
+        print(f"[bench cpu_baseline] iteration {it}: {times[-1]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
+        if time.time() - t_start > budget_s:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(F / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd, 1 window of {F} frames x N_res={N}, best of {max(1, len(times) - 1)} after "
+                      f"{'1 warm-up' if len(times) > 1 else 'no warm-up'} ({t:.2f} s/iter, torch CPU threads={threads}, "
+                      f"{cores} usable cores)"}
 
 
 def main():
