@@ -540,57 +540,98 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int fa = (wm * 64 + frow) * 128;
   const int fb = A3_BYTES + (wn * 160 + frow) * 128;
 
+  bf16x8 af[2][2], bfr[2][5];
+  auto ldfrag = [&](int set, const char* base, int k4) {
+    const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[set][i] = *(const bf16x8*)(base + fa + i * 32 * 128 + ch);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) bfr[set][j] = *(const bf16x8*)(base + fb + j * 32 * 128 + ch);
+  };
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+  };
+
   stage(0);
-  for (int s = 0; s < nsteps; ++s) {
+  if (w < 4) {
+    // ---- group A (one wave per SIMD): per K step [fragment reads][40 MFMAs], DMA pieces between the MFMAs ----
+    for (int s = 0; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* base = lds3 + (s & 1) * STAGE3_BYTES;
+      ldfrag(0, base, 0);
+      ldfrag(1, base, 1);
+      stage((s + 1) & 1);
+      mma(0);
+      ldfrag(0, base, 2);
+      mma(1);
+      ldfrag(1, base, 3);
+      mma(0);
+      mma(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+    }
+  } else {
+    // ---- group B (the second wave of every SIMD) runs HALF A K STEP BEHIND: it enters each step with the fragments of
+    // the previous tile's second half already in registers and issues those 20 MFMAs while group A is still reading its
+    // fragments; it reads the current tile late in the step (after A).  The two waves of a SIMD therefore alternate on
+    // the matrix pipe instead of both stalling on LDS right after the barrier.  Same barriers, same DMA share. ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* la = lds3 + (s & 1) * STAGE3_BYTES + fa;
-    const char* lb = lds3 + (s & 1) * STAGE3_BYTES + fb;
-    // Register double-buffered fragments (the ds_read_b128 of K16 block k4+1 fly under the MFMAs of k4) and the 9
-    // LDS-DMA pieces of the NEXT tile are spread one per two MFMAs, so their issue cost (address VALU + ~60-100
-    // cycles each) hides in the matrix-pipe gaps instead of serialising at the top of the step.
-    bf16x8 af[2][2], bfr[2][5];
+    ldfrag(0, lds3, 0);
+    ldfrag(1, lds3, 1);
+    stage(1);
+    mma(0);
+    ldfrag(0, lds3, 2);
+    mma(1);
+    ldfrag(1, lds3, 3);
+    for (int s = 1; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* base = lds3 + (s & 1) * STAGE3_BYTES;
+      stage((s + 1) & 1);
+      mma(0);                 // previous tile, K16 blocks 2 and 3
+      mma(1);
+      ldfrag(0, base, 0);
+      ldfrag(1, base, 1);
+      mma(0);
+      ldfrag(0, base, 2);
+      mma(1);
+      ldfrag(1, base, 3);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int ch = ((kb * 2 + fhalf) ^ fsw) << 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[kb][i] = *(const bf16x8*)(la + i * 32 * 128 + ch);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) bfr[kb][j] = *(const bf16x8*)(lb + j * 32 * 128 + ch);
-    }
-    stage((s + 1) & 1);
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k4 & 1][i], bfr[k4 & 1][j], acc[i][j], 0, 0, 0);
-      if (k4 < 2) {
-        const int ch = (((k4 + 2) * 2 + fhalf) ^ fsw) << 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[k4 & 1][i] = *(const bf16x8*)(la + i * 32 * 128 + ch);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) bfr[k4 & 1][j] = *(const bf16x8*)(lb + j * 32 * 128 + ch);
+      for (int g = 0; g < 9; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-    }
-    // pinned issue order
-    __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+    mma(0);
+    mma(1);
   }
   const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BN3) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
   if (vec_ok) {
