@@ -144,7 +144,7 @@ extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, i
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ T,
                                                                    int Wn, int Fp, int Wp, int C, int N, int d0,
-                                                                   int nd) {
+                                                                   int nd, float* __restrict__ colsum) {
   __shared__ bf16_t t[68][66];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int wf = blockIdx.z;  // w*Fp + f
@@ -169,6 +169,17 @@ __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t*
   __syncthreads();
   const long plane = (long)Wn * Fp * N;  // elements per (d, c)
   const int nw = min(64, N - n0);
+  if (colsum != nullptr) {
+    // fused bias gradient: per-channel sum over the interior cells of this tile (border rows / columns are zero)
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6, sh = 2 - d0;
+    float sacc = 0.f;
+    if (c < cw)
+      for (int n = part; n < nw; n += 4) sacc += bf2f(t[n + sh][c]);
+    __shared__ float cs[4][64];
+    cs[part][c] = sacc;
+    __syncthreads();
+    if (part == 0 && c < cw) atomicAdd(colsum + c0 + c, cs[0][c] + cs[1][c] + cs[2][c] + cs[3][c]);
+  }
   for (int d = 0; d < nd; ++d) {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
       const int n = e & 63, c = e >> 6;
@@ -178,12 +189,13 @@ __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t*
 }
 
 extern "C" int dfold_grid_transpose_shift(const void* X, void* T, int32_t Wn, int32_t Fp, int32_t Wp, int32_t C,
-                                          int32_t N, int32_t d0, int32_t nd, void* stream) {
+                                          int32_t N, int32_t d0, int32_t nd, float* colsum, void* stream) {
   if (!X || !T || Wn <= 0 || Fp <= 0 || Wp <= 0 || C <= 0 || N <= 0 || nd <= 0 || nd > 5 || d0 < 0) return DFOLD_EINVAL;
   if (N + d0 + nd - 1 > Wp) return DFOLD_EINVAL;
+  if (colsum && (d0 > 2 || 2 - d0 + 64 > 68)) return DFOLD_EINVAL;
   dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * Fp);
   DFOLD_LAUNCH(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
-                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd);
+                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd, colsum);
   return dfold_check_launch();
 }
 

@@ -162,7 +162,8 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
 //   dq_pts[i,c] = -hw sum_j dS_ij (q_ic - k_jc);   dhw[h] += sum_j dS_ij * (-0.5 |q_i - k_j|^2)
 // writes dS (fp32, and bf16 for the MFMA products dQ/dK).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __restrict__ P, const float* dP,
+template <int MT>
+__global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __restrict__ P, const float* dP,
                                                               const float* __restrict__ q_pts,
                                                               const float* __restrict__ k_pts,
                                                               const float* __restrict__ v_pts,
@@ -170,40 +171,49 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
                                                               float* dS, bf16_t* __restrict__ dSb,
                                                               float* __restrict__ dq_pts, float* __restrict__ dhw,
                                                               IpaDims d) {
+  // 8 waves share the per-(window,frame,head) key/value point tables AND the block's 64 query rows' point vectors in
+  // LDS (no per-row uniform global loads, ~100 VGPRs -> 4 waves per SIMD hide the row-serial latency chain).
   extern __shared__ float sm[];
   const int N = d.N, H = d.H;
-  float* kp = sm;            // [N][KPS]
-  float* vp = sm + N * KPS;  // [N][VPS]
+  float* kp = sm;                          // [N][KPS]
+  float* vp = kp + N * KPS;                // [N][VPS]
+  float* qr = vp + N * VPS;                // [ROWS][KP]
+  float* dr = qr + ROWS_PER_BLOCK * KP;    // [ROWS][VP]
   const int bf = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
   const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
   const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
-  for (int e = threadIdx.x; e < N * KP; e += 256) {
+  for (int e = threadIdx.x; e < N * KP; e += 512) {
     const int j = e / KP, c = e - j * KP;
     kp[j * KPS + c] = kbase[(long)j * H * KP + c];
   }
-  for (int e = threadIdx.x; e < N * VP; e += 256) {
+  for (int e = threadIdx.x; e < N * VP; e += 512) {
     const int j = e / VP, c = e - j * VP;
     vp[j * VPS + c] = vbase[(long)j * H * VP + c];
   }
+  for (int e = threadIdx.x; e < ROWS_PER_BLOCK * KP; e += 512) {
+    const int r = e / KP, c = e - r * KP;
+    qr[e] = (i0 + r < N) ? q_pts[(((long)bf * N + i0 + r) * H + h) * KP + c] : 0.f;
+  }
+  for (int e = threadIdx.x; e < ROWS_PER_BLOCK * VP; e += 512) {
+    const int r = e / VP, c = e - r * VP;
+    dr[e] = (i0 + r < N) ? do_pt[(((long)bf * N + i0 + r) * H + h) * VP + c] : 0.f;
+  }
   __syncthreads();
   const float hwh = hw[h];
-  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
   float dhw_acc = 0.f;
-  for (int r = w; r < ROWS_PER_BLOCK; r += 4) {
+  for (int r = w; r < ROWS_PER_BLOCK; r += 8) {
     const int i = i0 + r;
     if (i >= N) break;
     const long pix = ((long)bf * N + i) * H + h;
-    float qv[KP], dov[VP];
-#pragma unroll
-    for (int c = 0; c < KP; ++c) qv[c] = q_pts[pix * KP + c];
-#pragma unroll
-    for (int c = 0; c < VP; ++c) dov[c] = do_pt[pix * VP + c];
+    const float* qv = qr + r * KP;
+    const float* dov = dr + r * VP;
     const long row = (((long)bf * H + h) * N + i) * N;
-    float pv[MAXT], gv[MAXT];
+    float pv[MT], gv[MT];
     float dot = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       pv[t] = 0.f;
       gv[t] = 0.f;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < KP; ++c) dq[c] = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       if (j < N) {
         const float ds = pv[t] * (gv[t] - dot);
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(256) void ipa_softmax_bwd_kernel(const float* __res
     }
 #pragma unroll
     for (int c = 0; c < KP; ++c) {
-      const float s = wave_sum(dq[c]);
-      if (lane == 0) dq_pts[pix * KP + c] = -hwh * s;
+      const float sres = wave_sum(dq[c]);
+      if (lane == 0) dq_pts[pix * KP + c] = -hwh * sres;
     }
   }
   dhw_acc = wave_sum(dhw_acc);
@@ -253,12 +263,21 @@ extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const floa
   if (!P || !dP || !q_pts || !k_pts || !v_pts || !do_pt || !hw || !dS || !dS_bf16 || !dq_pts || !dhw) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  const size_t lds = (size_t)N * (KPS + VPS) * sizeof(float);
+  const size_t lds = ((size_t)N * (KPS + VPS) + (size_t)ROWS_PER_BLOCK * (KP + VP)) * sizeof(float);
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
-  hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  DFOLD_LAUNCH(ipa_softmax_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dP, q_pts, k_pts, v_pts, do_pt,
-                     hw, dS, (bf16_t*)dS_bf16, dq_pts, dhw, d);
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* dsb = (bf16_t*)dS_bf16;
+  if (N <= 256) {
+    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<4>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+  } else if (N <= 512) {
+    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<8>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+  } else {
+    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<MAXT>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+  }
   return dfold_check_launch();
 }
 

@@ -231,30 +231,31 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
                 seg_div=5, seg_div_mid=5, flags=flags)
 
 
-def grid_transpose_shift(g, x, C, d0, nd, out):
+def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None):
     check(_lib.lib().dfold_grid_transpose_shift(_p(x), _p(out), c_int32(g.Wn), c_int32(g.Fp), c_int32(g.Wp), c_int32(C),
-                                                c_int32(g.N), c_int32(d0), c_int32(nd), stream()),
+                                                c_int32(g.N), c_int32(d0), c_int32(nd), _p(colsum), stream()),
           "dfold_grid_transpose_shift")
     return out
 
 
-def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True):
+def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None):
     """dW (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.  The narrower operand gets the 5
     column-shifted transposed copies, the wider one a single copy; the WIDER operand is always the GEMM's M side
     (1280 = 5 x 256 rows, the narrow 640 = 2 x 320 columns: both tile exactly), so
       CI <= CO: dwg fp32 [CO][25][CI]            (gy rows x shifted-x columns)
-      CI >  CO: dwg fp32 [CI][25][CO] TRANSPOSED (x rows x shifted-gy columns, taps flipped)."""
+      CI >  CO: dwg fp32 [CI][25][CO] TRANSPOSED (x rows x shifted-gy columns, taps flipped).
+    bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass)."""
     CI, CO = x.shape[-1], gy.shape[-1]
     plane, N, F = g.plane, g.N, g.F
     fl = GEMM_ACCUM if accumulate else 0
     if CI <= CO:   # shift x
         tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)))
-        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)))
+        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)), colsum=bias_grad)
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
              a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
     else:          # shift gy, taps flipped, transposed accumulator
-        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)))
+        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)), colsum=bias_grad)
         tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
         gemm(tU, tS, dwg, CI, CO, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CO), ldb=plane,
              a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CO * plane),
@@ -351,13 +352,11 @@ class ConvTower:
         dv = relu_mask_bf16(gi, saved[3 * 3 + 2], ws.get("dv", tuple(gtop.shape)))
         for i in (3, 2, 1, 0):
             hprev, u, v = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
-            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws)
-            colsum_bf16(dv, self.db[2 * i + 1], dv.numel() // C, C, C)
+            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws, bias_grad=self.db[2 * i + 1])
             du = ws.get("du", tuple(u.shape))
             self._zero_border_once(du, "du")
             conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u)
-            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws)
-            colsum_bf16(du, self.db[2 * i], du.numel() // (C // 2), C // 2, C // 2)
+            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws, bias_grad=self.db[2 * i])
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
                 conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2])
