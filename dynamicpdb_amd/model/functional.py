@@ -378,6 +378,64 @@ class IpaCoreFn(Function):
         return dq, dkv, dq_pts, dk_pts, dv_pts, dz, dw_b, dw_dz, db_dz, None, dhw
 
 
+class IpaPointsFn(Function):
+    """raw point projections -> global-frame points (src/model/ipa_pytorch_dynamic.py:363-390).
+    raw_q fp32 [..,3*H*Pq], raw_kv fp32 [..,3*H*(Pq+Pv)], t7 fp32 [..,7] -> q_pts [..,H,Pq,3], k_pts, v_pts [..,H,Pv,3]"""
+
+    @staticmethod
+    def forward(ctx, raw_q, raw_kv, t7):
+        lead = t7.shape[:-1]
+        P = t7.numel() // 7
+        rq, rkv, t = raw_q.contiguous(), raw_kv.contiguous(), t7.contiguous()
+        dev = t7.device
+        q_pts = torch.empty(lead + (8, 8, 3), dtype=torch.float32, device=dev)
+        k_pts = torch.empty(lead + (8, 8, 3), dtype=torch.float32, device=dev)
+        v_pts = torch.empty(lead + (8, 12, 3), dtype=torch.float32, device=dev)
+        check(_lib.lib().dfold_ipa_points_fwd(_p(rq), _p(rkv), _p(t), _p(q_pts), _p(k_pts), _p(v_pts), c_int64(P), stream()),
+              "dfold_ipa_points_fwd")
+        ctx.save_for_backward(rq, rkv, t)
+        return q_pts, k_pts, v_pts
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        rq, rkv, t = ctx.saved_tensors
+        P = t.numel() // 7
+        drq, drkv, dt = torch.empty_like(rq), torch.empty_like(rkv), torch.empty_like(t)
+        dq, dk, dv = dq.contiguous(), dk.contiguous(), dv.contiguous()   # keep the copies alive across the launch
+        check(_lib.lib().dfold_ipa_points_bwd(_p(rq), _p(rkv), _p(t), _p(dq), _p(dk), _p(dv), _p(drq), _p(drkv), _p(dt),
+                                              c_int64(P), stream()),
+              "dfold_ipa_points_bwd")
+        return drq, drkv, dt
+
+
+class IpaOutFeatFn(Function):
+    """global-frame attended points -> the 2 x 384 geometry columns of the IPA output features (:470-488, :504):
+    [x|y|z|norm] of R^T(o_pt - t) (local frame) and of o_pt (global frame), bf16."""
+
+    @staticmethod
+    def forward(ctx, o_pt, t7, eps):
+        lead = t7.shape[:-1]
+        P = t7.numel() // 7
+        o, t = o_pt.contiguous(), t7.contiguous()
+        geo_l = torch.empty(lead + (384,), dtype=BF16, device=t7.device)
+        geo_g = torch.empty(lead + (384,), dtype=BF16, device=t7.device)
+        check(_lib.lib().dfold_ipa_outfeat_fwd(_p(o), _p(t), _p(geo_l), _p(geo_g), c_int64(P), ctypes_float(eps), stream()),
+              "dfold_ipa_outfeat_fwd")
+        ctx.save_for_backward(o, t)
+        ctx.eps = eps
+        return geo_l, geo_g
+
+    @staticmethod
+    def backward(ctx, dl, dg):
+        o, t = ctx.saved_tensors
+        P = t.numel() // 7
+        do, dt = torch.empty_like(o), torch.empty_like(t)
+        dl, dg = dl.contiguous(), dg.contiguous()     # (slices of the concatenated feature gradient: real copies)
+        check(_lib.lib().dfold_ipa_outfeat_bwd(_p(o), _p(t), _p(dl), _p(dg), _p(do), _p(dt),
+                                               c_int64(P), ctypes_float(ctx.eps), stream()), "dfold_ipa_outfeat_bwd")
+        return do, dt, None
+
+
 # ------------------------------------------------------------------------------------------------
 # IGSO(3) score series node
 # ------------------------------------------------------------------------------------------------

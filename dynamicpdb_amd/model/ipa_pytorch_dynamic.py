@@ -162,28 +162,12 @@ class InvariantPointAttention(nn.Module):
         kv = F_.linear(s, self.linear_kv.weight, self.linear_kv.bias)
         qp = F_.linear(s, self.linear_q_points.weight, self.linear_q_points.bias, out_fp32=True)
         kvp = F_.linear(s, self.linear_kv_points.weight, self.linear_kv_points.bias, out_fp32=True)
-        R = G.quat_to_rot(t7[..., :4])                    # [B,F,N,3,3]
-        tr = t7[..., 4:]
-
-        def to_global(raw, npts):
-            xyz = torch.stack(torch.chunk(raw, 3, dim=-1), -1)            # [B,F,N,H*npts,3]
-            glob = G.rot_apply(R[..., None, :, :], xyz) + tr[..., None, :]
-            return glob.view(B, Fr, N, H, npts, 3)
-
-        q_pts = to_global(qp, PQ)
-        kv_pts = to_global(kvp, PQ + PV)
-        k_pts, v_pts = kv_pts[..., :PQ, :].contiguous(), kv_pts[..., PQ:, :].contiguous()
+        q_pts, k_pts, v_pts = F_.IpaPointsFn.apply(qp, kvp, t7)                       # global frame (:363-390)
         hw = Fn.softplus(self.head_weights) * math.sqrt(1.0 / (3 * (PQ * 9.0 / 2)))
         o, o_pt_g, o_pair = F_.IpaCoreFn.apply(q, kv, q_pts, k_pts, v_pts, z, self.linear_b.weight, self.down_z.weight,
                                                self.down_z.bias, mask, hw)
-        o_pt_l = G.rot_apply(R.transpose(-1, -2)[..., None, None, :, :], o_pt_g - tr[..., None, None, :])  # :481
-        n_l = torch.sqrt((o_pt_l ** 2).sum(-1) + self.eps).reshape(B, Fr, N, H * PV)
-        n_g = torch.sqrt((o_pt_g ** 2).sum(-1) + self.eps).reshape(B, Fr, N, H * PV)
-        o_pt_l = o_pt_l.reshape(B, Fr, N, H * PV, 3)
-        o_pt_gf = o_pt_g.reshape(B, Fr, N, H * PV, 3)
-        geo = torch.cat([o_pt_l[..., 0], o_pt_l[..., 1], o_pt_l[..., 2], n_l], -1).to(BF16)
-        geo_g = torch.cat([o_pt_gf[..., 0], o_pt_gf[..., 1], o_pt_gf[..., 2], n_g], -1).to(BF16)
-        return torch.cat([o, geo, o_pair, geo_g], -1)                                                       # :504
+        geo_l, geo_g = F_.IpaOutFeatFn.apply(o_pt_g, t7, self.eps)                       # :470-488
+        return torch.cat([o, geo_l, o_pair, geo_g], -1)                                   # :504
 
     def forward(self, s, z, r, mask, _offload_inference=False, _z_reference_list=None):
         """Reference signature: s [*,N,c_s], z [N,N,c_z] (no frame axis), r Rigid [*,N], mask [*,N] -> [*,N,c_s]."""

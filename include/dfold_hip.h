@@ -106,6 +106,20 @@ int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64
                          int64_t bs_dst1, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rigid-frame geometry of IPA (src/model/ipa_pytorch_dynamic.py:363-390 and :470-488), H=8, Pq=8, Pv=12; all fp32, one
+ * workgroup per residue.  raw_q [P][3*64], raw_kv [P][3*160]: linear_q_points / linear_kv_points outputs (x|y|z blocks).
+ * dt7 [P][7] = gradient w.r.t. the tensor_7 frame (quaternion via dL/dR of the quadratic-form matrix, translation).
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_ipa_points_fwd(const float* raw_q, const float* raw_kv, const float* t7, float* q_pts, float* k_pts, float* v_pts,
+                         int64_t P, void* stream);
+int dfold_ipa_points_bwd(const float* raw_q, const float* raw_kv, const float* t7, const float* dq_pts, const float* dk_pts,
+                         const float* dv_pts, float* draw_q, float* draw_kv, float* dt7, int64_t P, void* stream);
+/* o_pt [P][8][12][3] global frame -> geo_l / geo_g bf16 [P][384] = [x|y|z|norm] of R^T(o_pt - t) and of o_pt (:470-488,504) */
+int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t P, float eps, void* stream);
+int dfold_ipa_outfeat_bwd(const float* o_pt, const float* t7, const void* dgeo_l, const void* dgeo_g, float* do_pt, float* dt7,
+                          int64_t P, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MyLayerNorm (src/model/ipa_pytorch_dynamic.py:709-724): whole-window statistics, unbiased variance,
  * eps inside the sqrt, no affine; optional fused SiLU (embedders :757-796).  x fp32 [W][n] -> y bf16.
  * stats: caller workspace of 2*W doubles; mean_rstd: 2*W floats kept for the backward.
