@@ -289,39 +289,33 @@ __global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restric
                                                           const float* __restrict__ q_pts, const float* __restrict__ k_pts,
                                                           const float* __restrict__ do_pt, const float* __restrict__ hw,
                                                           float* __restrict__ dk_pts, float* __restrict__ dv_pts, IpaDims d) {
-  extern __shared__ float sm[];
+  // lane <-> key/value residue j; the loop runs over query rows i.  The per-row vectors q_pts[i], do_pt[i] have
+  // wave-uniform addresses: they are fetched through the scalar unit (s_load) and enter the FMAs as SGPR operands --
+  // no LDS traffic at all (the LDS-broadcast version spent 61 ds_read per row iteration).
   const int N = d.N, H = d.H;
-  float* qp = sm;           // [N][KP]   (broadcast reads)
-  float* dop = sm + N * KP; // [N][VP]
   const int bf = blockIdx.z, h = blockIdx.y;
   const float* qbase = q_pts + ((long)bf * N * H + h) * KP;
   const float* dbase = do_pt + ((long)bf * N * H + h) * VP;
-  for (int e = threadIdx.x; e < N * KP; e += 256) {
-    const int i = e / KP, c = e - i * KP;
-    qp[e] = qbase[(long)i * H * KP + c];
-  }
-  for (int e = threadIdx.x; e < N * VP; e += 256) {
-    const int i = e / VP, c = e - i * VP;
-    dop[e] = dbase[(long)i * H * VP + c];
-  }
-  __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
+  const bool ok = j < N;
   float aq[KP], av[VP], cs = 0.f;
 #pragma unroll
   for (int c = 0; c < KP; ++c) aq[c] = 0.f;
 #pragma unroll
   for (int c = 0; c < VP; ++c) av[c] = 0.f;
-  const long base = ((long)bf * H + h) * N * N + j;
+  const long base = ((long)bf * H + h) * N * N + (ok ? j : 0);
   for (int i = 0; i < N; ++i) {
     const float ds = dS[base + (long)i * N];
     const float p = P[base + (long)i * N];
+    const float* qi = qbase + (long)i * H * KP;
+    const float* di = dbase + (long)i * H * VP;
     cs += ds;
 #pragma unroll
-    for (int c = 0; c < KP; ++c) aq[c] += ds * qp[i * KP + c];
+    for (int c = 0; c < KP; ++c) aq[c] += ds * qi[c];
 #pragma unroll
-    for (int c = 0; c < VP; ++c) av[c] += p * dop[i * VP + c];
+    for (int c = 0; c < VP; ++c) av[c] += p * di[c];
   }
+  if (!ok) return;
   const float hwh = hw[h];
   const long pix = ((long)bf * N + j) * H + h;
 #pragma unroll
@@ -336,11 +330,8 @@ extern "C" int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q
   if (!P || !dS || !q_pts || !k_pts || !do_pt || !hw || !dk_pts || !dv_pts) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  const size_t lds = (size_t)N * (KP + VP) * sizeof(float);
-  if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid((N + 255) / 256, H, B * F);
-  hipFuncSetAttribute((const void*)ipa_col_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  DFOLD_LAUNCH(ipa_col_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
+  DFOLD_LAUNCH(ipa_col_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
                      dv_pts, d);
   return dfold_check_launch();
 }
