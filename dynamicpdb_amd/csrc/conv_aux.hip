@@ -218,13 +218,78 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// 16-byte form: a thread owns 8 adjacent columns, a block covers TILE column groups x (256/TILE) row lanes; ~2 blocks
+// per CU so that the fp32 atomics per output address stay in the hundreds (same-address atomics serialise in L2).
+template <int TILE>
+__global__ __launch_bounds__(256) void colsum_bf16_v8_kernel(const bf16_t* __restrict__ X, float* __restrict__ out, long R,
+                                                             int C, long ld) {
+  constexpr int RL = 256 / TILE;
+  __shared__ float part[RL][TILE * 8 + 1];
+  const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
+  const int cg = blockIdx.x * TILE + tx;
+  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cg * 8 < C) {
+    const bf16_t* p = X + (long)cg * 8;
+    long r = r0 + ty;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(p + (r + (long)u * RL) * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bf16_t* e = (const bf16_t*)&v[u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(e[j]);
+      }
+    }
+    for (; r < r1; r += RL) {
+      const uint4 v = *(const uint4*)(p + r * ld);
+      const bf16_t* e = (const bf16_t*)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f(e[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < TILE * 8; c += 256) {
+    const int col = blockIdx.x * TILE * 8 + c;
+    if (col < C) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int y = 0; y < RL; ++y) s += part[y][c];
+      atomicAdd(out + col, s);
+    }
+  }
+}
+
 extern "C" int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream) {
   if (!X || !out || R <= 0 || C <= 0 || ld < C) return DFOLD_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if ((C % 8) == 0 && (ld % 8) == 0 && ((uintptr_t)X % 16) == 0) {
+    const int cgs = C / 8;
+    const int tile = cgs >= 64 ? 64 : cgs >= 32 ? 32 : cgs >= 16 ? 16 : cgs >= 8 ? 8 : 4;
+    const int bx = (cgs + tile - 1) / tile;
+    const int rl = 256 / tile;
+    long by = (R + (long)rl * 16 - 1) / ((long)rl * 16);
+    const long cap = max(1L, 512L / bx);
+    if (by > cap) by = cap;
+    dim3 grid(bx, (unsigned)by);
+    switch (tile) {
+      case 64: DFOLD_LAUNCH(colsum_bf16_v8_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+      case 32: DFOLD_LAUNCH(colsum_bf16_v8_kernel<32>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+      case 16: DFOLD_LAUNCH(colsum_bf16_v8_kernel<16>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+      case 8: DFOLD_LAUNCH(colsum_bf16_v8_kernel<8>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+      default: DFOLD_LAUNCH(colsum_bf16_v8_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+    }
+    return dfold_check_launch();
+  }
   long chunks = (R + 511) / 512;
   if (chunks > 1024) chunks = 1024;
   dim3 grid((C + 63) / 64, (unsigned)chunks);
-  DFOLD_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, out, (long)R, C,
-                     (long)ld);
+  DFOLD_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld);
   return dfold_check_launch();
 }
 

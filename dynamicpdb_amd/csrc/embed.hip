@@ -70,24 +70,35 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
     if (dx != nullptr)
       for (int e = threadIdx.x; e < EMB_ROWS * EMB_MAXK; e += 256) dxs[e / EMB_MAXK][e % EMB_MAXK] = 0.f;
     __syncthreads();
-    for (int r = 0; r < rows; ++r) {
-      float pre = bo;
+    // rows in groups of 8 with the 8 gradient loads issued together (the row loop is otherwise one dependent
+    // global load per iteration)
+    for (int rb = 0; rb < rows; rb += 8) {
+      float gv[8];
 #pragma unroll
-      for (int c = 0; c < EMB_MAXK; ++c)
-        if (c < k) pre += xs[r][c] * w[c];
-      const float sg = sigmoid_f(pre);
-      const float gp = bf2f(g[(r0 + r) * D + o]) * sg * (1.f + pre * (1.f - sg));
-      ab += gp;
+      for (int u = 0; u < 8; ++u) gv[u] = rb + u < rows ? bf2f(g[(r0 + rb + u) * D + o]) : 0.f;
 #pragma unroll
-      for (int c = 0; c < EMB_MAXK; ++c)
-        if (c < k) aw[c] += gp * xs[r][c];
-      if (dx != nullptr) {
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u;
+        if (r < rows) {
+          float pre = bo;
 #pragma unroll
-        for (int c = 0; c < EMB_MAXK; ++c)
-          if (c < k) {
-            const float s = wave_sum(gp * w[c]);
-            if (lane == 0) atomicAdd(&dxs[r][c], s);
+          for (int c = 0; c < EMB_MAXK; ++c)
+            if (c < k) pre += xs[r][c] * w[c];
+          const float sg = sigmoid_f(pre);
+          const float gp = gv[u] * sg * (1.f + pre * (1.f - sg));
+          ab += gp;
+#pragma unroll
+          for (int c = 0; c < EMB_MAXK; ++c)
+            if (c < k) aw[c] += gp * xs[r][c];
+          if (dx != nullptr) {
+#pragma unroll
+            for (int c = 0; c < EMB_MAXK; ++c)
+              if (c < k) {
+                const float s = wave_sum(gp * w[c]);
+                if (lane == 0) atomicAdd(&dxs[r][c], s);
+              }
           }
+        }
       }
     }
     if (dx != nullptr) {

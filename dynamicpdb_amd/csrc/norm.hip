@@ -86,7 +86,11 @@ extern "C" int dfold_gln_fwd(const float* x, double* stats, void* y_bf16, float*
   long bx = (n / 4 + 255) / 256;
   if (bx > 512) bx = 512;
   dim3 grid((unsigned)bx, W);
-  DFOLD_LAUNCH(gln_stats_kernel, grid, dim3(256), 0, st, x, stats, (long)n);
+  // the two fp64 atomics per workgroup all land on the window's stats pair and serialise in L2: ~1024 workgroups in all
+  long sx = bx;
+  const long cap = 1024 / W > 0 ? 1024 / W : 1;
+  if (sx > cap) sx = cap;
+  DFOLD_LAUNCH(gln_stats_kernel, dim3((unsigned)sx, W), dim3(256), 0, st, x, stats, (long)n);
   DFOLD_LAUNCH(gln_apply_kernel, grid, dim3(256), 0, st, x, (const double*)stats, (bf16_t*)y_bf16, mean_rstd, (long)n,
                      eps, silu);
   return dfold_check_launch();
@@ -103,12 +107,32 @@ __global__ __launch_bounds__(256) void gln_bwd_stats_kernel(const float* __restr
   const float* xw = x + (long)w * n;
   const bf16_t* gw = g + (long)w * n;
   double s = 0.0, s2 = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float y = (xw[i] - mean) * rstd;
-    float gy = bf2f(gw[i]);
-    if (silu) gy *= silu_grad_f(y);
-    s += gy;
-    s2 += (double)gy * y;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 xv = *(const float4*)(xw + i);
+      const uint2 gv = *(const uint2*)(gw + i);
+      const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float ge[4] = {bf_lo(gv.x), bf_hi(gv.x), bf_lo(gv.y), bf_hi(gv.y)};
+      float ps = 0.f, ps2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y = (xe[j] - mean) * rstd;
+        float gy = ge[j];
+        if (silu) gy *= silu_grad_f(y);
+        ps += gy;
+        ps2 += gy * y;
+      }
+      s += ps;
+      s2 += ps2;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float y = (xw[k] - mean) * rstd;
+        float gy = bf2f(gw[k]);
+        if (silu) gy *= silu_grad_f(y);
+        s += gy;
+        s2 += (double)gy * y;
+      }
+    }
   }
   s = wave_sum_d(s);
   s2 = wave_sum_d(s2);
@@ -134,23 +158,47 @@ __global__ __launch_bounds__(256) void gln_bwd_apply_kernel(const float* __restr
   const float* xw = x + (long)w * n;
   const bf16_t* gw = g + (long)w * n;
   bf16_t* dw = dx + (long)w * n;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float y = (xw[i] - mean) * rstd;
-    float gy = bf2f(gw[i]);
-    if (silu) gy *= silu_grad_f(y);
-    dw[i] = f2bf(rstd * (gy - mg - y * cg));
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 xv = *(const float4*)(xw + i);
+      const uint2 gv = *(const uint2*)(gw + i);
+      const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float ge[4] = {bf_lo(gv.x), bf_hi(gv.x), bf_lo(gv.y), bf_hi(gv.y)};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y = (xe[j] - mean) * rstd;
+        float gy = ge[j];
+        if (silu) gy *= silu_grad_f(y);
+        o[j] = rstd * (gy - mg - y * cg);
+      }
+      uint2 ov;
+      ov.x = pack2bf(o[0], o[1]);
+      ov.y = pack2bf(o[2], o[3]);
+      *(uint2*)(dw + i) = ov;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float y = (xw[k] - mean) * rstd;
+        float gy = bf2f(gw[k]);
+        if (silu) gy *= silu_grad_f(y);
+        dw[k] = f2bf(rstd * (gy - mg - y * cg));
+      }
+    }
   }
 }
 
 extern "C" int dfold_gln_bwd(const float* x, const void* g_bf16, const float* mean_rstd, double* stats, void* dx_bf16,
                              int32_t W, int64_t n, int32_t silu, void* stream) {
-  if (!x || !g_bf16 || !mean_rstd || !stats || !dx_bf16 || W <= 0 || n < 2) return DFOLD_EINVAL;
+  if (!x || !g_bf16 || !mean_rstd || !stats || !dx_bf16 || W <= 0 || n < 2 || (n & 3)) return DFOLD_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * W, st) != hipSuccess) return DFOLD_ELAUNCH;
-  long bx = (n + 255) / 256;
-  if (bx > 1024) bx = 1024;
+  long bx = (n / 4 + 255) / 256;
+  if (bx > 512) bx = 512;
   dim3 grid((unsigned)bx, W);
-  DFOLD_LAUNCH(gln_bwd_stats_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd, stats, (long)n, silu);
+  long sx = bx;
+  const long cap = 1024 / W > 0 ? 1024 / W : 1;
+  if (sx > cap) sx = cap;
+  DFOLD_LAUNCH(gln_bwd_stats_kernel, dim3((unsigned)sx, W), dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd, stats, (long)n, silu);
   DFOLD_LAUNCH(gln_bwd_apply_kernel, grid, dim3(256), 0, st, x, (const bf16_t*)g_bf16, mean_rstd,
                      (const double*)stats, (bf16_t*)dx_bf16, (long)n, silu);
   return dfold_check_launch();

@@ -97,6 +97,20 @@ def _conv_case(dev, Wn, F, N, CI, CO):
     assert float(out[:, :2].abs().max()) == 0 and float(out[:, :, -2:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("R,C,ld", [(65536, 256, 256), (524288, 32, 32), (10007, 128, 136), (5000, 1280, 1280),
+                                    (777, 24, 24), (3001, 6, 6), (64, 8, 8)])
+def test_colsum(dev, R, C, ld):
+    """bias-gradient column sums: 16-byte kernel (C, ld multiples of 8) and the scalar fallback."""
+    from dynamicpdb_amd import ops
+    x = _rand_bf16((R, ld), dev, 11)
+    out = torch.zeros(C, dtype=torch.float32, device=dev)
+    ops.colsum_bf16(x, out, R, C, ld)
+    ref = x[:, :C].double().sum(0)
+    assert (out.double() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    ops.colsum_bf16(x, out, R, C, ld)            # accumulates
+    assert (out.double() - 2 * ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_transpose_and_cast(dev):
     from dynamicpdb_amd import ops
     x = torch.randn(3, 70, 130, device=dev)
