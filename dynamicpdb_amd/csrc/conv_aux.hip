@@ -345,14 +345,57 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
+// 16-byte form (R, C, leading dimensions, batch strides all multiples of 8 and 16-byte aligned bases): a 64x64 tile is
+// read as 16-byte row segments, parked in LDS (row pitch 66: the transposed 2-byte gathers then spread over all
+// banks) and written as 16-byte segments of the destination rows.
+__global__ __launch_bounds__(256) void transpose_bf16_v8_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                int R, int C, long lds_, long ldd, long sbs0, long sbs1,
+                                                                long sbd0, long sbd1, int nb1) {
+  __shared__ bf16_t t[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int z0 = blockIdx.z / nb1, z1 = blockIdx.z - z0 * nb1;
+  const bf16_t* s = src + z0 * sbs0 + z1 * sbs1;
+  bf16_t* d = dst + z0 * sbd0 + z1 * sbd1;
+  const int ch = threadIdx.x & 7, rr = threadIdx.x >> 3;
+  uint4 v[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = r0 + rr + 32 * it, c = c0 + ch * 8;
+    v[it] = (r < R && c < C) ? *(const uint4*)(s + (long)r * lds_ + c) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    uint32_t* row = (uint32_t*)&t[rr + 32 * it][ch * 8];   // pitch 132 B: 4-byte aligned
+    row[0] = v[it].x; row[1] = v[it].y; row[2] = v[it].z; row[3] = v[it].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cl = rr + 32 * it, c = c0 + cl, r = r0 + ch * 8;
+    if (c < C && r < R) {
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (uint32_t)t[ch * 8 + 2 * j][cl] | ((uint32_t)t[ch * 8 + 2 * j + 1][cl] << 16);
+      *(uint4*)(d + (long)c * ldd + r) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32_t C, int64_t ld_src, int64_t ld_dst,
                                     int32_t nbatch, int32_t nb1, int64_t bs_src0, int64_t bs_src1, int64_t bs_dst0,
                                     int64_t bs_dst1, void* stream) {
   if (!src || !dst || R <= 0 || C <= 0 || nbatch <= 0 || nb1 <= 0 || ld_src < C || ld_dst < R) return DFOLD_EINVAL;
   if (nbatch > 65535) return DFOLD_EINVAL;
   dim3 grid((C + 63) / 64, (R + 63) / 64, nbatch);
-  DFOLD_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
-                     C, (long)ld_src, (long)ld_dst, (long)bs_src0, (long)bs_src1, (long)bs_dst0, (long)bs_dst1, nb1);
+  const bool vec = ((R | C) % 8) == 0 && ((ld_src | ld_dst | bs_src0 | bs_src1 | bs_dst0 | bs_dst1) % 8) == 0 &&
+                   ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0;
+  if (vec)
+    DFOLD_LAUNCH(transpose_bf16_v8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
+                 C, (long)ld_src, (long)ld_dst, (long)bs_src0, (long)bs_src1, (long)bs_dst0, (long)bs_dst1, nb1);
+  else
+    DFOLD_LAUNCH(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R,
+                 C, (long)ld_src, (long)ld_dst, (long)bs_src0, (long)bs_src1, (long)bs_dst0, (long)bs_dst1, nb1);
   return dfold_check_launch();
 }
 

@@ -94,3 +94,97 @@ extern "C" int dfold_se3_reverse(const float* t7, const double* rot_score, const
                rot_score, trans_score, z_rot, z_trans, mask, out, N, g_rot, b_t, dt, noise_scale, coordinate_scaling, center);
   return dfold_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Forward noising q(x_t | x_0) on device (reference SE3Diffuser.forward_marginal src/data/se3_diffuser.py:43-110 ->
+// SO3Diffuser.forward_marginal so3_diffuser.py:311-327: sample :233-248 (uniform direction x IGSO(3) angle by
+// inverse CDF :215-231 = np.interp on the cdf row of sigma(t)), compose_rotvec src/data/utils.py:184-195;
+// R3Diffuser.forward_marginal r3_diffuser.py:81-101).  The reference does this per item in forked DataLoader workers
+// (numpy fp64, scipy rotvec<->matrix, eigh back to quaternions); here one thread per frame, fp64 arithmetic, the
+// draws (u uniform, z_dir / z_trans normal) are INPUTS exactly as in dfold_se3_reverse.  The IGSO(3) score of the
+// sampled rotation vector is evaluated by dfold_igso3_series on `rotvec_out` (host wrapper).
+// Each window w has its own t: cdf_idx[w] selects the cdf row, b_t[w] = R3 marginal beta.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se3_forward_marginal_kernel(
+    const float* __restrict__ t7, const double* __restrict__ u, const double* __restrict__ z_dir,
+    const double* __restrict__ z_trans, const float* __restrict__ mask, const double* __restrict__ cdf,
+    const double* __restrict__ omega_grid, const int* __restrict__ cdf_idx, const double* __restrict__ b_t,
+    float* __restrict__ out, double* __restrict__ rotvec_out, float* __restrict__ trans_score, long P, long per_window,
+    int num_omega, double cs) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int w = (int)(p / per_window);
+  // ---- IGSO(3) angle: np.interp(u, cdf_row, omega_grid) ----
+  const double* xp = cdf + (long)cdf_idx[w] * num_omega;
+  const double x = u[p];
+  double om;
+  if (x <= xp[0]) {
+    om = omega_grid[0];
+  } else if (x >= xp[num_omega - 1]) {
+    om = omega_grid[num_omega - 1];
+  } else {
+    int lo = 0, hi = num_omega - 1;   // invariant: xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double slope = (omega_grid[lo + 1] - omega_grid[lo]) / (xp[lo + 1] - xp[lo]);
+    om = slope * (x - xp[lo]) + omega_grid[lo];
+  }
+  // ---- rotation vector = unit(z_dir) * omega ----
+  double v[3];
+  double n2 = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    v[c] = z_dir[p * 3 + c];
+    n2 += v[c] * v[c];
+  }
+  const double sc = om / sqrt(n2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] *= sc;
+  const bool keep = mask != nullptr && mask[p] == 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rotvec_out[p * 3 + c] = v[c];
+  // ---- q_t = normalize(q_0) (x) exp(v) ----
+  double q[4];
+  double qn = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    q[c] = t7[p * 7 + c];
+    qn += q[c] * q[c];
+  }
+  qn = 1.0 / sqrt(qn);
+  const double sh = om > 1e-12 ? sin(0.5 * om) / om : 0.5;
+  const double e0 = cos(0.5 * om), e1 = sh * v[0], e2 = sh * v[1], e3 = sh * v[2];
+  const double a = q[0] * qn, b = q[1] * qn, c_ = q[2] * qn, d = q[3] * qn;
+  double o[4];
+  o[0] = a * e0 - b * e1 - c_ * e2 - d * e3;
+  o[1] = a * e1 + b * e0 + c_ * e3 - d * e2;
+  o[2] = a * e2 - b * e3 + c_ * e0 + d * e1;
+  o[3] = a * e3 + b * e2 - c_ * e1 + d * e0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[p * 7 + c] = keep ? t7[p * 7 + c] : (float)o[c];
+  // ---- translation: x_t ~ N(e^{-b/2} x_0, 1 - e^{-b}) on scaled coordinates; score = -(x_t - e^{-b/2} x_0)/(1 - e^{-b})
+  const double bt = b_t[w], mean_c = exp(-0.5 * bt), var = 1.0 - exp(-bt), sd = sqrt(var);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double x0 = cs * (double)t7[p * 7 + 4 + c];
+    const double xt = mean_c * x0 + sd * z_trans[p * 3 + c];
+    out[p * 7 + 4 + c] = keep ? t7[p * 7 + 4 + c] : (float)(xt / cs);
+    trans_score[p * 3 + c] = keep ? 0.f : (float)(-(xt - mean_c * x0) / var);
+  }
+}
+
+extern "C" int dfold_se3_forward_marginal(const float* t7, const double* u, const double* z_dir, const double* z_trans,
+                                          const float* mask, const double* cdf, const double* omega_grid,
+                                          const int32_t* cdf_idx, const double* b_t, float* out, double* rotvec_out,
+                                          float* trans_score, int64_t P, int64_t per_window, int32_t num_omega,
+                                          double coordinate_scaling, void* stream) {
+  if (!t7 || !u || !z_dir || !z_trans || !cdf || !omega_grid || !cdf_idx || !b_t || !out || !rotvec_out || !trans_score)
+    return DFOLD_EINVAL;
+  if (P <= 0 || per_window <= 0 || (P % per_window) != 0 || num_omega < 2 || !(coordinate_scaling > 0)) return DFOLD_EINVAL;
+  DFOLD_LAUNCH(se3_forward_marginal_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t7, u,
+               z_dir, z_trans, mask, cdf, omega_grid, (const int*)cdf_idx, b_t, out, rotvec_out, trans_score, (long)P,
+               (long)per_window, num_omega, coordinate_scaling);
+  return dfold_check_launch();
+}

@@ -152,6 +152,75 @@ class SE3Diffuser:
             out[..., 4:] = t7[..., 4:]
         return out
 
+    def forward_marginal_t7(self, rigids_0, t, diffuse_mask=None, u=None, z_dir=None, z_trans=None):
+        """Device form of `forward_marginal` on tensor_7 frames: [F,N,7] with scalar t (the reference's per-item call,
+        Dfold_data_loader_dynamic.py:336-345) or [B,F,N,7] with t [B] (one t per window).  One HIP launch for the sampling
+        (csrc/diffusion.hip) + the IGSO(3) series launch for the rotation score.  Draws default to numpy's global RNG in
+        the reference's order per window (direction normals, then the uniform of the inverse CDF, so3_diffuser.py:233-248;
+        then the translation normals, r3_diffuser.py:96-99); pass u / z_dir / z_trans to inject them.  The quaternion of
+        rigids_t is q_0 (x) exp(v): the same rotation as the reference's matrix product, sign not canonicalised (the
+        reference's comes out of eigh, rigid_utils.py:226)."""
+        from ctypes import c_double, c_int32, c_int64
+        from .. import _lib
+        from ..ops import _p
+        dev = rigids_0.device
+        if dev.type != 'cuda':
+            raise RuntimeError("forward_marginal_t7 needs device tensors; use forward_marginal for host Rigid objects")
+        t7 = rigids_0.detach().float().contiguous()
+        batched = t7.dim() == 4
+        t_np = np.atleast_1d(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t, dtype=np.float64)).astype(np.float64)
+        W = t7.shape[0] if batched else 1
+        if len(t_np) != W:
+            raise ValueError(f'{t} must hold one value per window.')
+        if np.any(t_np < 0) or np.any(t_np > 1):
+            raise ValueError(f'Invalid t={t}')
+        P = t7.numel() // 7
+        per_window = P // W
+        lead = tuple(t7.shape[:-1])
+        if u is None or z_dir is None or z_trans is None:
+            zd, uu, zt = [], [], []
+            for _ in range(W):
+                zd.append(np.random.randn(per_window, 3))
+                uu.append(np.random.rand(per_window))
+                zt.append(np.random.normal(size=(per_window, 3)))
+            z_dir = np.stack(zd) if z_dir is None else z_dir
+            u = np.stack(uu) if u is None else u
+            z_trans = np.stack(zt) if z_trans is None else z_trans
+        as_dev = lambda x, dt_: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(device=dev, dtype=dt_).contiguous()
+        u_d, zd_d, zt_d = as_dev(u, torch.float64), as_dev(z_dir, torch.float64), as_dev(z_trans, torch.float64)
+        so3, r3 = self._so3_diffuser, self._r3_diffuser
+        tabs = so3.device_tables(dev)
+        idx = so3.t_to_idx(t_np)
+        idx_d = torch.as_tensor(np.asarray(idx, dtype=np.int32)).to(dev)
+        bt_d = torch.as_tensor(r3.marginal_b_t(t_np)).to(device=dev, dtype=torch.float64)
+        mask = as_dev(diffuse_mask, torch.float32) if diffuse_mask is not None else None
+        out = torch.empty_like(t7)
+        rotvec = torch.empty(lead + (3,), dtype=torch.float64, device=dev)
+        trans_score = torch.empty(lead + (3,), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().dfold_se3_forward_marginal(
+            _p(t7), _p(u_d), _p(zd_d), _p(zt_d), _p(mask), _p(tabs['cdf']), _p(tabs['omega']), _p(idx_d), _p(bt_d), _p(out),
+            _p(rotvec), _p(trans_score), c_int64(P), c_int64(per_window), c_int32(tabs['cdf'].shape[1]),
+            c_double(float(r3._r3_conf.coordinate_scaling)), _lib.stream()), "dfold_se3_forward_marginal")
+        from ..model import score_heads
+        sigma = np.atleast_1d(so3.discrete_sigma[idx])
+        rv = rotvec.float()
+        rot_score = score_heads.igso3_score(rv if batched else rv[None], sigma)
+        rot_score = rot_score if batched else rot_score[0]
+        if mask is not None:
+            rot_score = rot_score * mask.view(lead)[..., None]
+        if not self._diffuse_rot:
+            out[..., :4] = t7[..., :4]
+            rot_score = torch.zeros_like(rot_score)
+        if not self._diffuse_trans:
+            out[..., 4:] = t7[..., 4:]
+            trans_score = torch.zeros_like(trans_score)
+        rss = so3.score_scaling(t_np) if self._diffuse_rot else np.ones_like(t_np)
+        tss = r3.score_scaling(t_np) if self._diffuse_trans else np.ones_like(t_np)
+        if not batched:
+            rss, tss = rss[0], tss[0]
+        return {'rigids_t': out, 'trans_score': trans_score, 'rot_score': rot_score,
+                'trans_score_scaling': tss, 'rot_score_scaling': rss}
+
     def sample_ref(self, n_samples: int, impute: Rigid = None, diffuse_mask=None, as_tensor_7=False):
         if impute is not None:
             assert impute.shape[0] == n_samples

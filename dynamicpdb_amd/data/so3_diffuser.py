@@ -119,6 +119,15 @@ class SO3Diffuser:
         dsig = (coef @ (lo[None, :] * dhi - hi * dlo[None, :])) / (lo ** 2)[None, :]
         return pdf, cdf, dsig / (exp_vals + 1e-4)
 
+    def device_tables(self, device):
+        """cdf [num_sigma,num_omega] and the omega grid as fp64 device tensors (uploaded once per device)."""
+        cache = self.__dict__.setdefault('_dev_tables', {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = {'cdf': torch.as_tensor(np.ascontiguousarray(self._cdf, dtype=np.float64)).to(device),
+                          'omega': torch.as_tensor(np.ascontiguousarray(self.discrete_omega, dtype=np.float64)).to(device)}
+        return cache[key]
+
     @property
     def discrete_sigma(self):
         return self.sigma(np.linspace(0.0, 1.0, self.num_sigma))

@@ -220,6 +220,20 @@ int dfold_se3_reverse(const float* t7, const double* rot_score, const float* tra
                       const double* z_trans, const float* mask, float* out, int64_t rows, int32_t N, double g_rot, double b_t,
                       double dt, double noise_scale, double coordinate_scaling, int32_t center, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Forward noising q(x_t | x_0) of tensor_7 frames (replaces SE3Diffuser.forward_marginal, src/data/se3_diffuser.py:43-110
+ * -> SO3Diffuser.forward_marginal so3_diffuser.py:311-327 (sample :233-248, sample_igso3 :215-231, compose_rotvec
+ * src/data/utils.py:184-195) and R3Diffuser.forward_marginal r3_diffuser.py:81-101).  P = windows*frames*residues frames,
+ * per_window = frames*residues; window w uses cdf row cdf_idx[w] of cdf [num_sigma][num_omega] (fp64, device) and R3
+ * marginal beta b_t[w].  u fp64 [P] uniform(0,1), z_dir / z_trans fp64 [P][3] standard normal: draws are inputs.
+ * mask fp32 [P] or NULL (0 = frame stays at x_0 with zero scores).  out fp32 [P][7]; rotvec_out fp64 [P][3] = the sampled
+ * rotation vector (its IGSO(3) score comes from dfold_igso3_series); trans_score fp32 [P][3] (unscaled, as the reference).
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_se3_forward_marginal(const float* t7, const double* u, const double* z_dir, const double* z_trans,
+                               const float* mask, const double* cdf, const double* omega_grid, const int32_t* cdf_idx,
+                               const double* b_t, float* out, double* rotvec_out, float* trans_score, int64_t P,
+                               int64_t per_window, int32_t num_omega, double coordinate_scaling, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

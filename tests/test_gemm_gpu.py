@@ -119,6 +119,15 @@ def test_transpose_and_cast(dev):
     t = ops.transpose_bf16(xb, 70, 130, nbatch=3, nb1=1, bs_src=(70 * 130, 0))
     assert torch.equal(t, xb.transpose(1, 2).contiguous())
     assert torch.equal(ops.cast_f32(xb), xb.float())
+    # 16-byte path (all extents multiples of 8), ragged against the 64x64 tile, batched two-level, strided rows
+    for (nb0, nb1, R, C, ld) in [(1, 1, 72, 136, 136), (2, 3, 200, 328, 336), (1, 1, 4096, 1280, 1280), (4, 1, 8, 8, 8)]:
+        y = _rand_bf16((nb0, nb1, R, ld), dev, 5)
+        t = ops.transpose_bf16(y, R, C, ld_src=ld, nbatch=nb0 * nb1, nb1=nb1, bs_src=(nb1 * R * ld, R * ld))
+        assert torch.equal(t.view(nb0, nb1, C, R), y[..., :C].transpose(2, 3).contiguous())
+    # element offset that breaks 16-byte alignment -> scalar kernel
+    y = _rand_bf16((80 * 64 + 8,), dev, 6)
+    t = ops.transpose_bf16(y, 80, 64, src_off=4)
+    assert torch.equal(t, y[4:4 + 80 * 64].view(80, 64).t().contiguous())
 
 
 def _torch_tower(x, ws, bs):

@@ -60,6 +60,69 @@ def test_reverse_step_device_vs_host_mirror_with_mask(diffuser):
         diffuser.reverse_t7(t7.to(dev), rs, ts, np.array([0.4, 0.5]), 0.1)
 
 
+def test_forward_marginal_vs_reference_golden(diffuser):
+    """device forward noising consuming numpy's RNG stream in the reference's order reproduces the reference's own
+    SE3Diffuser.forward_marginal outputs (tests/golden/diffuser.npz, minted with np.random.seed(100+i))."""
+    dev = torch.device("cuda:0")
+    g = load_golden("diffuser.npz")
+    r0 = torch.tensor(g["rigids_0"]).to(dev)
+    for i, t in enumerate((0.05, 0.5, 0.9)):
+        np.random.seed(100 + i)
+        fm = diffuser.forward_marginal_t7(r0, float(t))
+        assert max_abs(_rotmats(fm["rigids_t"]), _rotmats(torch.tensor(g[f"fm{i}_rigids_t"]))) < 2e-5
+        assert max_abs(fm["rigids_t"][..., 4:], g[f"fm{i}_rigids_t"][..., 4:]) < 1e-4
+        assert max_abs(fm["trans_score"], g[f"fm{i}_trans_score"]) < 1e-4 * max(1.0, float(np.abs(g[f"fm{i}_trans_score"]).max()))
+        ref = g[f"fm{i}_rot_score"]
+        assert max_abs(fm["rot_score"], ref) < 2e-4 * max(1.0, float(np.abs(ref).max()))
+        assert abs(float(fm["rot_score_scaling"]) - float(g[f"fm{i}_rot_score_scaling"])) < 1e-12
+        assert abs(float(fm["trans_score_scaling"]) - float(g[f"fm{i}_trans_score_scaling"])) < 1e-12
+
+
+def test_forward_marginal_batched_windows_and_mask(diffuser):
+    """[B,F,N,7] with one t per window == B per-window calls; masked frames stay at x_0 with zero scores; host mirror
+    (numpy/scipy path) agrees on injected draws."""
+    from dynamicpdb_amd.rigid import Rigid
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    B, F, N = 3, 2, 20
+    q = rng.standard_normal((B, F, N, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    t7 = torch.tensor(np.concatenate([q, 8 * rng.standard_normal((B, F, N, 3))], -1), dtype=torch.float32)
+    ts = np.array([0.03, 0.47, 1.0])
+    u, zd, zt = rng.uniform(size=(B, F, N)), rng.standard_normal((B, F, N, 3)), rng.standard_normal((B, F, N, 3))
+    mask = (rng.uniform(size=(B, F, N)) > 0.25).astype(np.float32)
+    out = diffuser.forward_marginal_t7(t7.to(dev), ts, diffuse_mask=mask, u=u, z_dir=zd, z_trans=zt)
+    keep = torch.tensor(mask == 0)
+    assert torch.equal(out["rigids_t"].cpu()[keep], t7[keep])
+    assert float(out["rot_score"].cpu()[keep].abs().max()) == 0.0 and float(out["trans_score"].cpu()[keep].abs().max()) == 0.0
+    for b in range(B):
+        one = diffuser.forward_marginal_t7(t7[b].to(dev), float(ts[b]), diffuse_mask=mask[b], u=u[b], z_dir=zd[b], z_trans=zt[b])
+        assert torch.equal(one["rigids_t"], out["rigids_t"][b])
+        assert max_abs(one["rot_score"], out["rot_score"][b]) < 1e-12 + 1e-9 * float(out["rot_score"][b].abs().max())
+        assert float(one["rot_score_scaling"]) == float(out["rot_score_scaling"][b])
+        # host mirror on the same draws: replay them through numpy's global stream in the reference's order
+        st = np.random.get_state()
+        try:
+            seq = iter([zd[b].reshape(-1, 3), u[b].reshape(-1), zt[b]])
+            orig = (np.random.randn, np.random.rand, np.random.normal)
+            np.random.randn = lambda *a: next(seq)
+            np.random.rand = lambda *a: next(seq)
+            np.random.normal = lambda loc=0.0, scale=1.0, size=None: loc + scale * next(seq)
+            host = diffuser.forward_marginal(Rigid.from_tensor_7(t7[b]), float(ts[b]), diffuse_mask=mask[b])
+        finally:
+            np.random.randn, np.random.rand, np.random.normal = orig
+            np.random.set_state(st)
+        assert max_abs(_rotmats(one["rigids_t"]), _rotmats(torch.as_tensor(host["rigids_t"]).float())) < 2e-5
+        assert max_abs(one["rigids_t"][..., 4:], torch.as_tensor(host["rigids_t"])[..., 4:]) < 1e-4
+        hs = np.asarray(host["rot_score"])
+        assert max_abs(one["rot_score"], hs) < 2e-4 * max(1.0, float(np.abs(hs).max()))
+        assert max_abs(one["trans_score"], np.asarray(host["trans_score"])) < 1e-4 * max(1.0, float(np.abs(host["trans_score"]).max()))
+    with pytest.raises(ValueError):
+        diffuser.forward_marginal_t7(t7.to(dev), np.array([0.1, 0.2]))
+    with pytest.raises(ValueError):
+        diffuser.forward_marginal_t7(t7.to(dev), np.array([0.1, 0.2, 1.5]))
+
+
 def test_device_sampler_runs_and_is_reproducible():
     from dynamicpdb_amd import experiment, synthetic
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
