@@ -440,7 +440,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 template <int ROLE>
 __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds3[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR: LDS-DMA targets and the role branch stay scalar
   const int wm = w >> 1, wn = w & 1;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -493,29 +494,40 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   }
   const int nsteps = p.nseg * (p.seglen / BK);
 
-  // Tile cursor: (sa_cur, sb_cur) = operand bases of the tile staged next; advanced branch-free so that the DMA
-  // issue has no control flow around it (the scheduler can then spread the 9 pieces between MFMAs).  After the
-  // last tile the cursor stays put: the final, unused prefetch re-reads valid memory into the idle buffer.
-  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0, st_left = nsteps;
+  // Tile cursor: (pa, pb) = operand byte pointers of the tile staged next, advanced INCREMENTALLY and branch-free with
+  // integer masks (sign-bit tricks keep every step on the scalar ALU: the closed form seg0 + hi*s0 + mid*s1 + lo*s2 + kk
+  // cost ~85 scalar 64-bit multiply/add instructions plus VALU round trips per K step, issued by every wave right
+  // before the barrier with the matrix pipe idle).  Step deltas in bytes:
+  //   inside a segment +BK;  kk wraps: +E1;  lo wraps too: +E2;  mid wraps too: +E3   (differences, accumulated)
+  // After the last tile the pointers stay put: the final, unused prefetch re-reads valid memory into the idle buffer.
+  const long BK2 = BK * 2;
+  const long ea1 = (p.a_seg_s2 - p.seglen) * 2, ea2 = (p.a_seg_s1 - (long)p.seg_div * p.a_seg_s2) * 2,
+             ea3 = (p.a_seg_s0 - (long)p.seg_div_mid * p.a_seg_s1) * 2;
+  const long eb1 = (p.b_seg_s2 - p.seglen) * 2, eb2 = (p.b_seg_s1 - (long)p.seg_div * p.b_seg_s2) * 2,
+             eb3 = (p.b_seg_s0 - (long)p.seg_div_mid * p.b_seg_s1) * 2;
+  const char* pa = A + p.a_seg0 * 2;
+  const char* pb = B + p.b_seg0 * 2;
+  int st_mid = 0, st_lo = 0, st_kk = 0, st_left = nsteps;
   auto stage = [&](int buf) {
-    const char* sa = A + (p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk) * 2;
-    const char* sb = B + (p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk) * 2;
-    const bool adv = st_left > 1;
-    st_left -= adv ? 1 : 0;
-    int kk = st_kk + BK, lo = st_lo, mid = st_mid, hi = st_hi;
-    const bool w0 = kk >= p.seglen;
-    kk = w0 ? 0 : kk;
-    lo += w0 ? 1 : 0;
-    const bool w1 = lo == p.seg_div;
-    lo = w1 ? 0 : lo;
-    mid += w1 ? 1 : 0;
-    const bool w2 = mid == p.seg_div_mid;
-    mid = w2 ? 0 : mid;
-    hi += w2 ? 1 : 0;
-    st_kk = adv ? kk : st_kk;
-    st_lo = adv ? lo : st_lo;
-    st_mid = adv ? mid : st_mid;
-    st_hi = adv ? hi : st_hi;
+    const char* sa = pa;
+    const char* sb = pb;
+    const unsigned adv = (unsigned)(1 - st_left) >> 31;            // st_left > 1
+    st_left -= (int)adv;
+    int kk = st_kk + BK;
+    const unsigned w0 = (unsigned)(p.seglen - 1 - kk) >> 31;       // kk >= seglen
+    kk &= (int)(w0 - 1u);
+    int lo = st_lo + (int)w0;
+    const unsigned w1 = (unsigned)(p.seg_div - 1 - lo) >> 31;      // lo >= seg_div
+    lo &= (int)(w1 - 1u);
+    int mid = st_mid + (int)w1;
+    const unsigned w2 = (unsigned)(p.seg_div_mid - 1 - mid) >> 31; // mid >= seg_div_mid
+    mid &= (int)(w2 - 1u);
+    st_kk = kk;
+    st_lo = lo;
+    st_mid = mid;
+    const long k0 = -(long)w0, k1 = -(long)w1, k2 = -(long)w2, ka = -(long)adv;
+    pa += (BK2 + (ea1 & k0) + (ea2 & k1) + (ea3 & k2)) & ka;
+    pb += (BK2 + (eb1 & k0) + (eb2 & k1) + (eb3 & k2)) & ka;
     char* la = lds3 + buf * STAGE3_BYTES;
     char* lb = la + A3_BYTES;
 #pragma unroll
