@@ -437,8 +437,11 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 #define B3_BYTES (BN3 * BK * 2)
 #define STAGE3_BYTES (A3_BYTES + B3_BYTES)
 
-template <int ROLE>
+template <int ROLE, int NJ>
 __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmParams p) {
+  constexpr int BNW = 64 * NJ;                 // N tile: 320 (NJ = 5) or 256 (NJ = 4)
+  constexpr int BW_BYTES = BNW * BK * 2;
+  constexpr int STAGE_BYTES = A3_BYTES + BW_BYTES;
   extern __shared__ __attribute__((aligned(16))) char lds3[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR: LDS-DMA targets and the role branch stay scalar
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
-  const int tiles_n = (p.N + BN3 - 1) / BN3;
+  const int tiles_n = (p.N + BNW - 1) / BNW;
   int m0, n0, z0, z1;
   if (ROLE == 2) {
     // conv wgrad: 1-D grid over (n tile, dn, df, m tile), m tile fastest.  The ~31 consecutive ids that the XCD map
@@ -460,10 +463,10 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     z0 = r % 5;   // df
     r /= 5;
     z1 = r % 5;   // dn
-    n0 = (r / 5) * BN3;
+    n0 = (r / 5) * BNW;
   } else {
     m0 = (lid / tiles_n) * BM3;
-    n0 = (lid % tiles_n) * BN3;
+    n0 = (lid % tiles_n) * BNW;
     const int z = blockIdx.y;
     z0 = z / p.nb1;
     z1 = z - z0 * p.nb1;
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int rsub = lane >> 3;
   const int clog = cphys ^ ((((w & 1) << 2) + (lane >> 4)) & 7);
   const int kofs = clog * 8;
-  unsigned aoff[4], boff[5];
+  unsigned aoff[4], boff[NJ];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     long m = (long)m0 + (t * 8 + w) * 8 + rsub;
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     aoff[t] = (unsigned)((row_off(p.am, m) + kofs) * 2);
   }
 #pragma unroll
-  for (int t = 0; t < 5; ++t) {
+  for (int t = 0; t < NJ; ++t) {
     long n = (long)n0 + (t * 8 + w) * 8 + rsub;
     if (n >= p.N) n = p.N - 1;
     boff[t] = (unsigned)((n * p.ldb + kofs) * 2);
@@ -528,21 +531,21 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     const long k0 = -(long)w0, k1 = -(long)w1, k2 = -(long)w2, ka = -(long)adv;
     pa += (BK2 + (ea1 & k0) + (ea2 & k1) + (ea3 & k2)) & ka;
     pb += (BK2 + (eb1 & k0) + (eb2 & k1) + (eb3 & k2)) & ka;
-    char* la = lds3 + buf * STAGE3_BYTES;
+    char* la = lds3 + buf * STAGE_BYTES;
     char* lb = la + A3_BYTES;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < NJ; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][5];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -550,19 +553,19 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int fsw = (lane >> 1) & 7;
   const int fhalf = lane >> 5;
   const int fa = (wm * 64 + frow) * 128;
-  const int fb = A3_BYTES + (wn * 160 + frow) * 128;
+  const int fb = A3_BYTES + (wn * (32 * NJ) + frow) * 128;
 
-  bf16x8 af[2][2], bfr[2][5];
+  bf16x8 af[2][2], bfr[2][NJ];
   auto ldfrag = [&](int set, const char* base, int k4) {
     const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[set][i] = *(const bf16x8*)(base + fa + i * 32 * 128 + ch);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) bfr[set][j] = *(const bf16x8*)(base + fb + j * 32 * 128 + ch);
+    for (int j = 0; j < NJ; ++j) bfr[set][j] = *(const bf16x8*)(base + fb + j * 32 * 128 + ch);
   };
   auto mma = [&](int set) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const char* base = lds3 + (s & 1) * STAGE3_BYTES;
+      const char* base = lds3 + (s & 1) * STAGE_BYTES;
       ldfrag(0, base, 0);
       ldfrag(1, base, 1);
       stage((s + 1) & 1);
@@ -585,21 +588,22 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       ldfrag(1, base, 3);
       mma(0);
       mma(1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+      // issue order: [2(2+NJ) reads] [NJ x (2 MFMA, 1 DMA)] [2+NJ reads] [4 x (2 MFMA, 1 DMA)] [rest of mma(1)] [2+NJ reads] [4NJ MFMA]
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
 #pragma unroll
-      for (int g = 0; g < 5; ++g) {
+      for (int g = 0; g < NJ; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
+      if (NJ > 4) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
     }
   } else {
     // ---- group B (the second wave of every SIMD) runs HALF A K STEP BEHIND: it enters each step with the fragments of
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const char* base = lds3 + (s & 1) * STAGE3_BYTES;
+      const char* base = lds3 + (s & 1) * STAGE_BYTES;
       stage((s + 1) & 1);
       mma(0);                 // previous tile, K16 blocks 2 and 3
       mma(1);
@@ -631,160 +635,29 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       mma(1);
       ldfrag(1, base, 3);
 #pragma unroll
-      for (int g = 0; g < 9; ++g) {
+      for (int g = 0; g < 4 + NJ; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+      if (NJ > 4) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
     }
     mma(0);
     mma(1);
   }
-  const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BN3) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
+  const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BNW) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
   if (vec_ok) {
     __syncthreads();   // every wave is done with the operand stages: reuse the LDS as per-wave output staging
-    gemm_epilogue_lds_bf16<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane, lds3 + w * (32 * EPI_ROWB(5) + 256));
+    gemm_epilogue_lds_bf16<NJ>(p, acc, (long)m0 + wm * 64, n0 + wn * (32 * NJ), coff, lane, lds3 + w * (32 * EPI_ROWB(NJ) + 256));
   } else {
-    gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
+    gemm_epilogue<NJ>(p, acc, (long)m0 + wm * 64, n0 + wn * (32 * NJ), coff, lane);
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Deep-prefetch form of the 256 x 320 kernel: K step 32, FOUR 36-KiB LDS slots used as a ring.  The LDS-DMA of
-// tiles s+1 and s+2 stays in flight across the barrier of step s (counted s_waitcnt vmcnt, raw s_barrier) and the
-// DMA of tile s+3 is launched right after it, so a loaded-memory-system latency of 2-3 K steps is hidden.
-// LDS rows are 64 B (4 chunks of 16 B): physical chunk = logical ^ ((row >> 2) & 3) -> conflict-free ds_read_b128.
-// Per K step a wave issues 2 (A) + 3|2 (B) DMA pieces, 14 ds_read_b128 and 20 MFMAs.
-// ------------------------------------------------------------------------------------------------
-#define BK4 32
-#define A4_BYTES (BM3 * BK4 * 2)  // 16 KiB
-#define B4_BYTES (BN3 * BK4 * 2)  // 20 KiB
-#define SLOT4_BYTES (A4_BYTES + B4_BYTES)
-#define NSLOT4 4
-
-template <int ROLE>
-__global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320r_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char lds4[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
-  const int tiles_n = (p.N + BN3 - 1) / BN3;
-  const int m0 = (lid / tiles_n) * BM3, n0 = (lid % tiles_n) * BN3;
-  const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
-  const char* A = (const char*)(p.A + z0 * p.sa0 + z1 * p.sa1);
-  const char* B = (const char*)(p.B + z0 * p.sb0 + z1 * p.sb1);
-  const long coff = z0 * p.sc0 + z1 * p.sc1;
-
-  const int rsub = lane >> 2;                          // row inside a 16-row DMA piece
-  const int kofs = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;  // logical k chunk fetched by this lane
-  const bool b3 = w < 4;                               // waves 0-3 move three B pieces per tile, waves 4-7 two
-  unsigned aoff[2], boff[3];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    long m = (long)m0 + (t * 8 + w) * 16 + rsub;
-    if (m >= p.M) m = p.M - 1;
-    aoff[t] = (unsigned)((row_off(p.am, m) + kofs) * 2);
-  }
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    long n = (long)n0 + (t * 8 + w) * 16 + rsub;
-    if (n >= p.N) n = p.N - 1;
-    boff[t] = (unsigned)((n * p.ldb + kofs) * 2);
-  }
-  const int nsteps = p.nseg * (p.seglen / BK4);
-
-  int st_hi = 0, st_mid = 0, st_lo = 0, st_kk = 0;
-  auto stage = [&](int slot) {
-    const char* sa = A + (p.a_seg0 + st_hi * p.a_seg_s0 + st_mid * p.a_seg_s1 + st_lo * p.a_seg_s2 + st_kk) * 2;
-    const char* sb = B + (p.b_seg0 + st_hi * p.b_seg_s0 + st_mid * p.b_seg_s1 + st_lo * p.b_seg_s2 + st_kk) * 2;
-    st_kk += BK4;
-    if (st_kk >= p.seglen) {
-      st_kk = 0;
-      if (++st_lo == p.seg_div) {
-        st_lo = 0;
-        if (++st_mid == p.seg_div_mid) {
-          st_mid = 0;
-          ++st_hi;
-        }
-      }
-    }
-    char* la = lds4 + slot * SLOT4_BYTES;
-    char* lb = la + A4_BYTES;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
-    if (b3) __builtin_amdgcn_global_load_lds((const void*)(sb + boff[2]), (lds_ptr_t)(lb + (16 + w) * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[2][5];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int frow = lane & 31;
-  const int fsw = (lane >> 2) & 3;
-  const int fhalf = lane >> 5;
-  const int fa = (wm * 64 + frow) * 64;
-  const int fb = A4_BYTES + (wn * 160 + frow) * 64;
-  const int ch0 = ((0 + fhalf) ^ fsw) << 4, ch1 = ((2 + fhalf) ^ fsw) << 4;
-
-  // prologue: tiles 0..2 in flight
-  stage(0);
-  if (nsteps > 1) stage(1);
-  if (nsteps > 2) stage(2);
-  int slot = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    // tile s must have landed; later tiles (5 or 4 pieces each for this wave) may stay in flight
-    const int ahead = nsteps - 1 - s;   // tiles issued after tile s
-    if (ahead >= 2) {
-      if (b3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (ahead == 1) {
-      if (b3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (s + 3 < nsteps) stage((slot + 3) & 3);
-    const char* la = lds4 + slot * SLOT4_BYTES + fa;
-    const char* lb = lds4 + slot * SLOT4_BYTES + fb;
-    bf16x8 af[2][2], bfr[2][5];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[0][i] = *(const bf16x8*)(la + i * 32 * 64 + ch0);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) bfr[0][j] = *(const bf16x8*)(lb + j * 32 * 64 + ch0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[1][i] = *(const bf16x8*)(la + i * 32 * 64 + ch1);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) bfr[1][j] = *(const bf16x8*)(lb + j * 32 * 64 + ch1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kb][i], bfr[kb][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-    slot = (slot + 1) & 3;
-  }
-  gemm_epilogue<5>(p, acc, (long)m0 + wm * 64, n0 + wn * 160, coff, lane);
-}
 
 
 static long row_off_host(const RowMap& r, long m) {
@@ -835,36 +708,33 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
     static bool attr3_done = false;
     if (!attr3_done) {
-      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
-      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
-      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
       attr3_done = true;
     }
     dim3 grid3((unsigned)tiles320, d->nbatch, 1);
-    if (variant == 3200) {  // DFOLD_GEMM_VARIANT=3200: 4-slot ring, K step 32 (measured slower than the 2-stage K-64 form)
-      static bool attr4_done = false;
-      if (!attr4_done) {
-        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
-        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
-        hipFuncSetAttribute((const void*)dfold_mfma_gemm320r_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT4 * SLOT4_BYTES);
-        attr4_done = true;
-      }
-      const size_t lds4b = NSLOT4 * SLOT4_BYTES;
-      if (role == 1)
-        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<1>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
-      else if (role == 2)
-        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<2>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
-      else
-        DFOLD_LAUNCH(dfold_mfma_gemm320r_kernel<0>, grid3, dim3(512), lds4b, (hipStream_t)stream, p);
-      return dfold_check_launch();
-    }
     const size_t lds = 2 * STAGE3_BYTES;
     if (role == 1)
-      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<1>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+      DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);
     else if (role == 2)
-      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<2>, dim3((unsigned)(tiles320 * 25), 1, 1), dim3(512), lds, (hipStream_t)stream, p);
+      DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<2, 5>), dim3((unsigned)(tiles320 * 25), 1, 1), dim3(512), lds, (hipStream_t)stream, p);
     else
-      DFOLD_LAUNCH(dfold_mfma_gemm320_kernel<0>, grid3, dim3(512), lds, (hipStream_t)stream, p);
+      DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<0, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);
+    return dfold_check_launch();
+  }
+  // 256 x 256 form of the same kernel (wave tile 64 x 128): N a multiple of 256 -- the per-(window,frame,head) attention
+  // products (M = N = 256: one workgroup per batch item reads each operand once) and the 256-wide projections.
+  const long tilesq = (long)((d->M + BM3 - 1) / BM3) * (d->N / 256);
+  if (variant >= 256 && variant != 2560 && variant != 3201 && role == 0 && (d->N % 256) == 0 && (d->seglen % BK) == 0 && d->M >= 256 &&
+      steps >= 2 && tilesq * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
+    static bool attrq_done = false;
+    const size_t lds = 2 * (A3_BYTES + 256 * BK * 2);
+    if (!attrq_done) {
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attrq_done = true;
+    }
+    DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<0, 4>), dim3((unsigned)tilesq, d->nbatch, 1), dim3(512), lds, (hipStream_t)stream, p);
     return dfold_check_launch();
   }
   if (variant >= 256 && d->M >= 1024 && steps >= 4 && tiles256 * d->nbatch >= 192) {

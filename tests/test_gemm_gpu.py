@@ -23,7 +23,8 @@ def _rand_bf16(shape, dev, seed, scale=1.0):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1024, 640, 1280), (77, 6, 1280), (4096, 40, 128),
                                    (16384, 384, 520), (16500, 700, 256),    # 256x128 3-stage kernel
-                                   (32768, 640, 520), (16500, 1280, 192)])  # 256x320 conv-tower kernel
+                                   (32768, 640, 520), (16500, 1280, 192),   # 256x320 conv-tower kernel
+                                   (33000, 256, 192), (16500, 512, 256), (65536, 256, 3072)])  # its 256x256 form
 def test_gemm_plain(dev, M, N, K):
     from dynamicpdb_amd import ops
     a, b = _rand_bf16((M, K), dev, 1), _rand_bf16((N, K), dev, 2)
@@ -58,6 +59,33 @@ def test_gemm_batched_accumulate(dev):
     ops.gemm(a, b, out, M, N, K, a_rows=ops.rows_plain(K), c_rows=ops.rows_plain(N), ldb=K, nbatch=B0 * B1, nb1=B1,
              sa=(B1 * M * K, M * K), sb=(B1 * N * K, N * K), sc=(B1 * M * N, M * N), flags=ops.GEMM_ACCUM, alpha=0.5)
     assert rel_l2(out, 0.5 * ref + 1.0) < 1e-5
+
+
+def test_gemm_attention_batches(dev):
+    """per-(window,frame,head) attention products: M = N = 256, K = 256, strided head-major operands, two-level batch;
+    fp32 output with alpha, bf16 output, and fp32 accumulate (the 256x256 workgroup-per-batch kernel)."""
+    from dynamicpdb_amd import ops
+    BF, H, N, C = 20, 8, 256, 256
+    q, k = _rand_bf16((BF, N, H, C), dev, 21, 0.3), _rand_bf16((BF, N, H, C), dev, 22, 0.3)
+    ref = torch.einsum("bihc,bjhc->bhij", q.double(), k.double())
+    out = torch.empty((BF, H, N, N), dtype=torch.float32, device=dev)
+    kw = dict(a_rows=ops.rows_plain(H * C), c_rows=ops.rows_plain(N), ldb=H * C, nbatch=BF * H, nb1=H,
+              sa=(N * H * C, C), sb=(N * H * C, C), sc=(H * N * N, N * N))
+    ops.gemm(q, k, out, N, N, C, alpha=0.25, **kw)
+    assert rel_l2(out, 0.25 * ref) < 1e-5
+    outb = torch.empty((BF, H, N, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(q, k, outb, N, N, C, **kw)
+    assert rel_l2(outb, ref) < 4e-3
+    ops.gemm(q, k, out, N, N, C, flags=ops.GEMM_ACCUM, **kw)
+    assert rel_l2(out, 1.25 * ref) < 1e-5
+    # ragged M (last 256-row tile partly empty)
+    M2 = 300
+    a2 = _rand_bf16((BF * H, M2, C), dev, 23, 0.3)
+    b2 = _rand_bf16((BF * H, N, C), dev, 24, 0.3)
+    o2 = torch.empty((BF * H, M2, N), dtype=torch.float32, device=dev)
+    ops.gemm(a2, b2, o2, M2, N, C, a_rows=ops.rows_plain(C), c_rows=ops.rows_plain(N), ldb=C, nbatch=BF * H, nb1=1,
+             sa=(M2 * C, 0), sb=(N * C, 0), sc=(M2 * N, 0))
+    assert rel_l2(o2, torch.einsum("bmk,bnk->bmn", a2.double(), b2.double())) < 1e-5
 
 
 def test_splitk_reduce_rows(dev):
