@@ -9,9 +9,8 @@
 //
 // and the matching backward.  Point terms stay in fp32 on the VALU (coordinates are O(100 A); the
 // difference form |q-k|^2 is kept, never the bf16-hostile |q|^2+|k|^2-2qk expansion).  One wave owns
-// one attention row: the row lives in registers, max / sum / dot reductions are wave64 shuffles; the
-// per-(window,frame,head) key/value point tables are staged once per workgroup in LDS (padded rows,
-// conflict free for lane<->j access).
+// one attention row: the row lives in registers, max / sum / dot reductions are wave64 DPP reductions; the
+// per-(window,frame,head) key/value point tables are staged once per workgroup in LDS.
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
 
@@ -19,8 +18,11 @@
 #define IPA_PV 12
 #define KP (IPA_PQ * 3)  // 24 floats per (residue, head)
 #define VP (IPA_PV * 3)  // 36
-#define KPS 25           // padded LDS row strides
-#define VPS 37
+// LDS row strides of the point tables, in floats.  Rows are read as 16-byte vectors (ds_read_b128: 256 B/clk/CU vs
+// 128 for 4-byte reads, a quarter of the instructions); 28 = 4*7 and 36 = 4*9 keep every row 16-byte aligned and, 7 and
+// 9 being odd, spread any 16 lanes with distinct j mod 16 over all 64 banks (conflict free for lane <-> j access).
+#define KPS 28
+#define VPS 36
 #define MAXT 16          // columns per lane (N <= 1024)
 #define ROWS_PER_BLOCK 64   // attention rows per workgroup (16 per wave): amortises the per-block point-table staging
 
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
                                                               const float* __restrict__ mask, const float* __restrict__ hw,
                                                               float* P, bf16_t* __restrict__ Pb, IpaDims d,
                                                               float bias_scale, float inf) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   float* kp = sm;  // [N][KPS]
   const int N = d.N, H = d.H;
   const int bf = blockIdx.z, h = blockIdx.y, b = bf / d.F;
@@ -67,9 +69,10 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
       if (j < N) {
         float d2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < KP; ++c) {
-          const float df = qv[c] - kp[j * KPS + c];
-          d2 += df * df;
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+          const float4 kv = *(const float4*)(kp + j * KPS + 4 * c4);
+          const float d0 = qv[4 * c4] - kv.x, d1 = qv[4 * c4 + 1] - kv.y, d2_ = qv[4 * c4 + 2] - kv.z, d3 = qv[4 * c4 + 3] - kv.w;
+          d2 += d0 * d0 + d1 * d1 + d2_ * d2_ + d3 * d3;
         }
         float v = S[rowS + j] + bias_scale * bias[rowB + j] - 0.5f * hwh * d2;
         v += inf * (mi * mask[(long)bf * N + j] - 1.f);
@@ -115,17 +118,68 @@ extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const fl
 }
 
 // o_pt[b,f,i,h,c] = sum_j P[b,f,h,i,j] * v_pts[b,f,j,h,c]   (c = 36 point components, fp32)
-__global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restrict__ P, const float* __restrict__ v_pts,
-                                                          float* __restrict__ o_pt, IpaDims d, int rows_per_block) {
-  extern __shared__ float sm[];
-  const int N = d.N, H = d.H;
+// A workgroup stages `rows` attention rows of P (pitch N+4) next to the value-point table in LDS; a thread owns a
+// 2-row x 4-component register tile and walks j four at a time: 6 ds_read_b128 feed 32 FMAs (the one-output-per-thread
+// form issued 2 four-byte LDS reads per FMA and ran at the LDS instruction rate).  N % 4 == 0.
+#define OPT_THREADS 192
+__global__ __launch_bounds__(OPT_THREADS) void ipa_opt_fwd_kernel(const float* __restrict__ P, const float* __restrict__ v_pts,
+                                                                  float* __restrict__ o_pt, IpaDims d, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = d.N, H = d.H, NP = N + 4;
   float* vp = sm;             // [N][VPS]
-  float* pt = sm + N * VPS;   // [rows][N]
+  float* pt = sm + N * VPS;   // [rows][NP]
+  const int bf = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * rows_per_block;
+  const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
+  for (int e = threadIdx.x; e < N * (VP / 4); e += OPT_THREADS) {
+    const int j = e / (VP / 4), q = e - j * (VP / 4);
+    *(float4*)(vp + j * VPS + 4 * q) = *(const float4*)(vbase + (long)j * H * VP + 4 * q);
+  }
+  const int rows = min(rows_per_block, N - i0);
+  const float* pbase = P + (((long)bf * H + h) * N + i0) * N;
+  const int n4 = N >> 2;
+  for (int e = threadIdx.x; e < rows_per_block * n4; e += OPT_THREADS) {
+    const int r = e / n4, q = e - r * n4;
+    const float4 v = r < rows ? *(const float4*)(pbase + (long)r * N + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(pt + r * NP + 4 * q) = v;
+  }
+  __syncthreads();
+  const int rg = threadIdx.x / 9, cq = threadIdx.x - rg * 9;
+  if (2 * rg >= rows) return;
+  const float* p0 = pt + (2 * rg) * NP;
+  const float* p1 = p0 + NP;
+  const float* vq = vp + 4 * cq;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll 2
+  for (int j = 0; j < N; j += 4) {
+    const float4 x0 = *(const float4*)(p0 + j), x1 = *(const float4*)(p1 + j);
+    const float4 v0 = *(const float4*)(vq + (j + 0) * VPS), v1 = *(const float4*)(vq + (j + 1) * VPS),
+                 v2 = *(const float4*)(vq + (j + 2) * VPS), v3 = *(const float4*)(vq + (j + 3) * VPS);
+    a0.x += x0.x * v0.x + x0.y * v1.x + x0.z * v2.x + x0.w * v3.x;
+    a0.y += x0.x * v0.y + x0.y * v1.y + x0.z * v2.y + x0.w * v3.y;
+    a0.z += x0.x * v0.z + x0.y * v1.z + x0.z * v2.z + x0.w * v3.z;
+    a0.w += x0.x * v0.w + x0.y * v1.w + x0.z * v2.w + x0.w * v3.w;
+    a1.x += x1.x * v0.x + x1.y * v1.x + x1.z * v2.x + x1.w * v3.x;
+    a1.y += x1.x * v0.y + x1.y * v1.y + x1.z * v2.y + x1.w * v3.y;
+    a1.z += x1.x * v0.z + x1.y * v1.z + x1.z * v2.z + x1.w * v3.z;
+    a1.w += x1.x * v0.w + x1.y * v1.w + x1.z * v2.w + x1.w * v3.w;
+  }
+  const int i = i0 + 2 * rg;
+  *(float4*)(o_pt + (((long)bf * N + i) * H + h) * VP + 4 * cq) = a0;
+  if (2 * rg + 1 < rows) *(float4*)(o_pt + (((long)bf * N + i + 1) * H + h) * VP + 4 * cq) = a1;
+}
+
+// scalar form (any N): one output per thread, P rows and the value-point table in LDS
+__global__ __launch_bounds__(256) void ipa_opt_fwd_scalar_kernel(const float* __restrict__ P, const float* __restrict__ v_pts,
+                                                                 float* __restrict__ o_pt, IpaDims d, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = d.N, H = d.H;
+  float* vp = sm;             // [N][VPS + 1]
+  float* pt = sm + N * (VPS + 1);   // [rows][N]
   const int bf = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * rows_per_block;
   const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
   for (int e = threadIdx.x; e < N * VP; e += 256) {
     const int j = e / VP, c = e - j * VP;
-    vp[j * VPS + c] = vbase[(long)j * H * VP + c];
+    vp[j * (VPS + 1) + c] = vbase[(long)j * H * VP + c];
   }
   const int rows = min(rows_per_block, N - i0);
   const float* pbase = P + (((long)bf * H + h) * N + i0) * N;
@@ -134,7 +188,7 @@ __global__ __launch_bounds__(256) void ipa_opt_fwd_kernel(const float* __restric
   for (int o = threadIdx.x; o < rows * VP; o += 256) {
     const int r = o / VP, c = o - r * VP;
     float acc = 0.f;
-    for (int j = 0; j < N; ++j) acc += pt[r * N + j] * vp[j * VPS + c];
+    for (int j = 0; j < N; ++j) acc += pt[r * N + j] * vp[j * (VPS + 1) + c];
     o_pt[(((long)bf * N + i0 + r) * H + h) * VP + c] = acc;
   }
 }
@@ -143,15 +197,29 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
                                  void* stream) {
   if (!P || !v_pts || !o_pt || B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  // rows per block: as many as fit next to the value-point table in ~76 KiB (two blocks per CU), at most 64
-  int rows = (int)((76 * 1024 - (long)N * VPS * 4) / ((long)N * 4));
-  if (rows > 64) rows = 64;
-  if (rows < 4) rows = (int)((160 * 1024 - (long)N * VPS * 4) / ((long)N * 4));
-  if (rows < 1) return DFOLD_EINVAL;
-  const size_t lds = ((size_t)N * VPS + (size_t)rows * N) * sizeof(float);
-  dim3 grid((N + rows - 1) / rows, H, B * F);
+  if ((N & 3) || (((uintptr_t)P | (uintptr_t)v_pts | (uintptr_t)o_pt) & 15)) {
+    int rows = (int)((76 * 1024 - (long)N * (VPS + 1) * 4) / ((long)N * 4));
+    if (rows > 64) rows = 64;
+    if (rows < 4) rows = (int)((160 * 1024 - (long)N * (VPS + 1) * 4) / ((long)N * 4));
+    if (rows < 1) return DFOLD_EINVAL;
+    const size_t lds = ((size_t)N * (VPS + 1) + (size_t)rows * N) * sizeof(float);
+    hipFuncSetAttribute((const void*)ipa_opt_fwd_scalar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_LAUNCH(ipa_opt_fwd_scalar_kernel, dim3((N + rows - 1) / rows, H, B * F), dim3(256), lds, (hipStream_t)stream, P, v_pts,
+                 o_pt, d, rows);
+    return dfold_check_launch();
+  }
+  // rows per block: up to 32 (16 row pairs x 9 column quads = 144 of the 192 threads), fewer when the value-point
+  // table of a long chain leaves less LDS; two blocks per CU at N <= 256 so that staging overlaps compute
+  const long table = (long)N * VPS * 4, row_bytes = (long)(N + 4) * 4;
+  long rows = (78 * 1024 - table) / row_bytes;
+  if (rows < 8) rows = (160 * 1024 - table) / row_bytes;
+  if (rows > 32) rows = 32;
+  rows &= ~1L;
+  if (rows < 2) return DFOLD_EINVAL;
+  const size_t lds = (size_t)(table + rows * row_bytes);
+  dim3 grid((unsigned)((N + rows - 1) / rows), H, B * F);
   hipFuncSetAttribute((const void*)ipa_opt_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, v_pts, o_pt, d, rows);
+  DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(OPT_THREADS), lds, (hipStream_t)stream, P, v_pts, o_pt, d, (int)rows);
   return dfold_check_launch();
 }
 
@@ -173,7 +241,7 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
                                                               IpaDims d) {
   // 8 waves share the per-(window,frame,head) key/value point tables AND the block's 64 query rows' point vectors in
   // LDS (no per-row uniform global loads, ~100 VGPRs -> 4 waves per SIMD hide the row-serial latency chain).
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = d.N, H = d.H;
   float* kp = sm;                          // [N][KPS]
   float* vp = kp + N * KPS;                // [N][VPS]
@@ -220,7 +288,11 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
       if (j < N) {
         float g = dP[row + j];
 #pragma unroll
-        for (int c = 0; c < VP; ++c) g += dov[c] * vp[j * VPS + c];
+        for (int c4 = 0; c4 < VP / 4; ++c4) {
+          const float4 vv = *(const float4*)(vp + j * VPS + 4 * c4);
+          const float4 dd = *(const float4*)(dov + 4 * c4);
+          g += dd.x * vv.x + dd.y * vv.y + dd.z * vv.z + dd.w * vv.w;
+        }
         pv[t] = P[row + j];
         gv[t] = g;
         dot += pv[t] * g;
@@ -239,10 +311,15 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
         dSb[row + j] = f2bf(ds);
         float d2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < KP; ++c) {
-          const float df = qv[c] - kp[j * KPS + c];
-          dq[c] += ds * df;
-          d2 += df * df;
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+          const float4 kv = *(const float4*)(kp + j * KPS + 4 * c4);
+          const float4 qq = *(const float4*)(qv + 4 * c4);
+          const float df[4] = {qq.x - kv.x, qq.y - kv.y, qq.z - kv.z, qq.w - kv.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            dq[4 * c4 + u] += ds * df[u];
+            d2 += df[u] * df[u];
+          }
         }
         dhw_acc += -0.5f * ds * d2;
       }

@@ -30,7 +30,26 @@ def _ref_core(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw, H, C):
     return o, o_pt, o_pair
 
 
-@pytest.mark.parametrize("B,F,N", [(2, 3, 24), (1, 2, 72)])
+@pytest.mark.parametrize("N", [22, 64, 264, 516])
+def test_ipa_opt_fwd_direct(N):
+    """o_pt = P @ v_pts through the C ABI: register-tiled 16-byte kernel (N % 4 == 0, one and several row blocks, ragged
+    last block) and the scalar form (N % 4 != 0)."""
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device("cuda:0")
+    B, F, H = 1, 2, 3
+    gen = torch.Generator(device="cpu").manual_seed(N)
+    P = torch.softmax(torch.randn(B, F, H, N, N, generator=gen), -1).to(dev).contiguous()
+    v = (torch.randn(B, F, N, H, 36, generator=gen) * 5).to(dev).contiguous()
+    out = torch.full((B, F, N, H, 36), float("nan"), device=dev)
+    _lib.check(_lib.lib().dfold_ipa_opt_fwd(_p(P), _p(v), _p(out), c_int32(B), c_int32(F), c_int32(N), c_int32(H), _lib.stream()),
+               "dfold_ipa_opt_fwd")
+    ref = torch.einsum("bfhij,bfjhc->bfihc", P.double(), v.double())
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("B,F,N", [(2, 3, 24), (1, 2, 72), (1, 1, 328)])
 def test_ipa_core_fwd_bwd(B, F, N):
     from dynamicpdb_amd.model import functional as Fm
     dev = torch.device("cuda:0")
