@@ -51,8 +51,12 @@ class Trainer:
     """update_fn of the reference (zero_grad, loss_fn, backward, optimizer step) for one rank's shard of windows,
     with gradient averaging across ranks.  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
 
-    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=256 << 20):
+    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=256 << 20, last_frame_only=True):
+        """last_frame_only: run the model in its training-step mode (the live loss terms of loss_fn and the frame
+        updates read the last frame of each window only, so the conv tower evaluates just that frame's dependency
+        cone; identical loss and gradients, see DFOLDIpaScore.forward).  False = every frame, as the reference."""
         self.model = model
+        self.last_frame_only = last_frame_only
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
         self.loss_kwargs = loss_kwargs or {}
@@ -93,7 +97,7 @@ class Trainer:
 
     def update_fn(self, batch, step_optimizer=True):
         self.opt.zero_grad(set_to_none=True)
-        out = self.model(batch)
+        out = self.model(batch, last_frame_only=self.last_frame_only)
         loss, aux = loss_fn(out, batch, **self.loss_kwargs)
         loss.backward()
         self.allreduce_grads()

@@ -44,7 +44,7 @@ class FullScoreNetwork(nn.Module):
 
     _PER_WINDOW = ('node_repr', 'edge_repr', 't')
 
-    def forward(self, input_feats, drop_ref=False):
+    def forward(self, input_feats, drop_ref=False, last_frame_only=False):
         batched = input_feats['rigids_0'].dim() == 4
         feats = input_feats if batched else {k: (v[None] if torch.is_tensor(v) and k not in ('t',) else v)
                                              for k, v in input_feats.items()}
@@ -62,7 +62,7 @@ class FullScoreNetwork(nn.Module):
         exp_edge = F_.linear(ops.cast_bf16(edge_repr).view(B * N * N, -1), self.expand_edge.weight,
                              self.expand_edge.bias).view(B, N, N, -1)                                    # :474
         feats['expand_node_repr'], feats['expand_edge_repr'] = exp_node, exp_edge
-        model_out = self.score_model(None, None, feats, drop_ref=drop_ref)
+        model_out = self.score_model(None, None, feats, drop_ref=drop_ref, last_frame_only=last_frame_only)
         gt_angles = feats['torsion_angles_sin_cos'].to(torch.float32)
         fm = 1 - fixed_mask[..., None, None]
         angles_pred = self._apply_mask(model_out['angles'], gt_angles, fm)

@@ -204,29 +204,35 @@ class ConvTowerFn(Function):
     fp32) and handed to autograd once, by the application whose backward runs last."""
 
     @staticmethod
-    def forward(ctx, x, tower, *params):
+    def forward(ctx, x, tower, last_frame_only, *params):
+        """last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
+        dependency cone of that frame (ops.ConvTower.cone); the other output frames are returned as zeros and the
+        incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller)."""
         Wn, F, N, C = x.shape
         g = ops.Grid(Wn, F, N, x.device)
         tower.refresh()
         h0 = g.alloc(C)
         g.interior(h0).copy_(x)
-        h4, saved = tower.forward(g, h0)
-        ctx.tower, ctx.g, ctx.saved = tower, g, saved
+        h4, saved = tower.forward(g, h0, last_frame_only=last_frame_only)
+        ctx.tower, ctx.g, ctx.saved, ctx.last = tower, g, saved, last_frame_only
         tower.pending += 1
         return g.interior(h4).contiguous()
 
     @staticmethod
     def backward(ctx, gy):
         tower, g = ctx.tower, ctx.g
-        gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]))
-        g.interior(gt).copy_(gy)
-        g0 = tower.backward(g, ctx.saved, gt)
+        gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]), zero=ctx.last)
+        if ctx.last:
+            g.interior(gt)[:, -1:].copy_(gy[:, -1:])
+        else:
+            g.interior(gt).copy_(gy)
+        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last)
         ctx.saved = None
         tower.pending -= 1
         grads = [None] * (2 * len(tower.weights))
         if tower.pending == 0:
             grads = tower.collect_grads()
-        return (g.interior(g0).contiguous(), None, *grads)
+        return (g.interior(g0).contiguous(), None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

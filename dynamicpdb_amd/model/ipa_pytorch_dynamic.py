@@ -69,11 +69,11 @@ class ConvNet(nn.Module):
             self._tower = ops.ConvTower(ws, bs)
         return self._tower
 
-    def run(self, x):
-        """x bf16 [W,F,N,C] -> bf16 [W,F,N,C]"""
+    def run(self, x, last_frame_only=False):
+        """x bf16 [W,F,N,C] -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode)."""
         ws, bs = self._params()
         inter = [p for pair in zip(ws, bs) for p in pair]
-        return F_.ConvTowerFn.apply(x, self.tower(), *inter)
+        return F_.ConvTowerFn.apply(x, self.tower(), bool(last_frame_only), *inter)
 
     def forward(self, x):
         _require_cuda(x)
@@ -223,8 +223,12 @@ class DFOLDIpaScore(nn.Module):
         """cat([x[:-1], x[-2:-1]]) along the frame axis (axis 1 of the batched layout) (:819,822,826,842)"""
         return torch.cat([x[:, :-1], x[:, -2:-1]], 1)
 
-    def forward(self, init_node_embed, edge_embed, input_feats, drop_ref=False):
-        """Batched mirror of the reference forward (:798-907).  All per-window tensors in `input_feats` carry a
+    def forward(self, init_node_embed, edge_embed, input_feats, drop_ref=False, last_frame_only=False):
+        """Batched mirror of the reference forward (:798-907).  last_frame_only (engine extension, default off): the
+        caller only consumes frame F-1 of the per-frame outputs -- true for the training step, whose live loss terms
+        and frame updates read the last frame alone (:869, train_DFOLD_dynamics.py:1219-1340) -- so the shared conv
+        tower evaluates only the dependency cone of that frame (4x less conv work at F=32; loss and gradients are
+        unchanged, outputs of the other frames ('angles', 'rigid_update') are then NOT the reference's).  All per-window tensors in `input_feats` carry a
         leading window axis here ([B,F,N,..], node/edge repr [B,N,..], t [B]); FullScoreNetwork adds it for
         reference-shaped inputs.  init_node_embed / edge_embed are ignored exactly like the reference (:829-834)."""
         f32 = torch.float32
@@ -252,7 +256,7 @@ class DFOLDIpaScore(nn.Module):
             feats = ipa.features(node_embed, edge, curr_rigids, node_mask)
             ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
             node_feat = torch.cat([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], dim=-1)
-            node_feat = conv.run(node_feat)
+            node_feat = conv.run(node_feat, last_frame_only)
             rigid_update = self.trunk[f'bb_update_{b}'](node_feat)
             rigid_update = torch.cat([rigid_update[:, :-1] * 0.0, rigid_update[:, -1:]], 1)      # :869
             curr_rigids = G.compose_q_update_vec(curr_rigids, rigid_update, diffuse_mask[..., None])

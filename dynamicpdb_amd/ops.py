@@ -192,28 +192,32 @@ class Grid:
     def interior(self, t):
         return t[:, 2:-2, 2:-2, :]
 
-    def rows_in(self, C):          # conv input rows: top-left corner of the 5x5 window
-        return rows_grid(C, self.N, self.F, self.Fp, self.Wp, 0)
+    # Row maps take an optional frame sub-range [f_lo, f_lo + nf): GEMM row m <-> (window, frame f_lo + f', residue).
+    def rows_in(self, C, f_lo=0, nf=None):          # conv input rows: top-left corner of the 5x5 window
+        return rows_grid(C, self.N, self.F if nf is None else nf, self.Fp, self.Wp, f_lo * self.Wp * C)
 
-    def rows_center(self, C, ch_off=0):  # the cell itself
-        return rows_grid(C, self.N, self.F, self.Fp, self.Wp, (2 * self.Wp + 2) * C + ch_off)
+    def rows_center(self, C, ch_off=0, f_lo=0, nf=None):  # the cell itself
+        return rows_grid(C, self.N, self.F if nf is None else nf, self.Fp, self.Wp,
+                         ((2 + f_lo) * self.Wp + 2) * C + ch_off)
 
     def tap_offsets(self, C, ck=64):
         """K segment (chunk, df, dn) of the implicit GEMM: ck channels starting at chunk*ck of the cell at (+df rows,
         +dn columns).  Channel chunk OUTERMOST: the 25 shifted re-reads of one activation chunk stay in the XCD's L2."""
         return (0, ck, self.Wp * C, C)
 
-    def seg_shifted(self):
-        """wgrad K segment = window w of a transposed [c][w][f'][n] copy, starting at padded frame row 0 ..."""
-        return (0, self.Fp * self.N, 0)
+    def seg_shifted(self, f_lo=0):
+        """wgrad K segment = window w of a transposed [c][w][f'][n] copy, starting at padded frame row f_lo ..."""
+        return (f_lo * self.N, self.Fp * self.N, 0)
 
-    def seg_center(self):
-        """... or at padded frame row 2 (the un-shifted operand)."""
-        return (2 * self.N, self.Fp * self.N, 0)
+    def seg_center(self, f_lo=0):
+        """... or at padded frame row 2 + f_lo (the un-shifted operand)."""
+        return ((2 + f_lo) * self.N, self.Fp * self.N, 0)
 
 
-def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None):
-    """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO]."""
+def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
+                f_lo=0, nf=None):
+    """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO].
+    f_lo / nf: only the output cells of frames [f_lo, f_lo + nf) are computed (they read x frames f_lo-2 .. f_lo+nf+1)."""
     CO, _, CI = wf.shape
     flags = GEMM_RELU if relu else 0
     R = None
@@ -226,8 +230,9 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     if pre_resid_out is not None:
         C2, R2 = pre_resid_out, None
     ck = 64 if CI % 64 == 0 else CI            # K chunk per segment (one MFMA K step when channels allow)
-    return gemm(x, wf, out, g.M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI), c_rows=g.rows_center(CO),
-                ldb=25 * CI, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
+    nf = g.F - f_lo if nf is None else nf
+    return gemm(x, wf, out, g.Wn * nf * g.N, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
+                c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
                 seg_div=5, seg_div_mid=5, flags=flags)
 
 
@@ -238,27 +243,34 @@ def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None):
     return out
 
 
-def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None):
+def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf=None):
     """dW (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.  The narrower operand gets the 5
     column-shifted transposed copies, the wider one a single copy; the WIDER operand is always the GEMM's M side
     (1280 = 5 x 256 rows, the narrow 640 = 2 x 320 columns: both tile exactly), so
       CI <= CO: dwg fp32 [CO][25][CI]            (gy rows x shifted-x columns)
       CI >  CO: dwg fp32 [CI][25][CO] TRANSPOSED (x rows x shifted-gy columns, taps flipped).
-    bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass)."""
+    bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass).
+    f_lo / nf: gy is zero outside frames [f_lo, f_lo + nf): only those cells enter the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
-    plane, N, F = g.plane, g.N, g.F
+    plane, N = g.plane, g.N
+    F = g.F - f_lo if nf is None else nf
     fl = GEMM_ACCUM if accumulate else 0
     if CI <= CO:   # shift x
         tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)))
         tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)), colsum=bias_grad)
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
-             a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CI * plane),
+             a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
     else:          # shift gy, taps flipped, transposed accumulator
+        # here the reduction runs over the cells of x (the un-shifted operand): a cell pairs with gy up to 2 frames away,
+        # so the x range is the gy range widened by 2 frames on both sides (clipped to the grid)
+        lo = max(0, f_lo - 2)
+        F = min(g.F, f_lo + F + 2) - lo
+        f_lo = lo
         tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)), colsum=bias_grad)
         tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
         gemm(tU, tS, dwg, CI, CO, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CO), ldb=plane,
-             a_seg=g.seg_center(), b_seg=g.seg_shifted(), nbatch=25, nb1=5, sb=(N, CO * plane),
+             a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CO * plane),
              sc=(-5 * CO, -CO), c_off=24 * CO, flags=fl)
     return dwg
 
@@ -330,43 +342,66 @@ class ConvTower:
         for t in self.dwg + self.db:
             t.zero_()
 
-    def forward(self, g, h0, save=True):
-        """h0: padded grid [Wn,Fp,Wp,C] bf16.  Returns (h4, saved)."""
+    @staticmethod
+    def cone(F, i):
+        """Frame ranges of residual block i (0..3) when only the LAST frame of the tower output is consumed (training:
+        the frame update and every live loss term read frame F-1 only, reference ipa_pytorch_dynamic.py:869 and
+        train_DFOLD_dynamics.py:1219-1340).  Each 5x5 conv widens the dependency cone by 2 frames, so block i must
+        produce its output on the last 4*(3-i)+1 frames and its inner activation on 2 more; everything below the cone
+        has exactly zero gradient and no influence on the loss.  Returns ((f_lo1, nf1), (f_lo2, nf2))."""
+        r = 4 * (3 - i)
+        nf1, nf2 = min(F, r + 3), min(F, r + 1)
+        return (F - nf1, nf1), (F - nf2, nf2)
+
+    def forward(self, g, h0, save=True, last_frame_only=False):
+        """h0: padded grid [Wn,Fp,Wp,C] bf16.  Returns (h4, saved).  last_frame_only: compute the dependency cone of
+        the last output frame only (h4 is then valid on frame F-1 alone, zero elsewhere)."""
         C = h0.shape[-1]
         saved = [h0]
         h = h0
         for i in range(4):
+            (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else ((0, g.F), (0, g.F))
             u = g.alloc(C // 2)
-            conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True)
+            conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True, f_lo=l1, nf=n1)
             hn, v = g.alloc(C), g.alloc(C)
-            conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v)
+            conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v,
+                        f_lo=l2, nf=n2)
             saved += [u, v, hn]
             h = hn
         return h, saved
 
-    def backward(self, g, saved, gtop):
-        """gtop: dL/dh4 on the padded grid (border zero).  Accumulates dwg/db, returns dL/dh0."""
+    def backward(self, g, saved, gtop, last_frame_only=False):
+        """gtop: dL/dh4 on the padded grid (border zero).  Accumulates dwg/db, returns dL/dh0.
+        last_frame_only: gtop is nonzero on frame F-1 only (see cone()); gradients are propagated inside the cone,
+        where they are the only nonzero ones.  The scratch grids are re-zeroed first: below the (growing) frame range of
+        each step they must read as the zeros the full computation would produce, not as a previous call's values."""
         C = gtop.shape[-1]
         gi = gtop
         ws = self.ws
+        full = ((0, g.F), (0, g.F))
+        if last_frame_only:
+            for name, ch in (("du", C // 2), ("g0", C), ("g1", C)):
+                ws.get(name, (g.Wn, g.Fp, g.Wp, ch), zero=True)
         dv = relu_mask_bf16(gi, saved[3 * 3 + 2], ws.get("dv", tuple(gtop.shape)))
         for i in (3, 2, 1, 0):
             hprev, u, v = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
-            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws, bias_grad=self.db[2 * i + 1])
+            (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else full
+            (_, _), (l0, n0) = self.cone(g.F, i - 1) if (last_frame_only and i > 0) else full   # range of dL/d(block input)
+            if last_frame_only and i == 0:
+                n0 = min(g.F, 17)
+                l0 = g.F - n0
+            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws, bias_grad=self.db[2 * i + 1], f_lo=l2, nf=n2)
             du = ws.get("du", tuple(u.shape))
-            self._zero_border_once(du, "du")
-            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u)
-            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws, bias_grad=self.db[2 * i])
+            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1)
+            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws, bias_grad=self.db[2 * i], f_lo=l1, nf=n1)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
-                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2])
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2],
+                            f_lo=l0, nf=n0)
             else:
-                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi)
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0)
             gi = gn
         return gi
-
-    def _zero_border_once(self, t, name):
-        pass  # workspace buffers are allocated zeroed and kernels only ever write interior cells
 
     def finalize_grads(self):
         """GEMM-layout fp32 accumulators -> .grad of the reference-layout parameters."""

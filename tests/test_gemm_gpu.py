@@ -247,6 +247,42 @@ def test_conv_tower_fwd_bwd_vs_torch(dev, Wn, F, N, C):
         assert rel_l2(ws[i].grad, wr[i].grad) < 0.15, i     # 96-term sums, mask flips dominate at this toy size
 
 
+def test_conv_tower_last_frame_cone(dev):
+    """ConvTower in last-frame mode: output frame F-1 and all gradients equal the full evaluation when the incoming
+    gradient lives on frame F-1 only; run twice so that stale scratch contents of a previous (wider) call are covered."""
+    from dynamicpdb_amd import ops
+    Wn, F, N, C = 2, 20, 16, 128
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    ws = [(torch.randn(co, ci, 5, 5, generator=gen) * (2.0 / (25 * ci)) ** 0.5).to(dev)
+          for _ in range(4) for (co, ci) in ((C // 2, C), (C, C // 2))]
+    bs = [(torch.randn(w.shape[0], generator=gen) * 0.1).to(dev) for w in ws]
+    x = torch.randn(Wn, F, N, C, generator=gen).to(dev).to(torch.bfloat16)
+    gy = torch.zeros(Wn, F, N, C, device=dev, dtype=torch.bfloat16)
+    gy[:, -1] = torch.randn(Wn, N, C, generator=gen).to(dev).to(torch.bfloat16)
+    g = ops.Grid(Wn, F, N, dev)
+    res = {}
+    for mode in (False, True, False, True):
+        tower = res.get("tower") or ops.ConvTower(ws, bs)
+        res["tower"] = tower
+        tower.pack()
+        tower.zero_grad()
+        h0 = g.alloc(C)
+        g.interior(h0).copy_(x)
+        h4, saved = tower.forward(g, h0, last_frame_only=mode)
+        gt = g.alloc(C)
+        g.interior(gt).copy_(gy)
+        g0 = tower.backward(g, saved, gt, last_frame_only=mode)
+        res[mode] = (g.interior(h4).float().clone(), g.interior(g0).float().clone(), [d.clone() for d in tower.dwg],
+                     [d.clone() for d in tower.db])
+    full, last = res[False], res[True]
+    assert rel_l2(last[0][:, -1], full[0][:, -1]) < 2e-3
+    assert float(last[0][:, : F - 1].abs().max()) == 0.0               # frames below the cone are not produced
+    assert rel_l2(last[1], full[1]) < 5e-3                               # dL/dx: nonzero on the last 17 frames only
+    assert float(full[1][:, : F - 17].abs().max()) == 0.0
+    for a, b in zip(last[2] + last[3], full[2] + full[3]):
+        assert rel_l2(a, b) < 5e-3
+
+
 def test_convnet_vs_oracle_golden(dev):
     """ConvNet on the reference-minted capture (F=3, N=16, C=1280; tests/golden/network_F3_N16.npz)."""
     from dynamicpdb_amd import ops, synthetic

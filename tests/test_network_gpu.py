@@ -144,3 +144,33 @@ def test_fresh_seed_vs_oracle():
     assert max_abs(out["atom37"], ref["atom37"]) < 0.3
     assert max_abs(out["rigids"][..., 4:], ref["rigids"][..., 4:]) < 5e-3
     assert torch.equal(out["atom37"].cpu() == 0, ref["atom37"] == 0)    # integer gathers / masks bit-exact
+
+
+def test_last_frame_only_training_mode_equals_full():
+    """Training-step mode (conv tower evaluated on the dependency cone of the last frame only) vs every frame: same
+    last-frame outputs, same loss, same parameter gradients (up to bf16 re-rounding where a different tile kernel is
+    picked for the smaller row count).  F = 24 > 17 so that every block's cone is a proper subset of the frames."""
+    from dynamicpdb_amd import experiment, synthetic
+    dev = torch.device("cuda:0")
+    F, N, B = 24, 16, 2
+    model, diffuser = _build(F, 5, dev)
+    ws = [synthetic.synthetic_window(30 + i, F, N, t=0.4 + 0.3 * i, diffuser=diffuser) for i in range(B)]
+    batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0]}
+    batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
+    res = {}
+    for mode in (False, True):
+        model.zero_grad(set_to_none=True)
+        out = model({k: v.clone() for k, v in batch.items()}, last_frame_only=mode)
+        loss, aux = experiment.loss_fn(out, batch)
+        loss.backward()
+        res[mode] = (out, float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    full, last = res[False], res[True]
+    assert abs(full[1] - last[1]) < 1e-3 * abs(full[1])
+    for k in ("angles", "unorm_angles", "rigid_update", "rigids", "rot_score", "trans_score"):
+        assert rel_l2(last[0][k][:, -1], full[0][k][:, -1]) < 2e-3, k
+    assert set(full[2]) == set(last[2])
+    worst = max(((rel_l2(last[2][n], full[2][n]), n) for n in full[2] if float(full[2][n].abs().max()) > 0), key=lambda t: t[0])
+    assert worst[0] < 3e-2, worst
+    # the cone really skipped work: the frames below it come out as zeros from the tower
+    g = full[2]["score_model.trunk.conv_0.conv1.0.weight"]
+    assert float(g.abs().max()) > 0
