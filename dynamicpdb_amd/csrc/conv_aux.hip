@@ -140,14 +140,16 @@ extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, i
 // ---------------------------------------------------------------------------------------------
 // Transposed, column-shifted copies of a padded grid tensor for the conv wgrad:
 //   X bf16 [W][Fp][Wp][C]  ->  T bf16 [nd][C][W][Fp][N],  T[d][c][w][f][n] = X[w][f][n + d0 + d][c]
-// block = (n tile of 64, c tile of 64, (w,f) row)
+// for the padded frame rows f in [f0, f0 + nf) only (the rest of T is left untouched: a frame sub-range of the wgrad
+// reduction only reads those rows).  block = (n tile of 64, c tile of 64, (w, f - f0) row)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ T,
                                                                    int Wn, int Fp, int Wp, int C, int N, int d0,
-                                                                   int nd, float* __restrict__ colsum) {
+                                                                   int nd, int f0, int nf, float* __restrict__ colsum) {
   __shared__ bf16_t t[68][66];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int wf = blockIdx.z;  // w*Fp + f
+  const int wz = blockIdx.z / nf;
+  const int wf = wz * Fp + f0 + (blockIdx.z - wz * nf);  // w*Fp + f
   const int cols = min(64 + nd - 1, Wp - (n0 + d0));  // padded columns available from n0+d0
   const int cw = min(64, C - c0);
   const bf16_t* src = X + ((long)wf * Wp + n0 + d0) * C + c0;
@@ -189,13 +191,15 @@ __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t*
 }
 
 extern "C" int dfold_grid_transpose_shift(const void* X, void* T, int32_t Wn, int32_t Fp, int32_t Wp, int32_t C,
-                                          int32_t N, int32_t d0, int32_t nd, float* colsum, void* stream) {
+                                          int32_t N, int32_t d0, int32_t nd, int32_t f0, int32_t nf, float* colsum,
+                                          void* stream) {
   if (!X || !T || Wn <= 0 || Fp <= 0 || Wp <= 0 || C <= 0 || N <= 0 || nd <= 0 || nd > 5 || d0 < 0) return DFOLD_EINVAL;
+  if (f0 < 0 || nf <= 0 || f0 + nf > Fp) return DFOLD_EINVAL;
   if (N + d0 + nd - 1 > Wp) return DFOLD_EINVAL;
   if (colsum && (d0 > 2 || 2 - d0 + 64 > 68)) return DFOLD_EINVAL;
-  dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * Fp);
+  dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * nf);
   DFOLD_LAUNCH(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
-                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd, colsum);
+                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd, f0, nf, colsum);
   return dfold_check_launch();
 }
 

@@ -236,9 +236,12 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
                 seg_div=5, seg_div_mid=5, flags=flags)
 
 
-def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None):
+def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):
+    """transposed (column-shifted) copies of the padded frame rows [f0, f0+nf) of x (default: all F+4 rows)."""
+    nf = g.Fp - f0 if nf is None else nf
     check(_lib.lib().dfold_grid_transpose_shift(_p(x), _p(out), c_int32(g.Wn), c_int32(g.Fp), c_int32(g.Wp), c_int32(C),
-                                                c_int32(g.N), c_int32(d0), c_int32(nd), _p(colsum), stream()),
+                                                c_int32(g.N), c_int32(d0), c_int32(nd), c_int32(f0), c_int32(nf),
+                                                _p(colsum), stream()),
           "dfold_grid_transpose_shift")
     return out
 
@@ -256,8 +259,10 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
     F = g.F - f_lo if nf is None else nf
     fl = GEMM_ACCUM if accumulate else 0
     if CI <= CO:   # shift x
-        tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)))
-        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)), colsum=bias_grad)
+        # the K range of window w reads padded frame rows f_lo .. f_lo+F+3 of the shifted copies, f_lo+2 .. f_lo+F+1 of the
+        # un-shifted one: only those rows are (re)written
+        tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)), f0=f_lo, nf=F + 4)
+        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)), colsum=bias_grad, f0=f_lo + 2, nf=F)
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
              a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
@@ -267,8 +272,8 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
         lo = max(0, f_lo - 2)
         F = min(g.F, f_lo + F + 2) - lo
         f_lo = lo
-        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)), colsum=bias_grad)
-        tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)))
+        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)), colsum=bias_grad, f0=f_lo, nf=F + 4)
+        tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)), f0=f_lo + 2, nf=F)
         gemm(tU, tS, dwg, CI, CO, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CO), ldb=plane,
              a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CO * plane),
              sc=(-5 * CO, -CO), c_off=24 * CO, flags=fl)
