@@ -45,6 +45,8 @@ struct GemmParams {
   long sa0, sa1, sb0, sb1, sc0, sc1;
   int M, N, nseg, seglen, nb1, flags;
   float alpha;
+  float* ws;    // split-K partial tiles (nullptr: no split)
+  int* cnt;     // split-K arrival counters, one per output tile
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -649,6 +651,44 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     mma(0);
     mma(1);
   }
+  if (ROLE == 1 && p.ws != nullptr) {
+    // Deterministic split-K: gridDim.y workgroups hold partial sums of this output tile (each walked its own range of
+    // channel chunks).  Every one parks its fp32 partial tile in the workspace; the last to arrive adds the partials in
+    // the fixed order z = 0 .. S-1 and goes on to the epilogue, the others are done.
+    const int S = gridDim.y;
+    const long tile_elems = (long)BM3 * BNW;
+    float* slot = p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + (long)w * (2 * NJ * 1024) + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slot[((i * NJ + j) * 16 + e) * 64] = acc[i][j][e];
+    __threadfence();
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) s_last = atomicAdd(p.cnt + lid, 1) == S - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const float* part = p.ws + (long)lid * tile_elems + (long)w * (2 * NJ * 1024) + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int z = 0; z < S; ++z) {
+      const float* pz = part + (long)z * nwg * tile_elems;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += pz[((i * NJ + j) * 16 + e) * 64];
+    }
+    if (tid == 0) p.cnt[lid] = 0;   // counters are left clean for the next launch
+  }
   const bool vec_ok = (p.flags & DFOLD_GEMM_OUT_BF16) && (p.N % BNW) == 0 && ((p.cm.ld | p.cm.base | coff) & 7) == 0;
   if (vec_ok) {
     __syncthreads();   // every wave is done with the operand stages: reuse the LDS as per-wave output staging
@@ -694,6 +734,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
+  p.ws = nullptr; p.cnt = nullptr;
   const int role = (d->a_rows.mode == 1 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
   const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
   const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);
@@ -704,8 +745,22 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   }
   const long tiles320 = (long)((d->M + BM3 - 1) / BM3) * ((d->N + BN3 - 1) / BN3);
   const long a_extent = row_off_host(p.am, d->M - 1) + d->a_rows.ld;   // elements spanned by the A rows of one batch
-  if (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && (d->M >= 2048 || role == 2) && steps >= 4 &&
-      tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
+  int S = 1;
+  if (d->splitk > 1) {
+    const int chunks = d->nseg / 25;
+    if (role != 1 || d->nbatch != 1 || !d->splitk_ws || !d->splitk_cnt || (d->nseg % 25) || (chunks % d->splitk) ||
+        (d->N % BN3) || (d->seglen % BK) || (d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)))
+      return DFOLD_EINVAL;
+    S = d->splitk;
+    p.nseg = d->nseg / S;                                 // every part walks chunks/S channel chunks x 25 taps
+    p.sa0 = (long)(chunks / S) * d->a_seg_s0; p.sa1 = 0;  // part z starts z * chunks/S chunks further along K
+    p.sb0 = (long)(chunks / S) * d->b_seg_s0; p.sb1 = 0;
+    p.sc0 = 0; p.sc1 = 0; p.nb1 = 1;
+    p.ws = d->splitk_ws; p.cnt = d->splitk_cnt;
+  }
+  if (S > 1 && !(a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31) && steps / S >= 2)) return DFOLD_EINVAL;
+  if (S > 1 || (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && (d->M >= 2048 || role == 2) && steps >= 4 &&
+      tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31))) {
     static bool attr3_done = false;
     if (!attr3_done) {
       hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
@@ -713,7 +768,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
       attr3_done = true;
     }
-    dim3 grid3((unsigned)tiles320, d->nbatch, 1);
+    dim3 grid3((unsigned)tiles320, S > 1 ? S : d->nbatch, 1);
     const size_t lds = 2 * STAGE3_BYTES;
     if (role == 1)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);

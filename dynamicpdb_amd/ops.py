@@ -1,6 +1,7 @@
 """Thin Python launchers over the C ABI (include/dfold_hip.h).  Tensors are torch CUDA tensors used
 purely as device buffers; all arithmetic happens in libdfold_hip.so.  bf16 tensors are torch.bfloat16."""
 import ctypes
+import os
 from ctypes import byref, c_int32, c_int64, c_void_p
 
 import torch
@@ -48,7 +49,7 @@ def seg_table(values, device):
 
 def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
          a_seg=None, b_seg=None, seg_div=1, seg_div_mid=0, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, splitk_ws=None, splitk_cnt=None):
     """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
     assert A.dtype == BF16 and B.dtype == BF16
     if C.dtype == BF16:
@@ -75,6 +76,8 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.ldb = ldb
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
     d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
+    d.splitk, d.reserved0 = splitk, 0
+    d.splitk_ws, d.splitk_cnt = _p(splitk_ws if splitk > 1 else None), _p(splitk_cnt if splitk > 1 else None)
     check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
     return C
 
@@ -214,8 +217,32 @@ class Grid:
         return ((2 + f_lo) * self.N, self.Fp * self.N, 0)
 
 
+_N_CU = {}
+
+
+def conv_splitk(M, CO, CI, device):
+    """Split factor S for a narrow conv launch (few output rows, long K = 25 taps x CI): the 256x320 tile kernel runs
+    one workgroup per CU, so tiles x S should fill the CUs in whole rounds.  Cost model in K steps: rounds x (steps/S + a
+    fixed ~16 steps for prologue, partial-tile store and the reduction).  S divides the number of 64-channel chunks."""
+    if CO % 320 or CI % 64 or os.environ.get("DFOLD_CONV_SPLITK", "1") == "0":
+        return 1
+    n_cu = _N_CU.get(device)
+    if n_cu is None:
+        n_cu = _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
+    tiles = ((M + 255) // 256) * (CO // 320)
+    chunks, steps = CI // 64, 25 * (CI // 64)
+    best, best_cost = 1, -(-tiles // n_cu) * (steps + 16)
+    for S in (2, 4, 5, 10, 20):
+        if chunks % S or steps // S < 25 or tiles * S > 4 * n_cu:
+            continue
+        cost = -(-tiles * S // n_cu) * (steps // S + 16)
+        if cost < 0.9 * best_cost:
+            best, best_cost = S, cost
+    return best
+
+
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
-                f_lo=0, nf=None):
+                f_lo=0, nf=None, ws=None):
     """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO].
     f_lo / nf: only the output cells of frames [f_lo, f_lo + nf) are computed (they read x frames f_lo-2 .. f_lo+nf+1)."""
     CO, _, CI = wf.shape
@@ -231,8 +258,16 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         C2, R2 = pre_resid_out, None
     ck = 64 if CI % 64 == 0 else CI            # K chunk per segment (one MFMA K step when channels allow)
     nf = g.F - f_lo if nf is None else nf
-    return gemm(x, wf, out, g.Wn * nf * g.N, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
-                c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
+    M = g.Wn * nf * g.N
+    S, sk = 1, {}
+    if ws is not None and nf < g.F:        # frame sub-range launches (last-frame mode): split K where the grid is thin
+        S = conv_splitk(M, CO, CI, x.device)
+        if S > 1:
+            tiles = ((M + 255) // 256) * (CO // 320)
+            sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (4 * _N_CU[x.device] * 256 * 320,), torch.float32),
+                      splitk_cnt=ws.get("splitk_cnt", (4 * _N_CU[x.device],), torch.int32))
+    return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
+                c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
                 seg_div=5, seg_div_mid=5, flags=flags)
 
 
@@ -367,10 +402,11 @@ class ConvTower:
         for i in range(4):
             (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else ((0, g.F), (0, g.F))
             u = g.alloc(C // 2)
-            conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True, f_lo=l1, nf=n1)
+            ws = self.ws if last_frame_only else None
+            conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True, f_lo=l1, nf=n1, ws=ws)
             hn, v = g.alloc(C), g.alloc(C)
             conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v,
-                        f_lo=l2, nf=n2)
+                        f_lo=l2, nf=n2, ws=ws)
             saved += [u, v, hn]
             h = hn
         return h, saved
@@ -397,14 +433,15 @@ class ConvTower:
                 l0 = g.F - n0
             conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws, bias_grad=self.db[2 * i + 1], f_lo=l2, nf=n2)
             du = ws.get("du", tuple(u.shape))
-            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1)
+            sws = ws if last_frame_only else None
+            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws)
             conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws, bias_grad=self.db[2 * i], f_lo=l1, nf=n1)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
                 conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2],
-                            f_lo=l0, nf=n0)
+                            f_lo=l0, nf=n0, ws=sws)
             else:
-                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0)
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0, ws=sws)
             gi = gn
         return gi
 

@@ -77,6 +77,15 @@ typedef struct {
   int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements): batch z -> (z / nb1, z % nb1) */
   int32_t M, N, nseg, seglen, nbatch, nb1, flags;
   float alpha;
+  /* Optional deterministic split-K of the conv implicit GEMM (a_rows.mode == 1, seg_div == seg_div_mid == 5, nbatch == 1):
+     splitk = S > 1 splits the channel-chunk axis (nseg / 25 chunks, a multiple of S) over S workgroups per output tile.
+     Each writes its fp32 partial tile to splitk_ws, the last one to arrive (splitk_cnt, one int32 per tile, zero before
+     and after the call) sums the S partials in fixed order and runs the epilogue -- narrow launches (few output rows,
+     long K) then fill the 256 CUs.  splitk_ws: >= S * tiles * 256 * Ntile fp32 (tiles = ceil(M/256) * N/Ntile, Ntile = 320). */
+  int32_t splitk;
+  int32_t reserved0;
+  float* splitk_ws;
+  int32_t* splitk_cnt;
 } dfold_gemm_desc;
 
 int dfold_gemm_bf16(const dfold_gemm_desc* desc, void* stream);

@@ -283,6 +283,50 @@ def test_conv_tower_last_frame_cone(dev):
         assert rel_l2(a, b) < 5e-3
 
 
+def test_conv_splitk_matches_unsplit(dev):
+    """frame sub-range conv launches with the deterministic split-K (partial tiles + last-arriver reduction) against
+    the same launches unsplit: every epilogue variant of the tower, two rounds (counters / workspace reuse), and
+    run-to-run bit reproducibility of the split result."""
+    from dynamicpdb_amd import ops
+    Wn, F, N = 2, 12, 32
+    g = ops.Grid(Wn, F, N, dev)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    for (CI, CO) in ((640, 320), (320, 640)):
+        w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+        wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+        from ctypes import c_int32
+        from dynamicpdb_amd import _lib
+        _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+        bias = torch.randn(CO, generator=gen).to(dev)
+        mk = lambda C: g.alloc(C)
+        x = mk(CI); g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16))
+        r = mk(CO); g.interior(r).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+        r2 = mk(CO); g.interior(r2).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+        ws = ops.Workspace(dev)
+        assert ops.conv_splitk(Wn * 5 * N, CO, CI, dev) > 1
+        variants = [dict(relu=True), dict(relu=True, resid=r, pre_resid_out="c2"), dict(relu=False, relu_mask=r),
+                    dict(relu=False, resid=r, C2="c2", R2=r2)]
+        for rnd in range(2):
+            for kw in variants:
+                outs = []
+                for use_ws in (None, ws, ws):
+                    o, c2 = mk(CO), mk(CO)
+                    k = {a: (c2 if b == "c2" else b) for a, b in kw.items()}
+                    ops.conv5x5_fwd(g, x, wf, bias if kw.get("relu") else None, o, f_lo=F - 5, nf=5, ws=use_ws, **k)
+                    outs.append((o, c2))
+                (o0, c0), (o1, c1), (o2, c2_) = outs
+                assert float(o0[:, 2 + F - 5:2 + F].abs().max()) > 0
+                # different fp32 summation order -> values that differ in the last bf16 digit (2^-8 relative at most)
+                assert rel_l2(o1, o0) < 4e-3, (CI, CO, sorted(kw))
+                if float(c0.abs().max()) > 0:
+                    assert rel_l2(c1, c0) < 4e-3, (CI, CO, sorted(kw))
+                assert float((o1.float() - o0.float()).abs().max()) <= 2.0 ** -7 * float(o0.float().abs().max())
+                assert torch.equal(o1, o2) and torch.equal(c1, c2_)              # deterministic reduction order
+                assert float(o1[:, : 2 + F - 5].abs().max()) == 0                 # rows outside the range untouched
+        assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
+
+
 def test_convnet_vs_oracle_golden(dev):
     """ConvNet on the reference-minted capture (F=3, N=16, C=1280; tests/golden/network_F3_N16.npz)."""
     from dynamicpdb_amd import ops, synthetic

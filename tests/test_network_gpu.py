@@ -146,31 +146,42 @@ def test_fresh_seed_vs_oracle():
     assert torch.equal(out["atom37"].cpu() == 0, ref["atom37"] == 0)    # integer gathers / masks bit-exact
 
 
-def test_last_frame_only_training_mode_equals_full():
+def test_last_frame_only_training_mode_equals_full(monkeypatch):
     """Training-step mode (conv tower evaluated on the dependency cone of the last frame only) vs every frame: same
-    last-frame outputs, same loss, same parameter gradients (up to bf16 re-rounding where a different tile kernel is
-    picked for the smaller row count).  F = 24 > 17 so that every block's cone is a proper subset of the frames."""
-    from dynamicpdb_amd import experiment, synthetic
+    last-frame outputs, same loss, same parameter gradients.  With the split-K of the narrow launches switched off the
+    conv results are bit-identical and only the downstream kernels' tile choices differ; with it (default) sums are
+    associated differently, i.e. bf16-rounding-level differences in the activations, which flip a few ReLU masks at
+    this toy size (the tolerance class of the gradient comparisons against the reference-minted goldens).
+    F = 24 > 17 so that every block's cone is a proper subset of the frames."""
+    from dynamicpdb_amd import experiment, ops, synthetic
     dev = torch.device("cuda:0")
     F, N, B = 24, 16, 2
     model, diffuser = _build(F, 5, dev)
     ws = [synthetic.synthetic_window(30 + i, F, N, t=0.4 + 0.3 * i, diffuser=diffuser) for i in range(B)]
     batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0]}
     batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
-    res = {}
-    for mode in (False, True):
+
+    def run(mode):
         model.zero_grad(set_to_none=True)
         out = model({k: v.clone() for k, v in batch.items()}, last_frame_only=mode)
         loss, aux = experiment.loss_fn(out, batch)
         loss.backward()
-        res[mode] = (out, float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
-    full, last = res[False], res[True]
-    assert abs(full[1] - last[1]) < 1e-3 * abs(full[1])
-    for k in ("angles", "unorm_angles", "rigid_update", "rigids", "rot_score", "trans_score"):
-        assert rel_l2(last[0][k][:, -1], full[0][k][:, -1]) < 2e-3, k
-    assert set(full[2]) == set(last[2])
-    worst = max(((rel_l2(last[2][n], full[2][n]), n) for n in full[2] if float(full[2][n].abs().max()) > 0), key=lambda t: t[0])
-    assert worst[0] < 3e-2, worst
-    # the cone really skipped work: the frames below it come out as zeros from the tower
-    g = full[2]["score_model.trunk.conv_0.conv1.0.weight"]
-    assert float(g.abs().max()) > 0
+        return out, float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    full = run(False)
+    assert float(full[2]["score_model.trunk.conv_0.conv1.0.weight"].abs().max()) > 0
+    real_splitk = ops.conv_splitk
+    for split, tol_out, tol_loss, tol_grad in ((False, 2e-3, 1e-3, 3e-2), (True, 2e-2, 5e-3, 0.3)):
+        monkeypatch.setattr(ops, "conv_splitk", real_splitk if split else (lambda *a, **k: 1))
+        last = run(True)
+        assert abs(full[1] - last[1]) < tol_loss * abs(full[1]), split
+        for k in ("angles", "unorm_angles", "rigid_update", "rigids", "rot_score", "trans_score"):
+            assert rel_l2(last[0][k][:, -1], full[0][k][:, -1]) < tol_out, (split, k)
+        assert set(full[2]) == set(last[2])
+        worst = max(((rel_l2(last[2][n], full[2][n]), n) for n in full[2] if float(full[2][n].abs().max()) > 0),
+                    key=lambda t: t[0])
+        assert worst[0] < tol_grad, (split, worst)
+        cos = torch.nn.functional.cosine_similarity(
+            torch.cat([last[2][n].flatten() for n in sorted(full[2])]).double(),
+            torch.cat([full[2][n].flatten() for n in sorted(full[2])]).double(), dim=0)
+        assert float(cos) > (0.999 if not split else 0.99), (split, float(cos))
