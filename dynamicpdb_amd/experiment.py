@@ -58,7 +58,11 @@ class Trainer:
         self.model = model
         self.last_frame_only = last_frame_only
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
+        if self.params and self.params[0].is_cuda:
+            from .optim import FusedAdam       # same update rule and state layout, one HIP launch per step
+            self.opt = FusedAdam(self.params, lr=lr)
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
         self.loss_kwargs = loss_kwargs or {}
         self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

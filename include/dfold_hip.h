@@ -244,6 +244,24 @@ int dfold_se3_forward_marginal(const float* t7, const double* u, const double* z
                                const double* b_t, float* out, double* rotvec_out, float* trans_score, int64_t P,
                                int64_t per_window, int32_t num_omega, double coordinate_scaling, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Fused Adam(amsgrad=True) step over a list of fp32 tensors in one launch (replaces the optimizer step of
+ * train_DFOLD_dynamics.py:412 / :666, torch.optim.Adam foreach path).  table: n_tensors device records; chunk_start:
+ * device int32 [n_tensors + 1], exclusive prefix sum of ceil(n / dfold_adam_chunk()) per tensor; n_chunks = its last
+ * entry.  step >= 1 is the 1-based step count used for the bias corrections; no weight decay, not maximising.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  void* p;                /* fp32 parameter, updated in place */
+  const void* g;          /* fp32 gradient */
+  void* exp_avg;          /* fp32 states, updated in place */
+  void* exp_avg_sq;
+  void* max_exp_avg_sq;
+  int64_t n;              /* elements */
+} dfold_adam_tensor;
+int dfold_adam_amsgrad(const dfold_adam_tensor* table, const int32_t* chunk_start, int32_t n_tensors, int32_t n_chunks,
+                       double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+int dfold_adam_chunk(void);
+
 #ifdef __cplusplus
 }
 #endif

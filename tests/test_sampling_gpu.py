@@ -147,3 +147,37 @@ def test_device_sampler_runs_and_is_reproducible():
     assert np.isfinite(a["prot_traj"]).all() and np.isfinite(a["rigid_traj"]).all()
     assert np.abs(a["prot_traj"] - b["prot_traj"]).max() < 1e-3        # same draws -> same trajectory
     assert tuple(a["psi_pred"].shape) == (1, F, N, 7, 2)
+
+
+def test_fused_adam_matches_torch_adam():
+    """dfold_adam_amsgrad (one launch over all tensors) vs torch.optim.Adam(amsgrad=True): same parameters and same
+    states after several steps with ragged tensor sizes (chunk tails, unaligned views, a parameter without gradient),
+    and interchangeable state_dicts."""
+    from dynamicpdb_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    shapes = [(1280, 25, 64), (7,), (8193,), (3, 5), (1,), (256, 256)]
+    base = [torch.randn(s, generator=gen) for s in shapes]
+    big = torch.randn(8192 * 2 + 3, generator=gen)
+    pa = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(big.clone().to(dev)[1:])]
+    pb = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(big.clone().to(dev)[1:])]
+    dead_a, dead_b = torch.nn.Parameter(torch.ones(4, device=dev)), torch.nn.Parameter(torch.ones(4, device=dev))
+    oa = FusedAdam(pa + [dead_a], lr=3e-3)
+    ob = torch.optim.Adam(pb + [dead_b], lr=3e-3, amsgrad=True)
+    for it in range(4):
+        for x, y in zip(pa, pb):
+            g = torch.randn(x.shape, generator=gen).to(dev) * (10.0 ** (it - 2))
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            a, b = oa.state[x][k], ob.state[y][k]
+            assert float((a - b).abs().max()) <= 1e-6 * max(1e-12, float(b.abs().max()))
+        assert int(oa.state[x]["step"]) == 4
+    assert torch.equal(dead_a, dead_b) and len(oa.state[dead_a]) == 0
+    ob2 = torch.optim.Adam(pb + [dead_b], lr=3e-3, amsgrad=True)
+    ob2.load_state_dict(oa.state_dict())                       # torch Adam accepts the fused optimizer's state
+    oa2 = FusedAdam(pa + [dead_a], lr=3e-3)
+    oa2.load_state_dict(ob.state_dict())
