@@ -257,12 +257,22 @@ class DFOLDIpaScore(nn.Module):
             ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
             node_feat = torch.cat([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], dim=-1)
             node_feat = conv.run(node_feat, last_frame_only)
-            rigid_update = self.trunk[f'bb_update_{b}'](node_feat)
-            rigid_update = torch.cat([rigid_update[:, :-1] * 0.0, rigid_update[:, -1:]], 1)      # :869
+            if last_frame_only:
+                # only frame F-1 of the tower output is defined (and consumed): per-position heads run on it alone
+                upd_last = self.trunk[f'bb_update_{b}'](node_feat[:, -1:])
+                rigid_update = torch.cat([upd_last.new_zeros(B, Fr - 1, N, 6), upd_last], 1)          # :869
+            else:
+                rigid_update = self.trunk[f'bb_update_{b}'](node_feat)
+                rigid_update = torch.cat([rigid_update[:, :-1] * 0.0, rigid_update[:, -1:]], 1)      # :869
             curr_rigids = G.compose_q_update_vec(curr_rigids, rigid_update, diffuse_mask[..., None])
             if b == 0:
                 init_node_feat = node_feat
-        unorm_angles, angles = self.angle_resnet(node_feat, init_node_feat)
+        if last_frame_only:
+            un_l, an_l = self.angle_resnet(node_feat[:, -1:], init_node_feat[:, -1:])
+            pad = un_l.new_zeros((B, Fr - 1) + tuple(un_l.shape[2:]))
+            unorm_angles, angles = torch.cat([pad, un_l], 1), torch.cat([pad, an_l], 1)
+        else:
+            unorm_angles, angles = self.angle_resnet(node_feat, init_node_feat)
         t = input_feats['t'].reshape(B)
         rot_score = self.diffuser.calc_rot_score_t7(rigids_t[..., :4], curr_rigids[..., :4], t) * node_mask[..., None]
         curr_rigids = self.unscale_rigids(curr_rigids)
