@@ -228,3 +228,105 @@ extern "C" int dfold_ipa_outfeat_bwd(const float* o_pt, const float* t7, const v
                (const bf16_t*)dgeo_g, do_pt, dt7, eps);
   return dfold_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backbone frame update (reference Rigid.compose_q_update_vec, openfold/utils/rigid_utils.py:1039-1063 ->
+// Rotation.compose_q_update_vec :587-616 -> quat_multiply_by_vec :266-275, normalisation :331-332; called at
+// src/model/ipa_pytorch_dynamic.py:871 with the masked 6-vector of BackboneUpdate):
+//   q' = normalize(q + m * (q (x) (0, u)));   t' = t + m * R(q) v        (R = quadratic form of the UNnormalised q)
+// One thread per frame, forward and analytic backward (the torch composition of this op was ~90 elementwise launches
+// per call and ~230 in its backward).  t7 [P][7], upd [P][6] = (u, v), mask [P] or NULL.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compose_fwd_kernel(const float* __restrict__ t7, const float* __restrict__ upd,
+                                                          const float* __restrict__ mask, float* __restrict__ out, long P) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const float* s = t7 + p * 7;
+  const float a = s[0], b = s[1], c = s[2], d = s[3];
+  const float* w = upd + p * 6;
+  const float m = mask != nullptr ? mask[p] : 1.f;
+  const float u0 = w[0], u1 = w[1], u2 = w[2];
+  float qs[4];
+  qs[0] = a + m * (-b * u0 - c * u1 - d * u2);
+  qs[1] = b + m * (a * u0 + c * u2 - d * u1);
+  qs[2] = c + m * (a * u1 - b * u2 + d * u0);
+  qs[3] = d + m * (a * u2 + b * u1 - c * u0);
+  const float inv = 1.f / sqrtf(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+  float R[9];
+  quat_rot(s, R);
+  float* o = out + p * 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = qs[k] * inv;
+  o[4] = s[4] + m * (R[0] * w[3] + R[1] * w[4] + R[2] * w[5]);
+  o[5] = s[5] + m * (R[3] * w[3] + R[4] * w[4] + R[5] * w[5]);
+  o[6] = s[6] + m * (R[6] * w[3] + R[7] * w[4] + R[8] * w[5]);
+}
+
+__global__ __launch_bounds__(256) void compose_bwd_kernel(const float* __restrict__ t7, const float* __restrict__ upd,
+                                                          const float* __restrict__ mask, const float* __restrict__ g,
+                                                          float* __restrict__ dt7, float* __restrict__ dupd, long P) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const float* s = t7 + p * 7;
+  const float a = s[0], b = s[1], c = s[2], d = s[3];
+  const float* w = upd + p * 6;
+  const float m = mask != nullptr ? mask[p] : 1.f;
+  const float u0 = w[0], u1 = w[1], u2 = w[2];
+  float qs[4];
+  qs[0] = a + m * (-b * u0 - c * u1 - d * u2);
+  qs[1] = b + m * (a * u0 + c * u2 - d * u1);
+  qs[2] = c + m * (a * u1 - b * u2 + d * u0);
+  qs[3] = d + m * (a * u2 + b * u1 - c * u0);
+  const float inv = 1.f / sqrtf(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+  const float* gp = g + p * 7;
+  // through the normalisation: gqs = (gq - qn (qn . gq)) / |qs|
+  float qn[4], gq[4], dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    qn[k] = qs[k] * inv;
+    dot += qn[k] * gp[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gq[k] = (gp[k] - qn[k] * dot) * inv;
+  // qs = q + m (q (x) w), w = (0, u):  dL/dq = gqs + m (gqs (x) w*),  dL/dw = m (q* (x) gqs)
+  float dq[4];
+  dq[0] = gq[0] + m * (gq[1] * u0 + gq[2] * u1 + gq[3] * u2);
+  dq[1] = gq[1] + m * (-gq[0] * u0 - gq[2] * u2 + gq[3] * u1);
+  dq[2] = gq[2] + m * (-gq[0] * u1 + gq[1] * u2 - gq[3] * u0);
+  dq[3] = gq[3] + m * (-gq[0] * u2 - gq[1] * u1 + gq[2] * u0);
+  float* du = dupd + p * 6;
+  du[0] = m * (a * gq[1] - b * gq[0] - c * gq[3] + d * gq[2]);
+  du[1] = m * (a * gq[2] + b * gq[3] - c * gq[0] - d * gq[1]);
+  du[2] = m * (a * gq[3] - b * gq[2] + c * gq[1] - d * gq[0]);
+  // t' = t + m R(q) v
+  float R[9], G[9];
+  quat_rot(s, R);
+  const float gt0 = gp[4], gt1 = gp[5], gt2 = gp[6];
+  du[3] = m * (R[0] * gt0 + R[3] * gt1 + R[6] * gt2);
+  du[4] = m * (R[1] * gt0 + R[4] * gt1 + R[7] * gt2);
+  du[5] = m * (R[2] * gt0 + R[5] * gt1 + R[8] * gt2);
+  G[0] = m * gt0 * w[3]; G[1] = m * gt0 * w[4]; G[2] = m * gt0 * w[5];
+  G[3] = m * gt1 * w[3]; G[4] = m * gt1 * w[4]; G[5] = m * gt1 * w[5];
+  G[6] = m * gt2 * w[3]; G[7] = m * gt2 * w[4]; G[8] = m * gt2 * w[5];
+  float dqr[4];
+  drot_to_dquat(s, G, dqr);
+  float* o = dt7 + p * 7;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = dq[k] + dqr[k];
+  o[4] = gt0; o[5] = gt1; o[6] = gt2;
+}
+
+extern "C" int dfold_compose_fwd(const float* t7, const float* upd6, const float* mask, float* out, int64_t P, void* stream) {
+  if (!t7 || !upd6 || !out || P <= 0) return DFOLD_EINVAL;
+  DFOLD_LAUNCH(compose_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t7, upd6, mask, out,
+               (long)P);
+  return dfold_check_launch();
+}
+
+extern "C" int dfold_compose_bwd(const float* t7, const float* upd6, const float* mask, const float* g, float* dt7, float* dupd6,
+                                 int64_t P, void* stream) {
+  if (!t7 || !upd6 || !g || !dt7 || !dupd6 || P <= 0) return DFOLD_EINVAL;
+  DFOLD_LAUNCH(compose_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t7, upd6, mask, g, dt7,
+               dupd6, (long)P);
+  return dfold_check_launch();
+}

@@ -464,3 +464,35 @@ class Igso3SeriesFn(Function):
     def backward(ctx, g):
         (dsc,) = ctx.saved_tensors
         return (g * dsc).float(), None
+
+
+# ------------------------------------------------------------------------------------------------
+# backbone frame update
+# ------------------------------------------------------------------------------------------------
+
+class ComposeFn(Function):
+    """Rigid.compose_q_update_vec on tensor_7 frames (openfold/utils/rigid_utils.py:1039-1063; call site
+    src/model/ipa_pytorch_dynamic.py:871): one HIP launch forward, one backward (csrc/ipa_geom.hip)."""
+
+    @staticmethod
+    def forward(ctx, t7, upd6, mask):
+        t, u = t7.contiguous().float(), upd6.contiguous().float()
+        m = mask.expand(t.shape[:-1] + (1,)).contiguous().float() if mask is not None else None
+        out = torch.empty_like(t)
+        P = t.numel() // 7
+        check(_lib.lib().dfold_compose_fwd(_p(t), _p(u), _p(m), _p(out), c_int64(P), stream()), "dfold_compose_fwd")
+        ctx.save_for_backward(t, u, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, u, m = ctx.saved_tensors
+        gc = g.contiguous().float()
+        dt, du = torch.empty_like(t), torch.empty_like(u)
+        check(_lib.lib().dfold_compose_bwd(_p(t), _p(u), _p(m), _p(gc), _p(dt), _p(du), c_int64(t.numel() // 7), stream()),
+              "dfold_compose_bwd")
+        return dt, du, None
+
+
+def compose_q_update_vec(t7, upd6, mask=None):
+    return ComposeFn.apply(t7, upd6, mask)

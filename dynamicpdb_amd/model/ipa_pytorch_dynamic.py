@@ -264,7 +264,7 @@ class DFOLDIpaScore(nn.Module):
             else:
                 rigid_update = self.trunk[f'bb_update_{b}'](node_feat)
                 rigid_update = torch.cat([rigid_update[:, :-1] * 0.0, rigid_update[:, -1:]], 1)      # :869
-            curr_rigids = G.compose_q_update_vec(curr_rigids, rigid_update, diffuse_mask[..., None])
+            curr_rigids = F_.compose_q_update_vec(curr_rigids, rigid_update, diffuse_mask[..., None])
             if b == 0:
                 init_node_feat = node_feat
         if last_frame_only:

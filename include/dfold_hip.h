@@ -245,6 +245,17 @@ int dfold_se3_forward_marginal(const float* t7, const double* u, const double* z
                                int64_t per_window, int32_t num_omega, double coordinate_scaling, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Backbone frame update (replaces Rigid.compose_q_update_vec, openfold/utils/rigid_utils.py:1039-1063 ->
+ * Rotation.compose_q_update_vec :587-616, quat_multiply_by_vec :266-275, normalisation :331-332; call site
+ * src/model/ipa_pytorch_dynamic.py:871):  q' = normalize(q + m (q (x) (0,u))),  t' = t + m R(q) v.
+ * t7 fp32 [P][7], upd6 fp32 [P][6] = (u, v), mask fp32 [P] or NULL -> out [P][7];  backward: g = dL/dout ->
+ * dt7 [P][7], dupd6 [P][6].
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_compose_fwd(const float* t7, const float* upd6, const float* mask, float* out, int64_t P, void* stream);
+int dfold_compose_bwd(const float* t7, const float* upd6, const float* mask, const float* g, float* dt7, float* dupd6,
+                      int64_t P, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Fused Adam(amsgrad=True) step over a list of fp32 tensors in one launch (replaces the optimizer step of
  * train_DFOLD_dynamics.py:412 / :666, torch.optim.Adam foreach path).  table: n_tensors device records; chunk_start:
  * device int32 [n_tensors + 1], exclusive prefix sum of ceil(n / dfold_adam_chunk()) per tensor; n_chunks = its last

@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from util import rel_l2
+from util import max_abs, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -273,3 +273,30 @@ def test_ipa_module_vs_oracle_fwd_bwd():
             assert k == "linear_b.bias" and float(r.norm()) < 1e-4, k
             continue
         assert rel_l2(p.grad, r) < 3e-2, (k, rel_l2(p.grad, r))
+
+
+def test_compose_q_update_vec_node():
+    """dfold_compose_fwd/bwd vs the torch composition of Rigid.compose_q_update_vec (fp64 autograd), masked frames incl."""
+    from dynamicpdb_amd.model import functional as Fm
+    from dynamicpdb_amd.model import geometry as G
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    B, F, N = 2, 3, 37
+    q = torch.randn(B, F, N, 4, generator=gen)
+    t7 = torch.cat([q / q.norm(dim=-1, keepdim=True) * (1 + 0.05 * torch.randn(B, F, N, 1, generator=gen)),
+                    torch.randn(B, F, N, 3, generator=gen) * 10], -1)
+    upd = torch.randn(B, F, N, 6, generator=gen) * 0.4
+    mask = (torch.rand(B, F, N, 1, generator=gen) > 0.3).float()
+    g = torch.randn(B, F, N, 7, generator=gen)
+    a = t7.to(dev).requires_grad_(True)
+    u = upd.to(dev).requires_grad_(True)
+    out = Fm.compose_q_update_vec(a, u, mask.to(dev))
+    out.backward(g.to(dev))
+    ar, ur = t7.double().requires_grad_(True), upd.double().requires_grad_(True)
+    ref = G.compose_q_update_vec(ar, ur, mask.double())
+    ref.backward(g.double())
+    assert max_abs(out, ref) < 1e-5
+    assert max_abs(a.grad, ar.grad) < 2e-5 * max(1.0, float(ar.grad.abs().max()))
+    assert max_abs(u.grad, ur.grad) < 2e-5 * max(1.0, float(ur.grad.abs().max()))
+    out2 = Fm.compose_q_update_vec(a.detach(), u.detach(), None)          # no mask = all frames move
+    assert max_abs(out2, G.compose_q_update_vec(t7.double(), upd.double(), torch.ones(B, F, N, 1, dtype=torch.float64))) < 1e-5
