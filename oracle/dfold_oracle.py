@@ -540,3 +540,84 @@ def so3_reverse(sched, rotvec_t, score_t, t, dt, z):
     perturb = g ** 2 * score_t * dt + g * np.sqrt(dt) * z
     R = rotvec_to_rotmat(rotvec_t) @ rotvec_to_rotmat(perturb)
     return rotmat_to_rotvec(R)
+
+
+# ----------------------------------------------------------------------------
+# dataset-side geometry: atom37 coordinates -> rigid-group frames and torsion angles
+# (reference openfold/data/data_transforms.py:755-893 atom37_to_frames, :923-1088 atom37_to_torsion_angles,
+#  Rigid.from_3_points openfold/utils/rigid_utils.py:1233-1275; called per item by
+#  src/data/Dfold_data_loader_dynamic.py:237-240 on float64 tensors)
+# ----------------------------------------------------------------------------
+
+def from_3_points(p_neg_x, origin, p_xy, eps=1e-8):
+    """Gram-Schmidt frame (rigid_utils.py:1233-1275): returns (R [...,3,3] with columns e0,e1,e2, origin)."""
+    e0 = origin - p_neg_x
+    e1 = p_xy - origin
+    e0 = e0 / torch.sqrt((e0 * e0).sum(-1, keepdim=True) + eps)
+    e1 = e1 - e0 * (e0 * e1).sum(-1, keepdim=True)
+    e1 = e1 / torch.sqrt((e1 * e1).sum(-1, keepdim=True) + eps)
+    e2 = torch.cross(e0, e1, dim=-1)
+    return torch.stack([e0, e1, e2], -1), origin
+
+
+def _to_4x4(R, t):
+    out = torch.zeros(R.shape[:-2] + (4, 4), dtype=R.dtype)
+    out[..., :3, :3] = R
+    out[..., :3, 3] = t
+    out[..., 3, 3] = 1
+    return out
+
+
+def atom37_to_frames(aatype, pos, mask, eps=1e-8):
+    """aatype [...,N] int64, pos [...,N,37,3], mask [...,N,37] -> dict with rigidgroups_gt_frames [...,N,8,4,4],
+    rigidgroups_gt_exists, rigidgroups_group_exists, rigidgroups_group_is_ambiguous [...,N,8],
+    rigidgroups_alt_gt_frames (data_transforms.py:755-893)."""
+    T = residue_tables()
+    idx = T["group_base_atom37"][aatype]                                          # [...,N,8,3]
+    base = torch.gather(pos[..., None, :, :].expand(pos.shape[:-2] + (8, 37, 3)), -2,
+                        idx[..., None].expand(idx.shape + (3,)))                  # [...,N,8,3(atoms),3]
+    R, t = from_3_points(base[..., 0, :], base[..., 1, :], base[..., 2, :], eps)
+    group_exists = T["group_mask"][aatype].to(mask.dtype)
+    atoms_exist = torch.gather(mask[..., None, :].expand(mask.shape[:-1] + (8, 37)), -1, idx)
+    gt_exists = atoms_exist.min(-1)[0] * group_exists
+    flip = torch.ones(8, 3, dtype=pos.dtype)
+    flip[0, 0] = -1
+    flip[0, 2] = -1                                                               # group 0: diag(-1, 1, -1)
+    R = R * flip[:, None, :]                                                      # right-multiply by the diagonal matrix
+    amb = T["group_ambiguous"][aatype].to(pos.dtype)
+    sgn = torch.ones(amb.shape + (3,), dtype=pos.dtype)
+    sgn[..., 1] = 1 - 2 * amb
+    sgn[..., 2] = 1 - 2 * amb                                                     # ambiguous groups: diag(1, -1, -1)
+    R_alt = R * sgn[..., None, :]
+    return {"rigidgroups_gt_frames": _to_4x4(R, t), "rigidgroups_gt_exists": gt_exists,
+            "rigidgroups_group_exists": group_exists, "rigidgroups_group_is_ambiguous": amb.to(mask.dtype),
+            "rigidgroups_alt_gt_frames": _to_4x4(R_alt, t)}
+
+
+def atom37_to_torsion_angles(aatype, pos, mask):
+    """-> torsion_angles_sin_cos [...,N,7,2], alt_torsion_angles_sin_cos, torsion_angles_mask [...,N,7]
+    (data_transforms.py:923-1088): pre-omega, phi, psi, chi1-4; the previous residue along the chain supplies CA, C."""
+    T = residue_tables()
+    aatype = torch.clamp(aatype, max=20)
+    prev_pos = torch.cat([torch.zeros_like(pos[..., :1, :, :]), pos[..., :-1, :, :]], -3)
+    prev_mask = torch.cat([torch.zeros_like(mask[..., :1, :]), mask[..., :-1, :]], -2)
+    pre_omega = torch.cat([prev_pos[..., 1:3, :], pos[..., :2, :]], -2)
+    phi = torch.cat([prev_pos[..., 2:3, :], pos[..., :3, :]], -2)
+    psi = torch.cat([pos[..., :3, :], pos[..., 4:5, :]], -2)
+    m_omega = prev_mask[..., 1:3].prod(-1) * mask[..., :2].prod(-1)
+    m_phi = prev_mask[..., 2] * mask[..., :3].prod(-1)
+    m_psi = mask[..., :3].prod(-1) * mask[..., 4]
+    ci = T["chi_atom37"][aatype]                                                  # [...,N,4,4]
+    chis = torch.gather(pos[..., None, :, :].expand(pos.shape[:-2] + (4, 37, 3)), -2, ci[..., None].expand(ci.shape + (3,)))
+    chi_atoms_mask = torch.gather(mask[..., None, :].expand(mask.shape[:-1] + (4, 37)), -1, ci).prod(-1)
+    m_chi = T["chi_mask"][aatype].to(mask.dtype) * chi_atoms_mask
+    atoms = torch.cat([pre_omega[..., None, :, :], phi[..., None, :, :], psi[..., None, :, :], chis], -3)   # [...,N,7,4,3]
+    tmask = torch.cat([m_omega[..., None], m_phi[..., None], m_psi[..., None], m_chi], -1)
+    R, t = from_3_points(atoms[..., 1, :], atoms[..., 2, :], atoms[..., 0, :], 1e-8)
+    rel = ((atoms[..., 3, :] - t)[..., None, :] * R.transpose(-1, -2)).sum(-1)    # R^T (x - t)
+    sc = torch.stack([rel[..., 2], rel[..., 1]], -1)
+    sc = sc / torch.sqrt((sc * sc).sum(-1, keepdim=True) + 1e-8)
+    sc = sc * torch.tensor([1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0], dtype=pos.dtype)[:, None]
+    amb = T["chi_pi_periodic"][aatype].to(pos.dtype)
+    mirror = torch.cat([torch.ones(aatype.shape + (3,), dtype=pos.dtype), 1.0 - 2.0 * amb], -1)
+    return {"torsion_angles_sin_cos": sc, "alt_torsion_angles_sin_cos": sc * mirror[..., None], "torsion_angles_mask": tmask}

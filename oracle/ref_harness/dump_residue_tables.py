@@ -13,9 +13,41 @@ ref_import.install()
 from src.data import residue_constants as rc_src
 from openfold.np import residue_constants as rc_of
 
+# --- index / mask tables of the dataset-side geometry (openfold/data/data_transforms.py:755-893 atom37_to_frames,
+#     :895-1088 atom37_to_torsion_angles), built from the same residue constants the reference loops over there ---
+base_names = np.full([21, 8, 3], "", dtype=object)
+base_names[:, 0, :] = ["C", "CA", "N"]
+base_names[:, 3, :] = ["CA", "C", "O"]
+group_mask = np.zeros([21, 8], np.float32)
+group_mask[:, 0] = 1
+group_mask[:, 3] = 1
+group_mask[:20, 4:] = np.asarray(rc_of.chi_angles_mask, np.float32)
+for restype, letter in enumerate(rc_of.restypes):
+    resname = rc_of.restype_1to3[letter]
+    for chi in range(4):
+        if rc_of.chi_angles_mask[restype][chi]:
+            base_names[restype, chi + 4, :] = rc_of.chi_angles_atoms[resname][chi][1:]
+lut = dict(rc_of.atom_order)
+lut[""] = 0
+group_base_atom37 = np.vectorize(lambda x: lut[x])(base_names).astype(np.int64)                  # [21,8,3]
+group_ambiguous = np.zeros([21, 8], np.float32)
+for resname in rc_of.residue_atom_renaming_swaps:
+    restype = rc_of.restype_order[rc_of.restype_3to1[resname]]
+    group_ambiguous[restype, int(sum(rc_of.chi_angles_mask[restype]) - 1) + 4] = 1
+chi_atoms = []
+for letter in rc_of.restypes:
+    rows = [[rc_of.atom_order[a] for a in chi] for chi in rc_of.chi_angles_atoms[rc_of.restype_1to3[letter]]]
+    rows += [[0, 0, 0, 0]] * (4 - len(rows))
+    chi_atoms.append(rows)
+chi_atoms.append([[0, 0, 0, 0]] * 4)
+chi_mask = np.asarray(list(rc_of.chi_angles_mask) + [[0.0, 0.0, 0.0, 0.0]], np.float32)            # [21,4]
+chi_pi = np.asarray(rc_of.chi_pi_periodic, np.float32)                                            # [21,4]
+
 out = os.path.join(os.path.dirname(__file__), "..", "..", "dynamicpdb_amd", "data", "residue_tables.npz")
 np.savez_compressed(
     out,
+    group_base_atom37=group_base_atom37, group_mask=group_mask, group_ambiguous=group_ambiguous,
+    chi_atom37=np.asarray(chi_atoms, np.int64), chi_mask=chi_mask, chi_pi_periodic=chi_pi,
     default_frames=np.asarray(rc_src.restype_rigid_group_default_frame, np.float32),      # [21,8,4,4]
     atom14_group=np.asarray(rc_src.restype_atom14_to_rigid_group, np.int64),             # [21,14]
     atom14_mask=np.asarray(rc_src.restype_atom14_mask, np.float32),                      # [21,14]

@@ -180,7 +180,42 @@ def golden_diffuser(exp, F=3, N=16):
     print("diffuser golden written")
 
 
+def golden_dataset_geom(F=2, N=40, seed=11):
+    """atom37 -> rigid-group frames / torsion angles with the reference's own dataset transforms
+    (openfold/data/data_transforms.py:755-893, :923-1088), float64 as in the loader (Dfold_data_loader_dynamic.py:229-240).
+    Coordinates: the oracle's frames->atoms builder on random frames / torsions (all 20 residue types + unknown), with a
+    few atoms masked out so that the `exists` masks are exercised."""
+    from openfold.data import data_transforms
+    from oracle import dfold_oracle as O
+    rng = np.random.default_rng(seed)
+    aatype = torch.tensor(rng.integers(0, 21, size=(1, N))).long().expand(F, N).contiguous()
+    aatype[:, :21] = torch.arange(21)[None]                       # every residue type at least once
+    q = torch.tensor(rng.standard_normal((F, N, 4)))
+    q = q / q.norm(dim=-1, keepdim=True)
+    t7 = torch.cat([q, torch.tensor(rng.standard_normal((F, N, 3)) * 12)], -1)
+    ang = torch.tensor(rng.standard_normal((F, N, 7, 2)))
+    ang = ang / ang.norm(dim=-1, keepdim=True)
+    _, atom37 = O.frames_to_atoms(t7, ang, torch.clamp(aatype, max=20))
+    mask = O.residue_tables()["atom37_mask"][torch.clamp(aatype, max=20)].double().clone()
+    drop = torch.tensor(rng.uniform(size=mask.shape) < 0.04)
+    mask[drop] = 0
+    atom37 = atom37.double() * mask[..., None]
+    prot = {"aatype": aatype, "all_atom_positions": atom37.clone(), "all_atom_mask": mask.clone()}
+    prot = data_transforms.atom37_to_frames(prot)
+    prot = data_transforms.atom37_to_torsion_angles()(prot)
+    fix = {"aatype": np_(aatype), "all_atom_positions": np_(atom37), "all_atom_mask": np_(mask)}
+    for k in ("rigidgroups_gt_frames", "rigidgroups_gt_exists", "rigidgroups_group_exists", "rigidgroups_group_is_ambiguous",
+              "rigidgroups_alt_gt_frames", "torsion_angles_sin_cos", "alt_torsion_angles_sin_cos", "torsion_angles_mask"):
+        fix[k] = np_(prot[k])
+    np.savez_compressed(os.path.join(HERE, "dataset_geom.npz"), **fix)
+    print("dataset_geom golden written", {k: v.shape for k, v in fix.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset_geom":
+        golden_dataset_geom()
+        sys.exit(0)
     exp = golden_network()
     golden_diffuser(exp)
     golden_triangle()
+    golden_dataset_geom()

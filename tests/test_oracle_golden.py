@@ -114,3 +114,27 @@ def test_reverse_step_with_injected_noise():
         R1 = O.rotvec_to_rotmat(rv1)
         assert np.abs(R1 - g[f"rev{i}_rot_mats"]).max() < 2e-5      # reference went through fp32 quats
         assert np.abs(x1 - g[f"rev{i}_trans"]).max() < 1e-4
+
+
+def test_dataset_geometry_vs_reference_golden():
+    """atom37 -> rigid-group frames and torsion angles (dataset-side transforms) against outputs of the reference's own
+    openfold data_transforms on float64 inputs (tests/golden/dataset_geom.npz)."""
+    from oracle import dfold_oracle as O
+    g = load_golden("dataset_geom.npz")
+    aatype = torch.tensor(g["aatype"])
+    pos, mask = torch.tensor(g["all_atom_positions"]), torch.tensor(g["all_atom_mask"])
+    fr = O.atom37_to_frames(aatype, pos, mask)
+    for k in ("rigidgroups_gt_exists", "rigidgroups_group_exists", "rigidgroups_group_is_ambiguous"):
+        assert np.array_equal(fr[k].numpy(), g[k]), k                                # masks: exact
+    for k in ("rigidgroups_gt_frames", "rigidgroups_alt_gt_frames"):
+        # the reference's Rotation/Rigid classes hold fp32 (rigid_utils.py:326-329, 899): its frames are the fp64
+        # Gram-Schmidt result rounded to fp32 (translations up to ~40 A -> 4e-6 A of rounding)
+        assert g[k].dtype == np.float32 and np.abs(fr[k].numpy() - g[k]).max() < 1e-5, k
+    to = O.atom37_to_torsion_angles(aatype, pos, mask)
+    assert np.array_equal(to["torsion_angles_mask"].numpy(), g["torsion_angles_mask"])
+    for k in ("torsion_angles_sin_cos", "alt_torsion_angles_sin_cos"):
+        # (the reference's torsion frames also pass through its fp32 Rotation class: agreement at fp32 level)
+        assert np.abs(to[k].numpy() - g[k]).max() < 2e-5, k
+    # the synthetic torsions that built the coordinates come back (where every atom of the torsion exists)
+    m = g["torsion_angles_mask"][..., 3:] > 0
+    assert m.sum() > 20
