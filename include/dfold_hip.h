@@ -256,6 +256,22 @@ int dfold_compose_bwd(const float* t7, const float* upd6, const float* mask, con
                       int64_t P, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Dataset-side geometry (replaces openfold/data/data_transforms.py:755-893 atom37_to_frames and :923-1088
+ * atom37_to_torsion_angles as called by src/data/Dfold_data_loader_dynamic.py:237-240).  P = rows*N residues, chains are
+ * rows of N residues (the previous residue of a row's first residue does not exist).  Inputs float64 like the loader's;
+ * tables = the reference's residue constants (dynamicpdb_amd/data/residue_tables.npz).  Pass gt_frames == NULL to skip
+ * the frame block, torsion_sin_cos == NULL to skip the torsion block.
+ *   gt_frames / alt_gt_frames fp32 [P][8][4][4];  gt_exists, group_exists, group_is_ambiguous fp64 [P][8];
+ *   torsion_sin_cos / alt_torsion_sin_cos fp64 [P][7][2];  torsion_mask fp64 [P][7].
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_atom37_geometry(const int64_t* aatype, const double* all_atom_positions, const double* all_atom_mask,
+                          const int64_t* group_base_atom37, const float* group_mask, const float* group_ambiguous,
+                          const int64_t* chi_atom37, const float* chi_mask, const float* chi_pi_periodic,
+                          float* gt_frames, float* alt_gt_frames, double* gt_exists, double* group_exists,
+                          double* group_is_ambiguous, double* torsion_sin_cos, double* alt_torsion_sin_cos,
+                          double* torsion_mask, int64_t P, int32_t N, double eps, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Fused Adam(amsgrad=True) step over a list of fp32 tensors in one launch (replaces the optimizer step of
  * train_DFOLD_dynamics.py:412 / :666, torch.optim.Adam foreach path).  table: n_tensors device records; chunk_start:
  * device int32 [n_tensors + 1], exclusive prefix sum of ceil(n / dfold_adam_chunk()) per tensor; n_chunks = its last

@@ -181,3 +181,53 @@ def test_fused_adam_matches_torch_adam():
     ob2.load_state_dict(oa.state_dict())                       # torch Adam accepts the fused optimizer's state
     oa2 = FusedAdam(pa + [dead_a], lr=3e-3)
     oa2.load_state_dict(ob.state_dict())
+
+
+def test_dataset_transforms_vs_reference_golden():
+    """device atom37_to_frames / atom37_to_torsion_angles against the outputs of the reference's own transforms
+    (tests/golden/dataset_geom.npz): masks and index gathers exact, frames at the fp32 precision the reference stores,
+    torsions at the fp32-level agreement its own fp32 Rotation class leaves; plus a longer batched call vs the oracle."""
+    from oracle import dfold_oracle as O
+    from dynamicpdb_amd.data import data_transforms as dt
+    dev = torch.device("cuda:0")
+    g = load_golden("dataset_geom.npz")
+    prot = {"aatype": torch.tensor(g["aatype"]).to(dev), "all_atom_positions": torch.tensor(g["all_atom_positions"]).to(dev),
+            "all_atom_mask": torch.tensor(g["all_atom_mask"]).to(dev)}
+    prot = dt.atom37_to_frames(prot)
+    prot = dt.atom37_to_torsion_angles()(prot)
+    for k in ("rigidgroups_gt_exists", "rigidgroups_group_exists", "rigidgroups_group_is_ambiguous", "torsion_angles_mask"):
+        assert prot[k].dtype == torch.float64 and np.array_equal(prot[k].cpu().numpy(), g[k]), k
+    for k in ("rigidgroups_gt_frames", "rigidgroups_alt_gt_frames"):
+        assert prot[k].dtype == torch.float32 and max_abs(prot[k], g[k]) < 1e-5, k
+    for k in ("torsion_angles_sin_cos", "alt_torsion_angles_sin_cos"):
+        assert prot[k].dtype == torch.float64 and max_abs(prot[k], g[k]) < 2e-5, k
+    # batched [B, F, N, ...] input at a size the oracle still does in a second: fp64 agreement with the restatement
+    gen = np.random.default_rng(5)
+    B, F, N = 2, 3, 64
+    aatype = torch.tensor(gen.integers(0, 21, size=(B, F, N)))
+    q = torch.tensor(gen.standard_normal((B, F, N, 4)))
+    t7 = torch.cat([q / q.norm(dim=-1, keepdim=True), torch.tensor(gen.standard_normal((B, F, N, 3)) * 15)], -1)
+    ang = torch.tensor(gen.standard_normal((B, F, N, 7, 2)))
+    ang = ang / ang.norm(dim=-1, keepdim=True)
+    _, a37 = O.frames_to_atoms(t7, ang, torch.clamp(aatype, max=20))
+    mask = O.residue_tables()["atom37_mask"][torch.clamp(aatype, max=20)].double()
+    mask = mask * torch.tensor(gen.uniform(size=mask.shape) > 0.05)
+    a37 = a37.double() * mask[..., None]
+    p2 = dt.atom37_to_torsion_angles()(dt.atom37_to_frames(
+        {"aatype": aatype.to(dev), "all_atom_positions": a37.to(dev), "all_atom_mask": mask.to(dev)}))
+    fr, to = O.atom37_to_frames(aatype, a37, mask), O.atom37_to_torsion_angles(aatype, a37, mask)
+    assert max_abs(p2["rigidgroups_gt_frames"], fr["rigidgroups_gt_frames"]) < 1e-5
+    assert torch.equal(p2["rigidgroups_gt_exists"].cpu(), fr["rigidgroups_gt_exists"])
+    live = to["torsion_angles_mask"] > 0
+    for k in ("torsion_angles_sin_cos", "alt_torsion_angles_sin_cos"):
+        d = (p2[k].cpu() - to[k]).abs()
+        # defined torsions: fp64 agreement; undefined ones (missing atoms / no previous residue) are degenerate
+        # Gram-Schmidt problems whose value is don't-care and only agrees to the conditioning of the 1e-8 epsilons
+        assert float(d[live].max()) < 1e-9, (k, float(d[live].max()))
+        assert float(d.max()) < 1e-4, (k, float(d.max()))
+    assert torch.equal(p2["torsion_angles_mask"].cpu(), to["torsion_angles_mask"])
+    # the torsions that built the coordinates come back wherever all four atoms exist
+    sel = to["torsion_angles_mask"][..., 3:] > 0
+    assert float((p2["torsion_angles_sin_cos"].cpu()[..., 3:, :] - ang[..., 3:, :])[sel].abs().max()) < 1e-5
+    with pytest.raises(RuntimeError):
+        dt.atom37_to_frames({"aatype": aatype, "all_atom_positions": a37, "all_atom_mask": mask})
