@@ -359,3 +359,54 @@ class TriangleAttentionStartingNode(TriangleAttention):
 class TriangleAttentionEndingNode(TriangleAttention):
     def __init__(self, c_in, c_hidden, no_heads, inf=1e9):
         super().__init__(c_in, c_hidden, no_heads, starting=False, inf=inf)
+
+
+# ------------------------------------------------------------------------------------------------
+# pair transition (the pair-stack neighbour of the triangle operators)
+# ------------------------------------------------------------------------------------------------
+
+class RowLayerNormFn(Function):
+    """y = LayerNorm(x) over the last axis with affine (torch.nn.LayerNorm semantics, eps inside the sqrt), one wave per
+    row (csrc/triangle.hip row_ln_*).  x fp32 or bf16 [R, C] -> bf16 [R, C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        y, stats = _row_ln_fwd(x, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), eps)
+        ctx.save_for_backward(x, stats, gamma)
+        ctx.x_bf16 = x.dtype == BF16
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, gamma = ctx.saved_tensors
+        g = g.contiguous() if g.dtype == BF16 else ops.cast_bf16(g)
+        dx, dgamma, dbeta = _row_ln_bwd(x, stats, gamma.detach().float().contiguous(), g, ctx.x_bf16)
+        return dx, dgamma, dbeta, None
+
+
+class PairTransition(nn.Module):
+    """Drop-in for openfold/model/pair_transition.py:24-99 (Algorithm 15): same constructor, forward(z, mask=None,
+    chunk_size=None) and state_dict keys (layer_norm, linear_1, linear_2).  LayerNorm rows on the wave-per-row kernel,
+    both projections on the bf16 MFMA engine (ReLU fused into the first one's epilogue); chunk_size is accepted and
+    ignored -- nothing here materialises more than the [N*N, n*c_z] bf16 hidden activation."""
+
+    def __init__(self, c_z, n):
+        super().__init__()
+        if c_z % 8:
+            raise ValueError("c_z must be a multiple of 8")
+        self.c_z, self.n = c_z, n
+        self.layer_norm = nn.LayerNorm(c_z)
+        self.linear_1 = nn.Linear(c_z, n * c_z)
+        self.linear_2 = nn.Linear(n * c_z, c_z)
+
+    def forward(self, z, mask=None, chunk_size=None):
+        from . import functional as F_
+        if not z.is_cuda:
+            raise RuntimeError("dynamicpdb_amd pair operators need an MI355X device tensor (no CPU fallback)")
+        if mask is None:
+            mask = z.new_ones(z.shape[:-1])
+        x = RowLayerNormFn.apply(z.reshape(-1, self.c_z), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        h = F_.linear(x, self.linear_1.weight, self.linear_1.bias, relu=True)
+        y = F_.linear(h, self.linear_2.weight, self.linear_2.bias, out_fp32=True)
+        return y.view(z.shape) * mask.unsqueeze(-1).to(y.dtype)

@@ -621,3 +621,16 @@ def atom37_to_torsion_angles(aatype, pos, mask):
     amb = T["chi_pi_periodic"][aatype].to(pos.dtype)
     mirror = torch.cat([torch.ones(aatype.shape + (3,), dtype=pos.dtype), 1.0 - 2.0 * amb], -1)
     return {"torsion_angles_sin_cos": sc, "alt_torsion_angles_sin_cos": sc * mirror[..., None], "torsion_angles_mask": tmask}
+
+
+# ----------------------------------------------------------------------------
+# pair transition (openfold/model/pair_transition.py:24-99, Algorithm 15)
+# ----------------------------------------------------------------------------
+
+def pair_transition(P, z, mask=None):
+    """z [*,N,N,c_z] -> update [*,N,N,c_z]: LayerNorm, Linear(c_z -> n c_z), ReLU, Linear(n c_z -> c_z), times mask."""
+    if mask is None:
+        mask = z.new_ones(z.shape[:-1])
+    x = torch.nn.functional.layer_norm(z, (z.shape[-1],), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
+    h = torch.relu(linear(P, "linear_1", x))
+    return linear(P, "linear_2", h) * mask[..., None]

@@ -133,6 +133,38 @@ def golden_triangle(N=24, seed=3):
     print("triangle golden written")
 
 
+def golden_pair_transition(N=24, seed=6):
+    """PairTransition (openfold/model/pair_transition.py:24-99, Algorithm 15), the pair-stack neighbour of the triangle
+    operators: output, input gradient and every parameter gradient of the reference module."""
+    from openfold.model.pair_transition import PairTransition
+    rng = np.random.default_rng(seed)
+    fix = {}
+    z = torch.tensor(rng.standard_normal((N, N, 128), dtype=np.float32))
+    mask = torch.tensor((rng.uniform(size=(N, N)) > 0.1).astype(np.float32))
+    fix["z"], fix["mask"] = np_(z), np_(mask)
+    m = PairTransition(128, 4)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            w = rng.standard_normal(tuple(v.shape), dtype=np.float32) / np.sqrt(v.shape[-1])
+        elif k.endswith("weight"):
+            w = 1.0 + 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        else:
+            w = 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        sd[k] = torch.tensor(w.astype(np.float32))
+        fix[f"P.{k}"] = w.astype(np.float32)
+    m.load_state_dict(sd)
+    zz = z.clone().requires_grad_(True)
+    y = m(zz, mask=mask)
+    gy = torch.tensor(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(gy)
+    fix["out"], fix["gy"], fix["gz"] = np_(y), np_(gy), np_(zz.grad)
+    for k, p_ in m.named_parameters():
+        fix[f"G.{k}"] = np_(p_.grad)
+    np.savez_compressed(os.path.join(HERE, f"pair_transition_N{N}.npz"), **fix)
+    print("pair transition golden written", sorted(k for k in fix if k.startswith("P.")))
+
+
 def golden_diffuser(exp, F=3, N=16):
     d = exp.diffuser
     so3, r3 = d._so3_diffuser, d._r3_diffuser
@@ -215,7 +247,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset_geom":
         golden_dataset_geom()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pair_transition":
+        golden_pair_transition()
+        sys.exit(0)
     exp = golden_network()
     golden_diffuser(exp)
     golden_triangle()
     golden_dataset_geom()
+    golden_pair_transition()

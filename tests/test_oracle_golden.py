@@ -138,3 +138,16 @@ def test_dataset_geometry_vs_reference_golden():
     # the synthetic torsions that built the coordinates come back (where every atom of the torsion exists)
     m = g["torsion_angles_mask"][..., 3:] > 0
     assert m.sum() > 20
+
+
+def test_pair_transition_vs_reference_golden():
+    """oracle PairTransition vs the reference module's output and gradients (tests/golden/pair_transition_N24.npz)."""
+    g = load_golden("pair_transition_N24.npz")
+    P = {k[2:]: torch.tensor(v).requires_grad_(True) for k, v in g.items() if k.startswith("P.")}
+    z = torch.tensor(g["z"]).requires_grad_(True)
+    y = O.pair_transition(P, z, torch.tensor(g["mask"]))
+    assert rel_l2(y, g["out"]) < 1e-5
+    y.backward(torch.tensor(g["gy"]))
+    assert rel_l2(z.grad, g["gz"]) < 1e-5
+    for k, p in P.items():
+        assert rel_l2(p.grad, g["G." + k]) < 1e-5, k

@@ -66,3 +66,30 @@ def test_triangle_vs_oracle_n64(name):
     else:
         ref = O.triangle_attention(P, z, mask, starting=name.endswith("start"))
     assert rel_l2(y, ref) < 1.5e-2
+
+
+def test_pair_transition_vs_reference_golden_and_oracle():
+    """PairTransition against the reference module's golden (N = 24) and against the oracle at N = 96 with a batch axis."""
+    from oracle import dfold_oracle as O
+    from dynamicpdb_amd.model import triangle as T
+    dev = torch.device("cuda:0")
+    g = load_golden("pair_transition_N24.npz")
+    m = T.PairTransition(128, 4)
+    m.load_state_dict({k[2:]: torch.tensor(v) for k, v in g.items() if k.startswith("P.")}, strict=True)
+    m.to(dev)
+    z = torch.tensor(g["z"]).to(dev).requires_grad_(True)
+    y = m(z, mask=torch.tensor(g["mask"]).to(dev))
+    assert rel_l2(y, g["out"]) < 1e-2
+    y.backward(torch.tensor(g["gy"]).to(dev))
+    # gradient path: three bf16 storage points (dL/dy, dL/dh, dL/dx) and a ReLU mask on a bf16-rounded activation
+    assert rel_l2(z.grad, g["gz"]) < 5e-2
+    for k, p in m.named_parameters():
+        assert p.grad is not None and rel_l2(p.grad, g["G." + k]) < 5e-2, (k, rel_l2(p.grad, g["G." + k]))
+    rng = np.random.default_rng(2)
+    z2 = torch.tensor(rng.standard_normal((2, 96, 96, 128), dtype=np.float32))
+    mask2 = torch.tensor((rng.uniform(size=(2, 96, 96)) > 0.2).astype(np.float32))
+    with torch.no_grad():
+        y2 = m(z2.to(dev), mask=mask2.to(dev), chunk_size=4)
+        ref = O.pair_transition({k: v.detach().cpu() for k, v in m.state_dict().items()}, z2, mask2)
+    assert rel_l2(y2, ref) < 1e-2
+    assert float(y2.cpu()[mask2 == 0].abs().max()) == 0.0
