@@ -171,3 +171,29 @@ def test_data_parallel_gradient_average_gloo_world2():
         for got, want in zip(r[2], mean):
             assert np.allclose(got, want, rtol=1e-6, atol=1e-8)
         assert all(r[3])
+
+
+def test_conv_tower_cone_ranges_and_splitk_model(monkeypatch):
+    """Frame ranges of the last-frame dependency cone (pure host logic): nested, each 5x5 layer adds 2 frames, clipped to
+    the window; and the split-K cost model picks divisors of the chunk count that fill whole rounds of CUs."""
+    from dynamicpdb_amd import ops
+    for F in (1, 3, 8, 16, 17, 32, 64):
+        for i in (3, 2, 1, 0):
+            (l1, n1), (l2, n2) = ops.ConvTower.cone(F, i)
+            r = 4 * (3 - i)
+            assert n2 == min(F, r + 1) and n1 == min(F, r + 3) and l1 == F - n1 and l2 == F - n2
+            assert l1 <= l2 and l1 + n1 == F and l2 + n2 == F              # suffix ranges, the inner activation wider
+            if i < 3:   # what block i delivers covers what block i+1 reads: its inner range widened by one conv (2 frames)
+                assert n2 == min(F, ops.ConvTower.cone(F, i + 1)[0][1] + 2)
+        assert ops.ConvTower.cone(F, 3)[1] == (F - 1, 1)
+    monkeypatch.setitem(ops._N_CU, "dev", 256)
+    monkeypatch.delenv("DFOLD_CONV_SPLITK", raising=False)
+    # (rows, CO, CI) of the narrow launches at config 3 (8 windows x nf frames x 256 residues)
+    assert ops.conv_splitk(8 * 3 * 256, 640, 1280, "dev") == 5      # 48 tiles  -> 240 workgroups
+    assert ops.conv_splitk(8 * 7 * 256, 640, 1280, "dev") == 2      # 112 tiles -> 224
+    assert ops.conv_splitk(8 * 15 * 256, 640, 1280, "dev") == 1     # 240 tiles already fill one round
+    assert ops.conv_splitk(8 * 1 * 256, 1280, 640, "dev") == 5      # 32 tiles
+    assert ops.conv_splitk(8 * 32 * 256, 1280, 640, "dev") == 1     # full layer: whole rounds, no split
+    assert ops.conv_splitk(8 * 3 * 256, 600, 1280, "dev") == 1      # N tile does not divide: not eligible
+    monkeypatch.setenv("DFOLD_CONV_SPLITK", "0")
+    assert ops.conv_splitk(8 * 3 * 256, 640, 1280, "dev") == 1
