@@ -20,10 +20,22 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
 }
 
+// any alignment (views into larger tensors, e.g. one frame of a ragged [F, N, 6] gradient)
+__global__ void cast_f32_bf16_scalar_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = f2bf(src[i]);
+}
+
 extern "C" int dfold_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
   if (!src || !dst || n < 0) return DFOLD_EINVAL;
   if (n == 0) return DFOLD_OK;
-  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return DFOLD_EINVAL;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) {
+    long sb = (n + 255) / 256;
+    if (sb > 4096) sb = 4096;
+    DFOLD_LAUNCH(cast_f32_bf16_scalar_kernel, dim3((unsigned)sb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    return dfold_check_launch();
+  }
   long blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 4096) blocks = 4096;
   DFOLD_LAUNCH(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
@@ -139,12 +151,14 @@ extern "C" int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, i
 
 // ---------------------------------------------------------------------------------------------
 // Transposed, column-shifted copies of a padded grid tensor for the conv wgrad:
-//   X bf16 [W][Fp][Wp][C]  ->  T bf16 [nd][C][W][Fp][N],  T[d][c][w][f][n] = X[w][f][n + d0 + d][c]
+//   X bf16 [W][Fp][Wp][C]  ->  T bf16 [nd][C][W][Fp][NP],  T[d][c][w][f][n] = X[w][f][n + d0 + d][c]  for n < N
+// (NP >= N = row pitch of T, a multiple of 8 so that every frame row is a 16-byte aligned K run of the wgrad GEMM;
+// the tail n in [N, NP) is never written -- the caller keeps it zero)
 // for the padded frame rows f in [f0, f0 + nf) only (the rest of T is left untouched: a frame sub-range of the wgrad
 // reduction only reads those rows).  block = (n tile of 64, c tile of 64, (w, f - f0) row)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ T,
-                                                                   int Wn, int Fp, int Wp, int C, int N, int d0,
+                                                                   int Wn, int Fp, int Wp, int C, int N, int NP, int d0,
                                                                    int nd, int f0, int nf, float* __restrict__ colsum) {
   __shared__ bf16_t t[68][66];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t*
     }
   }
   __syncthreads();
-  const long plane = (long)Wn * Fp * N;  // elements per (d, c)
+  const long plane = (long)Wn * Fp * NP;  // elements per (d, c)
   const int nw = min(64, N - n0);
   if (colsum != nullptr) {
     // fused bias gradient: per-channel sum over the interior cells of this tile (border rows / columns are zero)
@@ -185,21 +199,22 @@ __global__ __launch_bounds__(256) void grid_transpose_shift_kernel(const bf16_t*
   for (int d = 0; d < nd; ++d) {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
       const int n = e & 63, c = e >> 6;
-      if (n < nw && c < cw) T[((long)d * C + c0 + c) * plane + (long)wf * N + n0 + n] = t[n + d][c];
+      if (n < nw && c < cw) T[((long)d * C + c0 + c) * plane + (long)wf * NP + n0 + n] = t[n + d][c];
     }
   }
 }
 
 extern "C" int dfold_grid_transpose_shift(const void* X, void* T, int32_t Wn, int32_t Fp, int32_t Wp, int32_t C,
-                                          int32_t N, int32_t d0, int32_t nd, int32_t f0, int32_t nf, float* colsum,
-                                          void* stream) {
+                                          int32_t N, int32_t NP, int32_t d0, int32_t nd, int32_t f0, int32_t nf,
+                                          float* colsum, void* stream) {
   if (!X || !T || Wn <= 0 || Fp <= 0 || Wp <= 0 || C <= 0 || N <= 0 || nd <= 0 || nd > 5 || d0 < 0) return DFOLD_EINVAL;
+  if (NP < N) return DFOLD_EINVAL;
   if (f0 < 0 || nf <= 0 || f0 + nf > Fp) return DFOLD_EINVAL;
   if (N + d0 + nd - 1 > Wp) return DFOLD_EINVAL;
   if (colsum && (d0 > 2 || 2 - d0 + 64 > 68)) return DFOLD_EINVAL;
   dim3 grid((N + 63) / 64, (C + 63) / 64, Wn * nf);
   DFOLD_LAUNCH(grid_transpose_shift_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X,
-                     (bf16_t*)T, Wn, Fp, Wp, C, N, d0, nd, f0, nf, colsum);
+                     (bf16_t*)T, Wn, Fp, Wp, C, N, NP, d0, nd, f0, nf, colsum);
   return dfold_check_launch();
 }
 

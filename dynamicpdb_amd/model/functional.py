@@ -82,9 +82,16 @@ def _linear_backward(x2d, weight, g2d, need_dx=True):
         wt = CACHE.wt(weight)                       # [K][N8]
         dx = torch.empty((M, K), dtype=BF16, device=x2d.device)
         gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
-    gT = ops.transpose_bf16(g8, M, N8)              # [N8][M]
-    xT = ops.transpose_bf16(x2d, M, K)              # [K][M]
-    dW = ops.gemm_reduce_rows(gT, xT, N8, K, M)
+    M8 = (M + 7) // 8 * 8
+    if M8 == M:
+        gT = ops.transpose_bf16(g8, M, N8)          # [N8][M]
+        xT = ops.transpose_bf16(x2d, M, K)          # [K][M]
+    else:   # the row axis becomes the GEMM K axis: pad it with zero columns to a multiple of 8 (16-byte bf16 chunks)
+        gT = torch.zeros((N8, M8), dtype=BF16, device=x2d.device)
+        xT = torch.zeros((K, M8), dtype=BF16, device=x2d.device)
+        ops.transpose_bf16(g8, M, N8, out=gT, bs_dst=(0, 0), ld_dst=M8)
+        ops.transpose_bf16(x2d, M, K, out=xT, bs_dst=(0, 0), ld_dst=M8)
+    dW = ops.gemm_reduce_rows(gT, xT, N8, K, M8)
     db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)
     ops.colsum_bf16(g8, db, M, N8, N8)
     return dx, dW[:N], db[:N]

@@ -155,7 +155,21 @@ class InvariantPointAttention(nn.Module):
             self.linear_out.bias.zero_()
 
     def features(self, s, z, t7, mask):
-        """s bf16 [B,F,N,c_s], z bf16 [B,N,N,c_z], t7 fp32 [B,F,N,7], mask [B,F,N] -> bf16 [B,F,N,H*(...)]  (:350-504)"""
+        """s bf16 [B,F,N,c_s], z bf16 [B,N,N,c_z], t7 fp32 [B,F,N,7], mask [B,F,N] -> bf16 [B,F,N,H*(...)]  (:350-504).
+        The attention products use the residue axis as a GEMM K axis (16-byte bf16 rows): when N_res is not a multiple
+        of 8 the inputs are padded with masked-out residues (identity frames, zero features, mask 0 -> exactly zero
+        attention weight as keys, their own rows discarded), which leaves every real row unchanged."""
+        N = s.shape[2]
+        pad = (-N) % 8
+        if pad == 0:
+            return self._features(s, z, t7, mask)
+        ident = t7.new_zeros(t7.shape[:2] + (pad, 7))
+        ident[..., 0] = 1.0
+        out = self._features(Fn.pad(s, (0, 0, 0, pad)), Fn.pad(z, (0, 0, 0, pad, 0, pad)), torch.cat([t7, ident], 2),
+                             Fn.pad(mask, (0, pad)))
+        return out[:, :, :N]
+
+    def _features(self, s, z, t7, mask):
         B, Fr, N, _ = s.shape
         H, PQ, PV = self.no_heads, self.no_qk_points, self.no_v_points
         q = F_.linear(s, self.linear_q.weight, self.linear_q.bias)

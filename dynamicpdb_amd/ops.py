@@ -183,11 +183,12 @@ class Grid:
     """Geometry of the zero-padded channels-last activation grid [windows, F+4, N+4, C]."""
 
     def __init__(self, Wn, F, N, device):
-        if N % 8:
-            raise ValueError("N_res must be a multiple of 8 (16-byte bf16 chunks)")
         self.Wn, self.F, self.N, self.Fp, self.Wp, self.device = Wn, F, N, F + 4, N + 4, device
         self.M = Wn * F * N
-        self.plane = Wn * self.Fp * N
+        # transposed [channel][window][frame][residue] copies of the weight-gradient product: frame rows are padded to a
+        # multiple of 8 residues (16-byte aligned K runs for any N_res; the pad columns stay zero)
+        self.NP = (N + 7) // 8 * 8
+        self.plane = Wn * self.Fp * self.NP
 
     def alloc(self, C):
         return torch.zeros((self.Wn, self.Fp, self.Wp, C), dtype=BF16, device=self.device)
@@ -210,11 +211,11 @@ class Grid:
 
     def seg_shifted(self, f_lo=0):
         """wgrad K segment = window w of a transposed [c][w][f'][n] copy, starting at padded frame row f_lo ..."""
-        return (f_lo * self.N, self.Fp * self.N, 0)
+        return (f_lo * self.NP, self.Fp * self.NP, 0)
 
     def seg_center(self, f_lo=0):
         """... or at padded frame row 2 + f_lo (the un-shifted operand)."""
-        return ((2 + f_lo) * self.N, self.Fp * self.N, 0)
+        return ((2 + f_lo) * self.NP, self.Fp * self.NP, 0)
 
 
 _N_CU = {}
@@ -275,7 +276,7 @@ def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):
     """transposed (column-shifted) copies of the padded frame rows [f0, f0+nf) of x (default: all F+4 rows)."""
     nf = g.Fp - f0 if nf is None else nf
     check(_lib.lib().dfold_grid_transpose_shift(_p(x), _p(out), c_int32(g.Wn), c_int32(g.Fp), c_int32(g.Wp), c_int32(C),
-                                                c_int32(g.N), c_int32(d0), c_int32(nd), c_int32(f0), c_int32(nf),
+                                                c_int32(g.N), c_int32(g.NP), c_int32(d0), c_int32(nd), c_int32(f0), c_int32(nf),
                                                 _p(colsum), stream()),
           "dfold_grid_transpose_shift")
     return out
@@ -290,14 +291,15 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
     bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass).
     f_lo / nf: gy is zero outside frames [f_lo, f_lo + nf): only those cells enter the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
-    plane, N = g.plane, g.N
+    plane, N = g.plane, g.NP        # N: K-run length of one frame row in the transposed copies
+    tag = "" if g.N == g.NP else "_n%d" % g.N   # ragged N: own scratch (its pad columns must never have been written)
     F = g.F - f_lo if nf is None else nf
     fl = GEMM_ACCUM if accumulate else 0
     if CI <= CO:   # shift x
         # the K range of window w reads padded frame rows f_lo .. f_lo+F+3 of the shifted copies, f_lo+2 .. f_lo+F+1 of the
         # un-shifted one: only those rows are (re)written
-        tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS", (5 * CI * plane + 64,)), f0=f_lo, nf=F + 4)
-        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU", (CO * plane + 64,)), colsum=bias_grad, f0=f_lo + 2, nf=F)
+        tS = grid_transpose_shift(g, x, CI, 0, 5, ws.get("tS" + tag, (5 * CI * plane + 64,)), f0=f_lo, nf=F + 4)
+        tU = grid_transpose_shift(g, gy, CO, 2, 1, ws.get("tU" + tag, (CO * plane + 64,)), colsum=bias_grad, f0=f_lo + 2, nf=F)
         gemm(tU, tS, dwg, CO, CI, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CI), ldb=plane,
              a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CI * plane),
              sc=(5 * CI, CI), flags=fl)
@@ -307,8 +309,8 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
         lo = max(0, f_lo - 2)
         F = min(g.F, f_lo + F + 2) - lo
         f_lo = lo
-        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS", (5 * CO * plane + 64,)), colsum=bias_grad, f0=f_lo, nf=F + 4)
-        tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU", (CI * plane + 64,)), f0=f_lo + 2, nf=F)
+        tS = grid_transpose_shift(g, gy, CO, 0, 5, ws.get("tS" + tag, (5 * CO * plane + 64,)), colsum=bias_grad, f0=f_lo, nf=F + 4)
+        tU = grid_transpose_shift(g, x, CI, 2, 1, ws.get("tU" + tag, (CI * plane + 64,)), f0=f_lo + 2, nf=F)
         gemm(tU, tS, dwg, CI, CO, F * N, nseg=g.Wn, a_rows=rows_plain(plane), c_rows=rows_plain(25 * CO), ldb=plane,
              a_seg=g.seg_center(f_lo), b_seg=g.seg_shifted(f_lo), nbatch=25, nb1=5, sb=(N, CO * plane),
              sc=(-5 * CO, -CO), c_off=24 * CO, flags=fl)

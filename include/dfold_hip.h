@@ -101,10 +101,11 @@ int dfold_conv_weight_pack(const float* W, void* Wf, void* Wd, int32_t CO, int32
 /* dWg fp32 [CO][25][CI] (transposed != 0: [CI][25][CO]) -> G fp32 [CO][CI][5][5]; accumulate != 0: G += */
 int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, int32_t accumulate, int32_t transposed,
                             void* stream);
-/* X bf16 [W][Fp][Wp][C] -> T bf16 [nd][C][W][Fp][N], T[d][c][w][f][n] = X[w][f][n+d0+d][c] for the padded frame rows
-   f in [f0, f0+nf) (other rows of T untouched); colsum (optional, fp32 [C], atomics): += per-channel sum over the
-   interior cells of those rows (the conv bias gradient, fused) */
-int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, int32_t Wp, int32_t C, int32_t N,
+/* X bf16 [W][Fp][Wp][C] -> T bf16 [nd][C][W][Fp][NP], T[d][c][w][f][n] = X[w][f][n+d0+d][c] (n < N <= NP; the tail
+   n in [N,NP) is not written and must be zero) for the padded frame rows f in [f0, f0+nf) (other rows of T untouched);
+   colsum (optional, fp32 [C], atomics): += per-channel sum over the interior cells of those rows (the conv bias
+   gradient, fused) */
+int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, int32_t Wp, int32_t C, int32_t N, int32_t NP,
                                int32_t d0, int32_t nd, int32_t f0, int32_t nf, float* colsum, void* stream);
 /* out[c] += sum_r X[r*ld + c]   (X bf16, out fp32, atomics) */
 int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream);

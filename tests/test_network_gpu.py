@@ -185,3 +185,43 @@ def test_last_frame_only_training_mode_equals_full(monkeypatch):
             torch.cat([last[2][n].flatten() for n in sorted(full[2])]).double(),
             torch.cat([full[2][n].flatten() for n in sorted(full[2])]).double(), dim=0)
         assert float(cos) > (0.999 if not split else 0.99), (split, float(cos))
+
+
+def test_ragged_nres_vs_oracle():
+    """N_res that is not a multiple of 8 (27 residues, 4 frames: 108 rows): the engine pads where it needs 16-byte rows
+    (masked residues inside IPA, zero columns in the weight-gradient layouts) -- outputs, loss and gradients against the
+    CPU oracle, both step modes."""
+    from oracle import dfold_oracle as O
+    from dynamicpdb_amd import experiment, synthetic
+    dev = torch.device("cuda:0")
+    F, N = 4, 27
+    model, diffuser = _build(F, 9, dev)
+    w = synthetic.synthetic_window(33, F, N, t=0.45, diffuser=diffuser)
+    sd = synthetic.seeded_state_dict(9)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.full_score_network(P, O.Schedules(), w)
+    ref_loss, _ = O.loss_fn(ref, w)
+    ref_loss.backward()
+    batch = {k: v[None].to(dev) for k, v in w.items()}
+    batch["t"] = w["t"].to(dev).reshape(1)
+    for mode in (False, True):
+        model.zero_grad(set_to_none=True)
+        out = model({k: v.clone() for k, v in batch.items()}, last_frame_only=mode)
+        sel = (lambda x: x[0, -1]) if mode else (lambda x: x[0])
+        rsel = (lambda x: x[-1]) if mode else (lambda x: x)
+        for k in ("angles", "unorm_angles"):
+            assert rel_l2(sel(out[k]), rsel(ref[k])) < 2e-2, (mode, k)
+        assert rel_l2(out["rot_score"][0], ref["rot_score"]) < 1e-2
+        assert rel_l2(out["trans_score"][0], ref["trans_score"]) < 1e-3
+        assert max_abs(out["rigids"][0][..., 4:], ref["rigids"][..., 4:]) < 5e-3
+        loss, _ = experiment.loss_fn(out, batch)
+        assert abs(float(loss) - float(ref_loss)) < 2e-2 * abs(float(ref_loss)), mode
+        loss.backward()
+        names = [n for n, p in model.named_parameters() if p.grad is not None]
+        # (the pair-bias Linear's bias shifts every logit of a softmax row alike: identically zero gradient, not produced)
+        extra = {n for n, p in P.items() if p.grad is not None} - set(names)
+        assert all(n.endswith("linear_b.bias") for n in extra) and set(names) <= set(P)
+        a = torch.cat([dict(model.named_parameters())[n].grad.flatten().cpu().double() for n in names])
+        b = torch.cat([P[n].grad.flatten().double() for n in names])
+        assert bool(torch.isfinite(a).all())
+        assert float(torch.nn.functional.cosine_similarity(a, b, dim=0)) > 0.97, mode
