@@ -113,6 +113,23 @@ def test_device_path_has_no_cpu_fallback(diffuser):
         model(w)
     with pytest.raises(RuntimeError):
         TriangleMultiplicationOutgoing(128, 128)(torch.zeros(8, 8, 128))
+    from dynamicpdb_amd.data import data_transforms
+    from dynamicpdb_amd.model.triangle import PairTransition
+    from dynamicpdb_amd.optim import FusedAdam
+    with pytest.raises(RuntimeError):
+        PairTransition(128, 4)(torch.zeros(8, 8, 128))
+    prot = {"aatype": torch.zeros(2, 8, dtype=torch.long), "all_atom_positions": torch.zeros(2, 8, 37, 3, dtype=torch.float64),
+            "all_atom_mask": torch.ones(2, 8, 37, dtype=torch.float64)}
+    with pytest.raises(RuntimeError):
+        data_transforms.atom37_to_frames(prot)
+    with pytest.raises(RuntimeError):
+        data_transforms.atom37_to_torsion_angles()(prot)
+    with pytest.raises(RuntimeError):
+        diffuser.forward_marginal_t7(torch.zeros(3, 8, 7), 0.5)
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(ValueError):
+        FusedAdam([p], lr=1e-3).step()            # host tensors: refused, never silently stepped on the CPU
 
 
 def test_batched_loss_matches_oracle():
