@@ -6,7 +6,10 @@ loss, backward, gradient all-reduce, Adam/amsgrad step) on one batch of syntheti
 
   metric = trajectory frames/s (fwd+bwd) at N_res=256; value = windows*frames of all ranks / max-over-ranks time;
   roofline = the dominant kernel (5x5 conv implicit GEMM, bf16 MFMA) vs the dense bf16 MFMA peak;
-  cpu_baseline = the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample.
+  cpu_baseline = the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample;
+  last_frame_mode = extra, NOT the headline: the same update_fn in the engine's training-step mode (conv tower evaluated
+                    on the dependency cone of the last frame only; identical loss / gradients).
+The headline `value` always runs every frame through the conv tower, i.e. the work the reference does.
 """
 import argparse
 import json
