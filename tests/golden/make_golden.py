@@ -37,7 +37,7 @@ def subsample(g, stride=9973):
     return flat[::stride].clone()
 
 
-def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5):
+def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973):
     from src.data.se3_diffuser import SE3Diffuser
     import train_DFOLD_dynamics as T
     conf = ref_import.make_conf(F, cache_dir=".cache/")
@@ -77,11 +77,12 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5):
     fix = {f"in_{k}": np_(v) for k, v in win.items()}
     for k in ("angles", "unorm_angles", "rot_score", "trans_score", "rigids", "atom37", "atom14", "rigid_update"):
         fix[f"out_{k}"] = np_(out[k])
-    for k, v in cap.items():
-        fix[f"cap_{k}"] = np_(v)
-    for i, (ci, co) in enumerate(conv_calls[:4]):
-        fix[f"cap_conv_in_{i}"] = np_(ci)
-        fix[f"cap_conv_out_{i}"] = np_(co)
+    if captures:
+        for k, v in cap.items():
+            fix[f"cap_{k}"] = np_(v)
+        for i, (ci, co) in enumerate(conv_calls[:4]):
+            fix[f"cap_conv_in_{i}"] = np_(ci)
+            fix[f"cap_conv_out_{i}"] = np_(co)
     fix["loss"] = np_(loss)
     for k, v in aux.items():
         if k in ("rot_loss", "trans_loss", "torsion_loss", "total_loss"):
@@ -92,8 +93,8 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5):
             continue
         g = p.grad
         fix[f"gnorm_{name}"] = np_(g.double().norm())
-        fix[f"gsub_{name}"] = np_(subsample(g) if g.numel() > 70000 else g)
-    fix["meta"] = np.array([F, N, seed_w, seed_x], np.int64)
+        fix[f"gsub_{name}"] = np_(subsample(g, grad_stride) if g.numel() > 70000 else g)
+    fix["meta"] = np.array([F, N, seed_w, seed_x, grad_stride], np.int64)
     np.savez_compressed(os.path.join(HERE, f"network_F{F}_N{N}.npz"), **fix)
     print("network golden: loss", float(loss), {k: float(v) for k, v in aux.items() if "batch" not in k})
     return exp
@@ -246,6 +247,11 @@ def golden_dataset_geom(F=2, N=40, seed=11):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset_geom":
         golden_dataset_geom()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_F8":
+        # second network capture: 8 frames (interior frames of the 5-tap conv axis, a last-frame cone that is clipped only
+        # in the first block), other seeds / diffusion time; outputs, loss, gradient norms and sparse gradient samples only
+        golden_network(F=8, N=16, seed_w=2, seed_x=5, t=0.3, captures=False, grad_stride=39989)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pair_transition":
         golden_pair_transition()

@@ -151,3 +151,35 @@ def test_pair_transition_vs_reference_golden():
     assert rel_l2(z.grad, g["gz"]) < 1e-5
     for k, p in P.items():
         assert rel_l2(p.grad, g["G." + k]) < 1e-5, k
+
+
+def test_network_second_capture_f8():
+    """Second reference capture (8 frames, other weights / window / diffusion time, tests/golden/network_F8_N16.npz):
+    outputs, loss and sparse gradient samples.  With 8 frames the 5-tap frame axis of the conv tower has interior
+    frames and the last-frame dependency cone is a proper subset in the later blocks."""
+    g = load_golden("network_F8_N16.npz")
+    F, N, seed_w, seed_x, stride = [int(v) for v in g["meta"]]
+    P = {k: v.clone().requires_grad_(True) for k, v in synthetic.seeded_state_dict(seed_w).items()}
+    w = window_from_golden(g)
+    out = O.full_score_network(P, O.Schedules(), w)
+    for k in ("angles", "unorm_angles", "trans_score", "rigid_update"):
+        assert rel_l2(out[k], g["out_" + k]) < 1e-5, k
+    assert rel_l2(out["rot_score"], g["out_rot_score"]) < 1e-5
+    assert max_abs(out["atom37"], g["out_atom37"]) < 1e-3
+    loss, aux = O.loss_fn(out, w)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    checked = 0
+    for k in g:
+        if not k.startswith("gsub_"):
+            continue
+        name = k[5:]
+        gr = P[name].grad
+        ref = torch.tensor(g[k]).double()
+        mine = (gr.reshape(-1)[::stride] if gr.numel() > 70000 else gr).double()
+        if float(g["gnorm_" + name]) < 1e-6:
+            continue
+        assert abs(float(gr.double().norm()) - float(g["gnorm_" + name])) < 1e-3 * float(g["gnorm_" + name]), name
+        assert float((mine - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-9, name
+        checked += 1
+    assert checked > 100
