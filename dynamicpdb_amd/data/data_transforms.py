@@ -2,7 +2,9 @@
 `atom37_to_frames` and `atom37_to_torsion_angles` of openfold/data/data_transforms.py (:755-893, :923-1088), with the
 reference's calling convention (a feature dict in, the same dict updated and returned; the torsion transform is curried
 like upstream: `atom37_to_torsion_angles()(protein)`), as used by src/data/Dfold_data_loader_dynamic.py:237-240.
-Both run in one HIP launch each (csrc/dataset_geom.hip) on [..., N_res, 37, 3] device tensors; there is no CPU path."""
+Both run in one HIP launch each (csrc/dataset_geom.hip) on [..., N_res, 37, 3] device tensors; there is no CPU path.
+`make_atom14_masks` / `make_atom14_positions` (:572-643, :653-752), the pure index gathers between them in the loader,
+are table look-ups on whatever device the features live on."""
 from ctypes import c_double, c_int32, c_int64, c_void_p
 
 import torch
@@ -66,3 +68,35 @@ def atom37_to_torsion_angles(prefix=""):
         protein[prefix + "torsion_angles_mask"] = tm.to(md)
         return protein
     return fn
+
+
+def make_atom14_masks(protein):
+    """openfold/data/data_transforms.py:572-643: per-residue atom14 <-> atom37 index maps and existence masks."""
+    aatype = protein["aatype"].to(torch.long)
+    T = residue_tables(aatype.device)
+    protein["atom14_atom_exists"] = T["atom14_exists"][aatype]
+    protein["residx_atom14_to_atom37"] = T["atom14_to_atom37"][aatype]
+    protein["residx_atom37_to_atom14"] = T["atom37_to_atom14"][aatype]
+    protein["atom37_atom_exists"] = T["atom37_mask"][aatype]
+    return protein
+
+
+def make_atom14_positions(protein):
+    """openfold/data/data_transforms.py:653-752: atom14 ground-truth positions / masks gathered from atom37, their
+    alternatives under the renaming of the chemically equivalent atoms (ASP, GLU, PHE, TYR), and the ambiguity mask.
+    The reference multiplies by 14x14 permutation matrices; a permutation is a gather."""
+    aatype = protein["aatype"].to(torch.long)
+    T = residue_tables(aatype.device)
+    exists = protein["atom14_atom_exists"]
+    idx = protein["residx_atom14_to_atom37"]
+    mask37, pos37 = protein["all_atom_mask"], protein["all_atom_positions"]
+    gt_mask = exists * torch.gather(mask37, -1, idx)
+    gt_pos = gt_mask[..., None] * torch.gather(pos37, -2, idx[..., None].expand(idx.shape + (3,)))
+    ren = T["atom14_rename"][aatype]
+    protein["atom14_atom_exists"] = exists
+    protein["atom14_gt_exists"] = gt_mask
+    protein["atom14_gt_positions"] = gt_pos
+    protein["atom14_alt_gt_positions"] = torch.gather(gt_pos, -2, ren[..., None].expand(ren.shape + (3,)))
+    protein["atom14_alt_gt_exists"] = torch.gather(gt_mask, -1, ren)
+    protein["atom14_atom_is_ambiguous"] = T["atom14_is_ambiguous"][aatype].to(mask37.dtype)
+    return protein

@@ -634,3 +634,21 @@ def pair_transition(P, z, mask=None):
     x = torch.nn.functional.layer_norm(z, (z.shape[-1],), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
     h = torch.relu(linear(P, "linear_1", x))
     return linear(P, "linear_2", h) * mask[..., None]
+
+
+def make_atom14(aatype, pos37, mask37):
+    """make_atom14_masks + make_atom14_positions (data_transforms.py:572-643, :653-752), restated with the reference's
+    permutation-matrix formulation (einsum with the 14x14 renaming matrices)."""
+    T = residue_tables()
+    exists = T["atom14_exists"][aatype]
+    idx = T["atom14_to_atom37"][aatype]
+    gt_mask = exists.to(mask37.dtype) * torch.gather(mask37, -1, idx)
+    gt_pos = gt_mask[..., None] * torch.gather(pos37, -2, idx[..., None].expand(idx.shape + (3,)))
+    M = torch.zeros(21, 14, 14, dtype=mask37.dtype)
+    M[torch.arange(21)[:, None], torch.arange(14)[None, :], T["atom14_rename"]] = 1.0
+    Mr = M[aatype]
+    return {"atom14_atom_exists": exists, "residx_atom14_to_atom37": idx, "residx_atom37_to_atom14": T["atom37_to_atom14"][aatype],
+            "atom37_atom_exists": T["atom37_mask"][aatype], "atom14_gt_exists": gt_mask, "atom14_gt_positions": gt_pos,
+            "atom14_alt_gt_positions": torch.einsum("...rac,...rab->...rbc", gt_pos, Mr),
+            "atom14_alt_gt_exists": torch.einsum("...ra,...rab->...rb", gt_mask, Mr),
+            "atom14_atom_is_ambiguous": T["atom14_is_ambiguous"][aatype].to(mask37.dtype)}

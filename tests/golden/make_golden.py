@@ -134,6 +134,20 @@ def golden_triangle(N=24, seed=3):
     print("triangle golden written")
 
 
+def golden_dataset_atom14():
+    """make_atom14_masks + make_atom14_positions of the reference on the inputs of dataset_geom.npz."""
+    from openfold.data import data_transforms
+    g = np.load(os.path.join(HERE, "dataset_geom.npz"))
+    prot = {"aatype": torch.tensor(g["aatype"]), "all_atom_positions": torch.tensor(g["all_atom_positions"]),
+            "all_atom_mask": torch.tensor(g["all_atom_mask"])}
+    prot = data_transforms.make_atom14_masks(prot)
+    prot = data_transforms.make_atom14_positions(prot)
+    keys = ("atom14_atom_exists", "residx_atom14_to_atom37", "residx_atom37_to_atom14", "atom37_atom_exists", "atom14_gt_exists",
+            "atom14_gt_positions", "atom14_alt_gt_positions", "atom14_alt_gt_exists", "atom14_atom_is_ambiguous")
+    np.savez_compressed(os.path.join(HERE, "dataset_atom14.npz"), **{k: np_(prot[k]) for k in keys})
+    print("dataset_atom14 golden written", {k: (tuple(prot[k].shape), str(prot[k].dtype)) for k in keys})
+
+
 def golden_pair_transition(N=24, seed=6):
     """PairTransition (openfold/model/pair_transition.py:24-99, Algorithm 15), the pair-stack neighbour of the triangle
     operators: output, input gradient and every parameter gradient of the reference module."""
@@ -247,6 +261,9 @@ def golden_dataset_geom(F=2, N=40, seed=11):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset_geom":
         golden_dataset_geom()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset_atom14":
+        golden_dataset_atom14()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_F8":
         # second network capture: 8 frames (interior frames of the 5-tap conv axis, a last-frame cone that is clipped only

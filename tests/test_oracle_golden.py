@@ -183,3 +183,23 @@ def test_network_second_capture_f8():
         assert float((mine - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-9, name
         checked += 1
     assert checked > 100
+
+
+def test_atom14_transforms_vs_reference_golden():
+    """make_atom14_masks / make_atom14_positions: the oracle (permutation-matrix form) and the product's table gathers
+    (device-agnostic torch indexing, run here on host tensors) against the reference's outputs -- everything exact
+    (index gathers, 0/1 masks, positions are copies)."""
+    from dynamicpdb_amd.data import data_transforms as dt
+    gi, g = load_golden("dataset_geom.npz"), load_golden("dataset_atom14.npz")
+    aatype = torch.tensor(gi["aatype"])
+    pos, mask = torch.tensor(gi["all_atom_positions"]), torch.tensor(gi["all_atom_mask"])
+    ref = O.make_atom14(aatype, pos, mask)
+    prot = dt.make_atom14_positions(dt.make_atom14_masks({"aatype": aatype, "all_atom_positions": pos, "all_atom_mask": mask}))
+    for k in g:
+        want = g[k]
+        for name, got in (("oracle", ref[k]), ("product", prot[k])):
+            got = got.numpy()
+            assert got.shape == want.shape, (name, k)
+            assert np.array_equal(got.astype(want.dtype), want), (name, k)
+        assert prot[k].dtype == torch.from_numpy(want).dtype, k          # dtypes of the reference's features
+    assert float(np.abs(g["atom14_alt_gt_positions"] - g["atom14_gt_positions"]).max()) > 0       # some residues do swap
