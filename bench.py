@@ -181,7 +181,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt)
     tlog(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
-    roof = conv_kernel_roofline(model, trainer, batch, B, F, N) if (rank == 0 and args.mode == "all_frames") else None
+    # the instrumented extra step contains the gradient all-reduce: EVERY rank runs it (a collective issued by rank 0
+    # alone would pair with the other ranks' next step and hang the job at the end); rank 0 reports its own timings
+    roof = conv_kernel_roofline(model, trainer, batch, B, F, N) if args.mode == "all_frames" else None
     # second timed region: the engine's training-step mode (Trainer default).  Loss, gradients and the optimizer update
     # are identical (tests/test_network_gpu.py::test_last_frame_only_training_mode_equals_full); the conv tower only
     # evaluates the dependency cone of the last frame, the one frame the live loss terms and frame updates read.
