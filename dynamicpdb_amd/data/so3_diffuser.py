@@ -90,14 +90,25 @@ class SO3Diffuser:
             f'eps_{so3_conf.num_sigma}_omega_{so3_conf.num_omega}_min_sigma_{tag(so3_conf.min_sigma)}'
             f'_max_sigma_{tag(so3_conf.max_sigma)}_schedule_{so3_conf.schedule}')
         names = [os.path.join(cache_dir, n) for n in ('pdf_vals.npy', 'cdf_vals.npy', 'score_norms.npy')]
+        loaded = None
         if all(os.path.exists(n) for n in names):
-            self._pdf, self._cdf, self._score_norms = (np.load(n) for n in names)
+            try:    # several ranks may start at once on a fresh box: a file another rank is still writing is ignored
+                loaded = tuple(np.load(n) for n in names)
+                shape = (self.num_sigma, so3_conf.num_omega)
+                if any(a.shape != shape for a in loaded):
+                    loaded = None
+            except (OSError, ValueError, EOFError):
+                loaded = None
+        if loaded is not None:
+            self._pdf, self._cdf, self._score_norms = loaded
         else:
             self._pdf, self._cdf, self._score_norms = self._build_tables(so3_conf.num_omega)
             try:
                 os.makedirs(cache_dir, exist_ok=True)
                 for n, a in zip(names, (self._pdf, self._cdf, self._score_norms)):
-                    np.save(n, a)
+                    tmp = f"{n}.{os.getpid()}.tmp.npy"       # written whole, then renamed: readers never see a partial file
+                    np.save(tmp, a)
+                    os.replace(tmp, n)
             except OSError:
                 self._log.warning(f'could not write IGSO3 cache to {cache_dir}')
         self._score_scaling = np.sqrt(np.abs(
