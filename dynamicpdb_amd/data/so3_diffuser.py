@@ -19,47 +19,62 @@ def _series_terms(omega, L):
     return np.sin(arg), (ls + 0.5) * np.cos(arg)
 
 
-def igso3_expansion(omega, eps, L=1000, use_torch=False):
-    """f(omega; eps) = sum_l (2l+1) exp(-l(l+1)eps^2/2) sin((l+1/2)omega)/sin(omega/2)."""
-    lib = torch if use_torch else np
-    ls = lib.arange(L)
-    if use_torch:
-        ls = ls.to(omega.device)
-    if len(omega.shape) == 2:
-        ls, omega, eps = ls[None, None], omega[..., None], eps[..., None]
-    elif len(omega.shape) == 1:
-        ls, omega = ls[None], omega[..., None]
-    else:
+def _series_sums(omega, sigma, L):
+    """Host evaluation (float64) of the truncated IGSO(3) series and of the numerator of its omega-derivative:
+        f    = sum_l c_l(sigma) sin((l+1/2) omega) / sin(omega/2),      c_l = (2l+1) exp(-l(l+1) sigma^2 / 2)
+        dnum = sum_l c_l(sigma) d/domega [sin((l+1/2) omega) / sin(omega/2)]
+    omega and sigma broadcast against each other; the l axis is contracted in blocks so that a [n_sigma, n_omega]
+    request never materialises more than ~16 MB of terms."""
+    omega = np.asarray(omega, dtype=np.float64)
+    sigma = np.asarray(sigma, dtype=np.float64)
+    shape = np.broadcast(omega, sigma).shape
+    om = np.broadcast_to(omega, shape).reshape(-1)
+    sg = np.broadcast_to(sigma, shape).reshape(-1)
+    ls = np.arange(L, dtype=np.float64)
+    lo, dlo = np.sin(om / 2), 0.5 * np.cos(om / 2)
+    f, dnum = np.empty_like(om), np.empty_like(om)
+    step = max(1, (1 << 21) // max(L, 1))
+    for i in range(0, om.size, step):
+        o, s_ = om[i:i + step, None], sg[i:i + step, None]
+        c = (2 * ls + 1) * np.exp(-ls * (ls + 1) * s_ ** 2 / 2)
+        hi, dhi = np.sin(o * (ls + 0.5)), (ls + 0.5) * np.cos(o * (ls + 0.5))
+        l0, d0 = lo[i:i + step, None], dlo[i:i + step, None]
+        f[i:i + step] = (c * hi).sum(-1) / l0[:, 0]
+        dnum[i:i + step] = (c * (l0 * dhi - hi * d0)).sum(-1) / (l0[:, 0] ** 2)
+    return f.reshape(shape), dnum.reshape(shape)
+
+
+def _host(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def _check_rank(omega):
+    if np.ndim(omega) not in (1, 2):
         raise ValueError("Omega must be 1D or 2D.")
-    p = (2 * ls + 1) * lib.exp(-ls * (ls + 1) * eps ** 2 / 2) * lib.sin(omega * (ls + 1 / 2)) / lib.sin(omega / 2)
-    return p.sum(dim=-1) if use_torch else p.sum(axis=-1)
+
+
+def igso3_expansion(omega, eps, L=1000, use_torch=False):
+    """Truncated power series of the IGSO(3) density at rotation angle(s) `omega` for scale(s) `eps`
+    (reference module function src/data/so3_diffuser.py:9-49, same signature).  Host helper: evaluated in float64 numpy
+    whatever the container; `use_torch` only selects the return type (no autograd -- the differentiable, on-device
+    series is csrc/score.hip behind SO3Diffuser.torch_score)."""
+    _check_rank(omega)
+    f, _ = _series_sums(_host(omega), _host(eps), L)
+    return torch.as_tensor(f) if use_torch else f
 
 
 def density(expansion, omega, marginal=True):
-    if marginal:
-        return expansion * (1 - np.cos(omega)) / np.pi
-    return expansion / 8 / np.pi ** 2
+    """IGSO(3) density from its series (reference :52-68): over the angle (marginal) or over SO(3)."""
+    return expansion * (1 - np.cos(omega)) / np.pi if marginal else expansion / (8 * np.pi ** 2)
 
 
 def score(exp, omega, eps, L=1000, use_torch=False):
-    """d/d omega log f(omega; eps) by the quotient rule, regularised by +1e-4."""
-    lib = torch if use_torch else np
-    ls = lib.arange(L)
-    if use_torch:
-        ls = ls.to(omega.device)
-    ls = ls[None]
-    if len(omega.shape) == 2:
-        ls = ls[None]
-    elif len(omega.shape) > 2:
+    """d/d omega log f(omega; eps) with the reference's +1e-4 regulariser in the denominator (reference :71-117)."""
+    if np.ndim(omega) > 2:
         raise ValueError("Omega must be 1D or 2D.")
-    omega, eps = omega[..., None], eps[..., None]
-    hi = lib.sin(omega * (ls + 1 / 2))
-    dhi = (ls + 1 / 2) * lib.cos(omega * (ls + 1 / 2))
-    lo = lib.sin(omega / 2)
-    dlo = 1 / 2 * lib.cos(omega / 2)
-    dsig = (2 * ls + 1) * lib.exp(-ls * (ls + 1) * eps ** 2 / 2) * (lo * dhi - hi * dlo) / lo ** 2
-    dsig = dsig.sum(dim=-1) if use_torch else dsig.sum(axis=-1)
-    return dsig / (exp + 1e-4)
+    _, dnum = _series_sums(_host(omega), _host(eps), L)
+    out = dnum / (_host(exp) + 1e-4)
+    return torch.as_tensor(out) if use_torch else out
 
 
 def _rotvec_to_matrix(v):
@@ -191,16 +206,20 @@ class SO3Diffuser:
             if len(sigma) == 1:
                 return score_heads.igso3_score(vec[None], sigma, eps)[0]
             return score_heads.igso3_score(vec, sigma, eps)
-        omega = torch.linalg.norm(vec, dim=-1) + eps
+        # host tensors (dataset-side noising, SO3Diffuser.score): float64 numpy series, no autograd
+        vec64 = vec.detach().to(torch.float64)
+        omega = torch.linalg.norm(vec64, dim=-1) + eps
+        idx = self.t_to_idx(t_np)
         if self.use_cached_score:
-            score_norms_t = torch.tensor(self._score_norms[self.t_to_idx(t_np)]).to(vec.device)
-            omega_idx = torch.bucketize(omega, torch.tensor(self.discrete_omega[:-1]).to(vec.device))
+            score_norms_t = torch.as_tensor(self._score_norms[idx]).to(vec.device)
+            omega_idx = torch.bucketize(omega, torch.as_tensor(self.discrete_omega[:-1]).to(vec.device))
             omega_scores_t = torch.gather(score_norms_t, 1, omega_idx)
         else:
-            sigma = torch.tensor(self.discrete_sigma[self.t_to_idx(t_np)]).to(vec.device)
-            omega_vals = igso3_expansion(omega, sigma[:, None], use_torch=True)
-            omega_scores_t = score(omega_vals, omega, sigma[:, None], use_torch=True)
-        return omega_scores_t[..., None] * vec / (omega[..., None] + eps)
+            sigma = np.atleast_1d(self.discrete_sigma[idx])[:, None]
+            om = omega.cpu().numpy().reshape(sigma.shape[0], -1)
+            f, dnum = _series_sums(om, sigma, 1000)
+            omega_scores_t = torch.as_tensor((dnum / (f + 1e-4)).reshape(omega.shape)).to(vec.device)
+        return omega_scores_t[..., None] * vec64 / (omega[..., None] + eps)
 
     def score_scaling(self, t):
         return self._score_scaling[self.t_to_idx(t)]

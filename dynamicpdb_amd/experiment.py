@@ -101,6 +101,10 @@ class Trainer:
 
     def update_fn(self, batch, step_optimizer=True):
         self.opt.zero_grad(set_to_none=True)
+        for m in self.model.modules():
+            t = getattr(m, "_tower", None)
+            if t is not None:
+                t.reset_step()
         out = self.model(batch, last_frame_only=self.last_frame_only)
         loss, aux = loss_fn(out, batch, **self.loss_kwargs)
         loss.backward()
@@ -134,7 +138,7 @@ def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, 
     dt = 1.0 / num_t
     all_rigids, all_bb_prots, all_trans_0_pred, all_bb_0_pred = [], [], [], []
     z_iter = iter(z_draws) if z_draws is not None else None
-    angles = None
+    angles = rigid_pred = None
     with torch.no_grad():
         if self_condition:
             feats = set_t_feats(diffuser, feats, reverse_steps[0], like)
@@ -154,9 +158,11 @@ def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, 
                                                         diffuse_mask=diffuse_mask, center=center, noise_scale=noise_scale,
                                                         z_rot=zr, z_trans=zt)
             else:
+                # last step (t == min_t): the state becomes the network's own frame prediction (:1502-1504).  Like the
+                # reference, `rigid_pred` keeps the PREVIOUS step's prediction here (it is only assigned in the branch
+                # above), which is what the x0 traces below are built from.
                 model_out = model(feats)
-                rigid_pred = model_out['rigids']
-                feats['rigids_t'] = rigid_pred.clone()
+                feats['rigids_t'] = model_out['rigids'].clone()
             fixed_mask = feats['fixed_mask'].float() * feats['res_mask'].float()
             diffuse_mask = (1 - feats['fixed_mask'].float()) * feats['res_mask'].float()
             angles = model_out['angles']
@@ -164,7 +170,9 @@ def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, 
                 all_rigids.append(model_out['rigids'].cpu().numpy())
                 trans_pred_0 = diffuse_mask[..., None] * rigid_pred[..., 4:] + fixed_mask[..., None] * feats['rigids_t'][..., 4:]
                 all_trans_0_pred.append(trans_pred_0.cpu().numpy())
-                all_bb_0_pred.append(model_out['atom37'].cpu().numpy())
+                # all_atom.compute_backbone_atom37(rigid_pred, aatype, angles) (:1515-1520): all atoms of the predicted frames
+                from .model import geometry as G
+                all_bb_0_pred.append(G.frames_to_atoms_hip(rigid_pred, angles, feats['aatype'])[1].cpu().numpy())
             all_bb_prots.append(model_out['atom37'].cpu().numpy())
     flip = lambda x: np.flip(np.stack(x), (0,))
     ret = {'prot_traj': flip(all_bb_prots)}

@@ -211,23 +211,29 @@ class ConvTowerFn(Function):
     fp32) and handed to autograd once, by the application whose backward runs last."""
 
     @staticmethod
-    def forward(ctx, x, tower, last_frame_only, *params):
+    def forward(ctx, x, tower, last_frame_only, track, *params):
         """last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
         dependency cone of that frame (ops.ConvTower.cone); the other output frames are returned as zeros and the
-        incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller)."""
+        incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller).
+        track: a backward will follow (grad mode on and something requires grad, decided by the caller -- inside
+        Function.forward grad mode is always off).  Only then are the activations kept and the application counted in
+        `tower.pending`; a no_grad pass (sampling, self-conditioning, evaluation) leaves no trace in the tower."""
         Wn, F, N, C = x.shape
         g = ops.Grid(Wn, F, N, x.device)
         tower.refresh()
         h0 = g.alloc(C)
         g.interior(h0).copy_(x)
-        h4, saved = tower.forward(g, h0, last_frame_only=last_frame_only)
-        ctx.tower, ctx.g, ctx.saved, ctx.last = tower, g, saved, last_frame_only
-        tower.pending += 1
+        h4, saved = tower.forward(g, h0, save=track, last_frame_only=last_frame_only)
+        ctx.tower, ctx.g, ctx.saved, ctx.last, ctx.track = tower, g, saved, last_frame_only, track
+        if track:
+            tower.pending += 1
         return g.interior(h4).contiguous()
 
     @staticmethod
     def backward(ctx, gy):
         tower, g = ctx.tower, ctx.g
+        if not ctx.track or ctx.saved is None:
+            raise RuntimeError("ConvTowerFn.backward: forward ran without activation tracking (no_grad) or twice")
         gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]), zero=ctx.last)
         if ctx.last:
             g.interior(gt)[:, -1:].copy_(gy[:, -1:])
@@ -237,9 +243,10 @@ class ConvTowerFn(Function):
         ctx.saved = None
         tower.pending -= 1
         grads = [None] * (2 * len(tower.weights))
-        if tower.pending == 0:
+        if tower.pending <= 0:
+            tower.pending = 0
             grads = tower.collect_grads()
-        return (g.interior(g0).contiguous(), None, None, *grads)
+        return (g.interior(g0).contiguous(), None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

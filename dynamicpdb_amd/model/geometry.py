@@ -91,39 +91,3 @@ def frames_to_atoms_hip(t7, angles, aatype):
                                                 _p(T["atom37_mask"]), _p(a14), _p(a37), c_int64(P), _lib.stream()),
                "dfold_frames_to_atoms")
     return a14.view(lead + (14, 3)), a37.view(lead + (37, 3))
-
-
-def frames_to_atoms(t7, angles, aatype):
-    """feats.torsion_angles_to_frames (openfold/utils/feats.py:165-228) + all_atom.frames_to_atom14_pos
-    (src/data/all_atom.py:114-154) + atom14_to_atom37 (src/model/Dfold_network_dynamic.py:574-594).
-    t7 [..,7], angles [..,7,2] (sin,cos), aatype [..] int64 -> atom14 [..,14,3], atom37 [..,37,3].
-    Integer gathers use the reference's own tables (dynamicpdb_amd/data/residue_tables.npz)."""
-    T = residue_tables(t7.device)
-    dt = t7.dtype
-    d44 = T["default_frames"][aatype].to(dt)
-    Rd, td = d44[..., :3, :3], d44[..., :3, 3]
-    bb = torch.zeros(angles.shape[:-2] + (1, 2), dtype=dt, device=t7.device)
-    bb[..., 1] = 1
-    al = torch.cat([bb, angles], -2)
-    Rt = torch.zeros(al.shape[:-1] + (3, 3), dtype=dt, device=t7.device)
-    Rt[..., 0, 0] = 1
-    Rt[..., 1, 1] = al[..., 1]
-    Rt[..., 1, 2] = -al[..., 0]
-    Rt[..., 2, 1] = al[..., 0]
-    Rt[..., 2, 2] = al[..., 1]
-    Rf = Rd @ Rt
-    R_l, t_l = [Rf[..., i, :, :] for i in range(8)], [td[..., i, :] for i in range(8)]
-    for i in (5, 6, 7):
-        R_l[i], t_l[i] = R_l[i - 1] @ R_l[i], rot_apply(R_l[i - 1], t_l[i]) + t_l[i - 1]
-    Rb, tb = torch.stack(R_l, -3), torch.stack(t_l, -2)
-    Rg = quat_to_rot(t7[..., :4])[..., None, :, :]
-    Rall, tall = Rg @ Rb, rot_apply(Rg, tb) + t7[..., None, 4:]
-    grp = T["atom14_group"][aatype]
-    Ra = torch.gather(Rall, -3, grp[..., None, None].expand(grp.shape + (3, 3)))
-    ta = torch.gather(tall, -2, grp[..., None].expand(grp.shape + (3,)))
-    pos = rot_apply(Ra, T["atom14_pos"][aatype].to(dt)) + ta
-    atom14 = pos * T["atom14_mask"][aatype].to(dt)[..., None]
-    i37 = T["atom37_to_atom14"][aatype]
-    atom37 = torch.gather(atom14, -2, i37[..., None].expand(i37.shape + (3,)))
-    atom37 = atom37 * T["atom37_mask"][aatype].to(dt)[..., None]
-    return atom14, atom37

@@ -73,7 +73,8 @@ class ConvNet(nn.Module):
         """x bf16 [W,F,N,C] -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode)."""
         ws, bs = self._params()
         inter = [p for pair in zip(ws, bs) for p in pair]
-        return F_.ConvTowerFn.apply(x, self.tower(), bool(last_frame_only), *inter)
+        track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in inter))
+        return F_.ConvTowerFn.apply(x, self.tower(), bool(last_frame_only), bool(track), *inter)
 
     def forward(self, x):
         _require_cuda(x)

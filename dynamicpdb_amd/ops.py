@@ -384,6 +384,13 @@ class ConvTower:
         for t in self.dwg + self.db:
             t.zero_()
 
+    def reset_step(self):
+        """Start of a training step: forget applications whose backward never ran (an exception between forward and
+        backward, a forward whose loss was dropped) so that their count and partial sums cannot leak into this step."""
+        if self.pending:
+            self.pending = 0
+            self.zero_grad()
+
     @staticmethod
     def cone(F, i):
         """Frame ranges of residual block i (0..3) when only the LAST frame of the tower output is consumed (training:
@@ -399,7 +406,7 @@ class ConvTower:
         """h0: padded grid [Wn,Fp,Wp,C] bf16.  Returns (h4, saved).  last_frame_only: compute the dependency cone of
         the last output frame only (h4 is then valid on frame F-1 alone, zero elsewhere)."""
         C = h0.shape[-1]
-        saved = [h0]
+        saved = [h0] if save else None
         h = h0
         for i in range(4):
             (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else ((0, g.F), (0, g.F))
@@ -409,7 +416,8 @@ class ConvTower:
             hn, v = g.alloc(C), g.alloc(C)
             conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v,
                         f_lo=l2, nf=n2, ws=ws)
-            saved += [u, v, hn]
+            if save:
+                saved += [u, v, hn]
             h = hn
         return h, saved
 

@@ -15,6 +15,7 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=True, foreach=False)
         self._chunk = None
         self._prefix = {}
+        self._tables = {}
 
     def _init_state(self, p):
         st = self.state[p]
@@ -66,12 +67,22 @@ class FusedAdam(torch.optim.Adam):
                         acc += (n + self._chunk - 1) // self._chunk
                         cs.append(acc)
                     pre = self._prefix[key] = (torch.tensor(cs, dtype=torch.int32).to(dev), acc)
-                table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                # the device pointer table only changes when a tensor is re-allocated (grads with set_to_none=True come
+                # back from the caching allocator at the same addresses in steady state): re-upload on change only
+                tkey = tuple(rows)
+                ent = self._tables.get(key)
+                if ent is None or ent[0] != tkey:
+                    host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+                    ent = self._tables[key] = (tkey, host.to(dev, non_blocking=True), host)
+                table = ent[1]
                 b1, b2 = group["betas"]
                 _lib.check(L.dfold_adam_amsgrad(_p(table), _p(pre[0]), c_int32(len(rows)), c_int32(pre[1]), c_double(group["lr"]),
                                                 c_double(b1), c_double(b2), c_double(group["eps"]), c_int64(step0 + 1),
                                                 _lib.stream()), "dfold_adam_amsgrad")
                 for p in ps:
                     self.state[p]["step"] += 1
+                # the kernel writes the parameters through raw pointers: tell autograd / the bf16 weight caches
+                # (functional.WeightCache, ops.ConvTower.refresh key on (data_ptr, _version)) that they changed
+                torch.autograd.graph.increment_version(ps)
                 del keep
         return loss

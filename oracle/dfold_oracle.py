@@ -6,9 +6,9 @@ for the HIP path: only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import it.  The product path (dynamicpdb_amd/) never does.
 
 Parity status: PINNED against the reference's own code executed in the build
-container -- tests/test_oracle_vs_reference.py compares every function here with
-the reference modules imported from /root/reference (oracle/ref_harness), and
-tests/golden/*.npz hold reference outputs minted by tests/golden/make_golden.py.
+container -- tests/golden/*.npz hold outputs of the reference modules imported from
+/root/reference (oracle/ref_harness), minted by tests/golden/make_golden.py, and
+tests/test_oracle_golden.py compares every function here with them.
 The reference ships no tests / golden vectors of its own.
 
 Every function cites the reference file:line it restates (paths relative to
