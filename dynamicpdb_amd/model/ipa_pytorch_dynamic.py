@@ -98,6 +98,13 @@ class BackboneUpdate(nn.Module):
         return F_.linear(s.to(BF16), self.linear.weight, self.linear.bias, out_fp32=True)
 
 
+def _relu(x):
+    y = torch.relu(x)
+    if ops.RELU_MASK_LOG is not None:
+        ops.RELU_MASK_LOG.append((y > 0).float().cpu())
+    return y
+
+
 class AngleResnetBlock(nn.Module):
     def __init__(self, c_hidden):
         super().__init__()
@@ -119,12 +126,14 @@ class AngleResnet(nn.Module):
     def forward(self, s, s_initial):
         _require_cuda(s)
         s, s_initial = s.to(BF16), s_initial.to(BF16)
-        a = F_.linear(torch.relu(s), self.linear_in.weight, self.linear_in.bias) + \
-            F_.linear(torch.relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
+        a = F_.linear(_relu(s), self.linear_in.weight, self.linear_in.bias) + \
+            F_.linear(_relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
         for l in self.layers:
-            h = F_.linear(torch.relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
+            h = F_.linear(_relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
+            if ops.RELU_MASK_LOG is not None:
+                ops.RELU_MASK_LOG.append((h > 0).float().cpu())
             a = a + F_.linear(h, l.linear_2.weight, l.linear_2.bias)
-        out = F_.linear(torch.relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
+        out = F_.linear(_relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
         out = out.view(out.shape[:-1] + (-1, 2))
         unnorm = out
         denom = torch.sqrt(torch.clamp(torch.sum(out ** 2, dim=-1, keepdim=True), min=self.eps))

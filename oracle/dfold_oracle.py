@@ -121,9 +121,50 @@ def _q(x):
     return x + (x.detach().to(torch.bfloat16).to(x.dtype) - x.detach())
 
 
-def linear(P, name, x):
+class _GradRound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _qg(x):
+    """identity whose GRADIENT is rounded to bf16: the engine stores activation gradients in bf16 between kernels
+    (conv tower dgrad outputs, dx of every dense layer, the incoming gradient of every dense layer's output)."""
+    if not EMULATE_BF16_OPERANDS or not x.requires_grad:
+        return x
+    return _GradRound.apply(x)
+
+
+def _qs(x):
+    """a bf16 storage point of the engine: value rounded on the way forward, gradient rounded on the way back"""
+    return _q(_qg(x))
+
+
+# Optional ReLU-mask feed (GPU gradient-parity test): a list of 0/1 tensors, consumed in call order by every ReLU of the
+# path (conv tower: inner / outer activation of each residual pair; AngleResnet).  With a feed, relu(x) = x * mask --
+# the engine's own stored masks -- so that a pre-activation within bf16 rounding of zero takes the same branch on both
+# sides and the comparison measures the kernels, not which side of zero a rounding fell.  None = plain ReLU.
+RELU_MASK_FEED = None
+
+
+def _relu(x):
+    if RELU_MASK_FEED is None:
+        return F.relu(x)
+    m = RELU_MASK_FEED.pop(0)
+    return x * m.to(x.dtype).reshape(x.shape)
+
+
+def linear(P, name, x, quant=True):
+    """quant=False: the engine evaluates this layer on fp32 operands (the k <= 14 wide embedder inputs, csrc/embed.hip);
+    only matters under EMULATE_BF16_OPERANDS."""
     b = P.get(name + ".bias")
-    return F.linear(_q(x), _q(P[name + ".weight"].to(x.dtype)), None if b is None else b.to(x.dtype))
+    w = P[name + ".weight"].to(x.dtype)
+    y = F.linear(_qs(x), _q(w), None if b is None else b.to(x.dtype)) if quant else F.linear(x, w, None if b is None else b.to(x.dtype))
+    return _qg(y)
 
 
 def my_layer_norm(x, eps=1e-4):
@@ -136,7 +177,7 @@ def my_layer_norm(x, eps=1e-4):
 
 def embedder(P, name, x):
     """Linear-SiLU-Linear-MyLayerNorm-SiLU, ipa_pytorch_dynamic.py:757-796."""
-    h = F.silu(linear(P, name + ".0", x))
+    h = F.silu(linear(P, name + ".0", x, quant=False))
     h = linear(P, name + ".2", h)
     return F.silu(my_layer_norm(h))
 
@@ -148,20 +189,21 @@ def convnet(P, name, x):
     for i in (1, 2, 3, 4):
         w0, b0 = P[f"{name}.conv{i}.0.weight"].to(x.dtype), P[f"{name}.conv{i}.0.bias"].to(x.dtype)
         w2, b2 = P[f"{name}.conv{i}.2.weight"].to(x.dtype), P[f"{name}.conv{i}.2.bias"].to(x.dtype)
-        y = F.relu(F.conv2d(_q(h), _q(w0), b0, padding=2))
-        y = F.relu(F.conv2d(_q(y), _q(w2), b2, padding=2))
-        h = y + _q(h)
-    return h.squeeze(0).permute(1, 2, 0)
+        h = _qs(h)          # block input: a stored bf16 grid; its gradient (conv path + skip path) is stored in bf16 too
+        y = _relu(_qg(F.conv2d(h, _q(w0), b0, padding=2)))
+        y = _relu(_qg(F.conv2d(_q(y), _q(w2), b2, padding=2)))
+        h = y + h
+    return _q(h).squeeze(0).permute(1, 2, 0)
 
 
 def angle_resnet(P, name, s, s_initial, eps=1e-12):
     """AngleResnet openfold/model/structure_module.py:114-158 (2 blocks, 7 angles)."""
-    a = linear(P, name + ".linear_in", F.relu(s)) + linear(P, name + ".linear_initial", F.relu(s_initial))
+    a = linear(P, name + ".linear_in", _relu(s)) + linear(P, name + ".linear_initial", _relu(s_initial))
     for l in (0, 1):
-        h = linear(P, f"{name}.layers.{l}.linear_1", F.relu(a))
-        h = linear(P, f"{name}.layers.{l}.linear_2", F.relu(h))
+        h = linear(P, f"{name}.layers.{l}.linear_1", _relu(a))
+        h = linear(P, f"{name}.layers.{l}.linear_2", _relu(h))
         a = a + h
-    out = linear(P, name + ".linear_out", F.relu(a))
+    out = linear(P, name + ".linear_out", _relu(a))
     out = out.reshape(out.shape[:-1] + (-1, 2))
     denom = torch.sqrt(torch.clamp((out * out).sum(-1, keepdim=True), min=eps))
     return out, out / denom
@@ -178,8 +220,8 @@ def ipa(P, name, s, z, t7, mask, inf=1e5, eps=1e-8, return_attn=False):
     """s[F,N,c_s], z[N,N,c_z] (no frame axis; broadcast), t7[F,N,7], mask[F,N]."""
     H, C, PQ, PV = IPA_H, IPA_C, IPA_PQ, IPA_PV
     Fr, N = s.shape[0], s.shape[1]
-    q = linear(P, name + ".linear_q", s).reshape(Fr, N, H, C)                       # :350-354
-    kv = linear(P, name + ".linear_kv", s).reshape(Fr, N, H, 2 * C)                 # :351-360
+    q = _q(linear(P, name + ".linear_q", s)).reshape(Fr, N, H, C)                   # :350-354
+    kv = _q(linear(P, name + ".linear_kv", s)).reshape(Fr, N, H, 2 * C)             # :351-360
     k, v = kv[..., :C], kv[..., C:]
 
     def points(lin, npts):                                                          # :363-390
@@ -202,7 +244,7 @@ def ipa(P, name, s, z, t7, mask, inf=1e5, eps=1e-8, return_attn=False):
     sq_mask = inf * (mask[:, :, None] * mask[:, None, :] - 1)                       # :426-427
     a = torch.softmax(a + sq_mask[:, None], dim=-1)                                 # :443-444
 
-    o = torch.einsum("fhij,fjhc->fihc", a, v).reshape(Fr, N, H * C)                 # :452-457
+    o = torch.einsum("fhij,fjhc->fihc", _q(a), v).reshape(Fr, N, H * C)             # :452-457
     o_pt_g = torch.einsum("fhij,fjhpx->fihpx", a, v_pts)                            # :460-469 (global frame)
     o_pt_l = rigid_invert_apply(t7[:, :, None, None, :], o_pt_g)                    # :481
     n_l = torch.sqrt((o_pt_l ** 2).sum(-1) + eps).reshape(Fr, N, H * PV)            # :484-486
@@ -210,7 +252,10 @@ def ipa(P, name, s, z, t7, mask, inf=1e5, eps=1e-8, return_attn=False):
     o_pt_l = o_pt_l.reshape(Fr, N, H * PV, 3)
     o_pt_g = o_pt_g.reshape(Fr, N, H * PV, 3)
     pair_z = linear(P, name + ".down_z", z)                                         # :498 [N,N,32]
-    o_pair = torch.einsum("fhij,ijc->fihc", a, pair_z).reshape(Fr, N, -1)           # :499-502
+    # (the engine adds down_z's bias after the aggregation -- rows of `a` sum to 1 -- so the bf16 operand is bias-free)
+    bz = P[name + ".down_z.bias"].to(s.dtype)
+    o_pair = (torch.einsum("fhij,ijc->fihc", _q(a), _q(pair_z - bz)) + bz * a.sum(-1).permute(0, 2, 1)[..., None]
+              if EMULATE_BF16_OPERANDS else torch.einsum("fhij,ijc->fihc", a, pair_z)).reshape(Fr, N, -1)   # :499-502
     feats = [o, o_pt_l[..., 0], o_pt_l[..., 1], o_pt_l[..., 2], n_l, o_pair,
              o_pt_g[..., 0], o_pt_g[..., 1], o_pt_g[..., 2], n_g]                   # :504
     out = linear(P, name + ".linear_out", torch.cat(feats, -1))                     # :510-514

@@ -37,7 +37,13 @@ def subsample(g, stride=9973):
     return flat[::stride].clone()
 
 
-def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973):
+DIFFUSER_KEYS = ("rigids_t", "rot_score", "trans_score", "rot_score_scaling", "trans_score_scaling")
+
+
+def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973, compact=False):
+    """compact=True (BASELINE-sized captures): only the diffuser-dependent inputs are stored; every other input is
+    regenerated bit-identically on the test side from dynamicpdb_amd.synthetic.synthetic_window(seed_x, F, N, t) and
+    pinned by a float64 checksum."""
     from src.data.se3_diffuser import SE3Diffuser
     import train_DFOLD_dynamics as T
     conf = ref_import.make_conf(F, cache_dir=".cache/")
@@ -74,7 +80,13 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_str
         h.remove()
     with torch.no_grad():
         out = model({k: v.clone() for k, v in win.items()})
-    fix = {f"in_{k}": np_(v) for k, v in win.items()}
+    if compact:
+        fix = {f"in_{k}": np_(win[k]) for k in DIFFUSER_KEYS}
+        # numpy's sum: single-threaded pairwise, the same on a host with any number of cores (torch's is not)
+        fix["in_checksum"] = np.array([float(np.asarray(win[k].numpy(), dtype=np.float64).sum()) for k in sorted(win)
+                                       if k not in DIFFUSER_KEYS])
+    else:
+        fix = {f"in_{k}": np_(v) for k, v in win.items()}
     for k in ("angles", "unorm_angles", "rot_score", "trans_score", "rigids", "atom37", "atom14", "rigid_update"):
         fix[f"out_{k}"] = np_(out[k])
     if captures:
@@ -95,9 +107,40 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_str
         fix[f"gnorm_{name}"] = np_(g.double().norm())
         fix[f"gsub_{name}"] = np_(subsample(g, grad_stride) if g.numel() > 70000 else g)
     fix["meta"] = np.array([F, N, seed_w, seed_x, grad_stride], np.int64)
+    fix["t"] = np.array([t])
     np.savez_compressed(os.path.join(HERE, f"network_F{F}_N{N}.npz"), **fix)
     print("network golden: loss", float(loss), {k: float(v) for k, v in aux.items() if "batch" not in k})
     return exp
+
+
+def golden_sampler(F=3, N=16, seed_w=4, seed_x=8, num_t=3, noise_scale=0.5, seed_z=77):
+    """Experiment.inference_fn of the reference (train_DFOLD_dynamics.py:1425-1547), num_t model forwards + the
+    self-conditioning pass + (num_t - 1) host reverse steps, with the numpy draws of the reverse steps recorded in the
+    reference's order (so3 then r3 per step, se3_diffuser.py:184-204)."""
+    import train_DFOLD_dynamics as T
+    conf = ref_import.make_conf(F, cache_dir=".cache/")
+    conf.data.num_t = num_t
+    exp = T.Experiment(conf=conf)
+    exp.model.load_state_dict(synthetic.seeded_state_dict(seed_w), strict=True)
+    win = synthetic.synthetic_window(seed_x, F, N, t=1.0, diffuser=exp.diffuser)
+    np.random.seed(seed_z - 1)
+    prior = exp.diffuser.sample_ref(n_samples=F * N, as_tensor_7=True)["rigids_t"].reshape(F, N, 7).to(torch.float32)
+    init = {k: v.clone() for k, v in win.items()}
+    init["rigids_t"] = prior
+    np.random.seed(seed_z)
+    draws = [(np.random.normal(size=(F, N, 3)), np.random.normal(size=(F, N, 3))) for _ in range(num_t - 1)]
+    np.random.seed(seed_z)
+    ret = exp.inference_fn({k: v.clone() for k, v in init.items()}, num_t=num_t, min_t=0.01, center=True, aux_traj=True,
+                           self_condition=True, noise_scale=noise_scale)
+    fix = {f"in_{k}": np_(v) for k, v in init.items()}
+    for i, (zr, zt) in enumerate(draws):
+        fix[f"z_rot_{i}"], fix[f"z_trans_{i}"] = zr, zt
+    for k in ("prot_traj", "rigid_traj", "trans_traj", "rigid_0_traj", "psi_pred"):
+        fix[f"out_{k}"] = np_(ret[k])
+    fix["meta"] = np.array([F, N, seed_w, seed_x, num_t], np.int64)
+    fix["noise_scale"] = np.array([noise_scale])
+    np.savez_compressed(os.path.join(HERE, f"sampler_F{F}_N{N}.npz"), **fix)
+    print("sampler golden written", {k: v.shape for k, v in fix.items() if k.startswith("out_")})
 
 
 def golden_triangle(N=24, seed=3):
@@ -269,6 +312,17 @@ if __name__ == "__main__":
         # second network capture: 8 frames (interior frames of the 5-tap conv axis, a last-frame cone that is clipped only
         # in the first block), other seeds / diffusion time; outputs, loss, gradient norms and sparse gradient samples only
         golden_network(F=8, N=16, seed_w=2, seed_x=5, t=0.3, captures=False, grad_stride=39989)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_cfg1":
+        # BASELINE config 1 shape: one window of 16 frames x N_res 96 (the reference's CPU-runnable configuration)
+        golden_network(F=16, N=96, seed_w=11, seed_x=12, t=0.4, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_n256":
+        # run_train.sh window (frame_time = 2) at the headline N_res = 256
+        golden_network(F=2, N=256, seed_w=13, seed_x=14, t=0.6, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sampler":
+        golden_sampler()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pair_transition":
         golden_pair_transition()

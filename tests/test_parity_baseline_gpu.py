@@ -1,0 +1,308 @@
+"""Parity at BASELINE-sized configurations.
+
+* the full step (forward, loss, backward) against golden vectors minted from the reference's own code at BASELINE config 1
+  (one window, 16 frames x N_res 96: tests/golden/network_F16_N96.npz) and at the run_train.sh window on the headline
+  N_res (2 frames x N_res 256: network_F2_N256.npz) -- reference lines train_DFOLD_dynamics.py:660-667,1182-1400;
+* parameter gradients against the oracle with the engine's bf16 operand rounding emulated AND the engine's own ReLU masks
+  fed back (oracle.RELU_MASK_FEED): the SURVEY 8c bf16 class (rel-L2 <= 3e-2);
+* the production-shape conv launches (config-3 grid: 8 windows x 32 frames x N_res 256, 1280 <-> 640 channels) -- forward,
+  data gradient, weight gradient (the 256x320 kernel's role 2) and the deterministic split-K of the narrow launches --
+  against fp64 sums on sampled output cells / weight slices."""
+import numpy as np
+import pytest
+import torch
+
+from util import canon_quat, compact_window, load_golden, max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(F, seed_w, dev):
+    from dynamicpdb_amd import synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    model.load_state_dict(synthetic.seeded_state_dict(seed_w), strict=True)
+    return model.to(dev), diffuser
+
+
+def _step_vs_golden(name):
+    from dynamicpdb_amd import experiment
+    dev = torch.device(DEV)
+    g = load_golden(name)
+    w, (F, N, seed_w, stride) = compact_window(g)
+    model, _ = _build(F, seed_w, dev)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    out = model({k: v.clone() for k, v in wd.items()})
+    batch = {k: v[None] for k, v in wd.items()}
+    batch["t"] = wd["t"].reshape(1)
+    loss, aux = experiment.loss_fn({k: v[None] for k, v in out.items()}, batch)
+    loss.backward()
+    # forward outputs: the bf16-path class of DESIGN.md section 2
+    for k in ("angles", "unorm_angles", "rigid_update"):
+        assert rel_l2(out[k], g["out_" + k]) < 2e-2, (name, k, rel_l2(out[k], g["out_" + k]))
+    assert rel_l2(out["trans_score"], g["out_trans_score"]) < 1e-3
+    assert rel_l2(out["rot_score"], g["out_rot_score"]) < 1e-2
+    assert max_abs(out["atom14"][..., :3, :], g["out_atom14"][..., :3, :]) < 1e-2
+    # side-chain atoms inherit the torsion error x lever arm; a torsion whose raw 2-vector is short is ill-conditioned
+    # (normalising amplifies the bf16 noise), so single atoms may move by most of an Angstrom while the RMS stays at the
+    # SURVEY 8c coordinate class.  The atom builder itself is exact: the oracle's builder on the ENGINE's frames/torsions
+    # reproduces the engine's atoms (kernel check), so this distance is propagated torsion error only.
+    d37 = (out["atom37"].cpu().double() - torch.tensor(g["out_atom37"]).double())
+    rms = float(d37.pow(2).sum(-1).mean().sqrt())
+    print(f"[{name}] atom37 rms {rms:.4f} A, max {float(d37.abs().max()):.3f} A")
+    assert rms < 5e-2 and float(d37.abs().max()) < 1.5
+    from oracle import dfold_oracle as O
+    _, a37 = O.frames_to_atoms(out["rigids"].detach().cpu(), out["angles"].detach().cpu(), w["aatype"].long())
+    assert max_abs(out["atom37"], a37) < 2e-3
+    assert torch.equal(out["atom37"].cpu() == 0, torch.tensor(g["out_atom37"]) == 0)       # integer gathers bit-exact
+    assert max_abs(canon_quat(out["rigids"].cpu()), canon_quat(g["out_rigids"])) < 5e-3
+    assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    for k, v in aux.items():
+        assert abs(float(v) - float(g["aux_" + k])) < 2e-2 * max(1.0, abs(float(g["aux_" + k]))), k
+    # gradients: norm and sampled entries of every parameter
+    P = dict(model.named_parameters())
+    stats = {}
+    for k in g:
+        if not k.startswith("gsub_"):
+            continue
+        n = k[5:]
+        gr, ref_norm = P[n].grad, float(g["gnorm_" + n])
+        if ref_norm < 1e-6:
+            assert gr is None or float(gr.double().norm()) < 1e-4, n
+            continue
+        assert gr is not None, n
+        ref = torch.tensor(g[k]).double()
+        mine = (gr.reshape(-1)[::stride] if gr.numel() > 70000 else gr).double().cpu().reshape(ref.shape)
+        stats[n] = (abs(float(gr.double().norm()) - ref_norm) / ref_norm, float((mine - ref).norm() / (ref.norm() + 1e-30)))
+    for k in g:
+        if k.startswith("gradnone_"):
+            assert P[k[9:]].grad is None, k
+    return stats
+
+
+def _report(stats, tag):
+    rel = sorted(v[1] for v in stats.values())
+    nrm = sorted(v[0] for v in stats.values())
+    worst = max(stats.items(), key=lambda kv: kv[1][1])
+    print(f"[{tag}] grad rel-L2 median {rel[len(rel) // 2]:.4f} max {rel[-1]:.4f} ({worst[0]}); "
+          f"norm err median {nrm[len(nrm) // 2]:.4f} max {nrm[-1]:.4f}")
+    return rel, nrm
+
+
+def test_step_vs_reference_golden_config1():
+    """BASELINE config 1 (16 frames x N_res 96, one window) against the reference's own fp32 run."""
+    stats = _step_vs_golden("network_F16_N96.npz")
+    rel, nrm = _report(stats, "cfg1 F16 N96")
+    # fp32 reference, bf16-storage engine, every ReLU / min() branch free to differ: the class of DESIGN.md section 2
+    # (a flipped branch is an O(1) error on that unit).  The mask-aligned comparison below, at this same size, is the
+    # tight one; measured here: median 0.07, max 0.14, norms within 7 %.
+    assert nrm[-1] < 0.1 and rel[-1] < 0.25 and rel[len(rel) // 2] < 0.12, (rel[len(rel) // 2], rel[-1], nrm[-1])
+
+
+def test_step_vs_reference_golden_nres256():
+    """run_train.sh window (frame_time 2) at N_res 256 against the reference's own fp32 run."""
+    stats = _step_vs_golden("network_F2_N256.npz")
+    rel, nrm = _report(stats, "F2 N256")
+    # (2 frames: every gradient is a sum over the 256 positions of the last frame only; measured median 0.05, max 0.31 on
+    # an AngleResnet weight whose two ReLUs sit right in front of the ill-conditioned torsion normalisation)
+    assert nrm[-1] < 0.1 and rel[-1] < 0.4 and rel[len(rel) // 2] < 0.12, (rel[len(rel) // 2], rel[-1], nrm[-1])
+
+
+@pytest.mark.parametrize("gname", ["network_F3_N16.npz", "network_F8_N16.npz", "network_F2_N256.npz", "network_F16_N96.npz"])
+def test_gradients_mask_aligned_oracle(gname):
+    """Every parameter gradient of the full step against the oracle that (a) rounds values AND gradients to bf16 at the
+    engine's storage points (operands of every dense contraction, activation gradients between kernels:
+    oracle._q / _qg) and (b) takes each ReLU's branch from the ENGINE's stored mask: what is left is kernel arithmetic
+    (fp32 accumulation order, roundings that straddle a bf16 tie) -- SURVEY 8c's bf16 class, rel-L2 <= 3e-2 per tensor."""
+    from oracle import dfold_oracle as O
+    from dynamicpdb_amd import experiment, ops, synthetic
+    from util import window_from_golden
+    dev = torch.device(DEV)
+    g = load_golden(gname)
+    F, N, seed_w = [int(v) for v in g["meta"][:3]]
+    model, _ = _build(F, seed_w, dev)
+    if "in_checksum" in g:      # BASELINE-sized captures (config 1; run_train.sh window at N_res 256): inputs from the seed
+        w = {k: v.to(dev) for k, v in compact_window(g)[0].items()}
+    else:
+        w = window_from_golden(g, dev)
+    ops.RELU_MASK_LOG = []
+    try:
+        out = model({k: v.clone() for k, v in w.items()})
+        masks = ops.RELU_MASK_LOG
+    finally:
+        ops.RELU_MASK_LOG = None
+    assert len(masks) == 4 * 8 + 7, len(masks)       # 4 tower applications x 8 ReLUs + AngleResnet's 7
+    batch = {k: v[None] for k, v in w.items()}
+    batch["t"] = w["t"].reshape(1)
+
+    def readout(loss_fn, o, b, lead):
+        """translation-x0 + rotation-score terms of the reference loss (train_DFOLD_dynamics.py:1248-1340) plus a SMOOTH
+        torsion read-out on the raw (un-normalised) 2-vectors of the last frame.  The reference's torsion term normalises
+        them first (openfold/utils/loss.py:58-59): its gradient ~ 1/|raw| is dominated by the few torsions whose raw
+        vector is short, where the forward's own bf16-level difference is amplified 10-100x -- a conditioning property
+        of that read-out (measured: it alone moves whole gradient tensors by 4 % at 112 torsions, 40 % at 1792), not of
+        any kernel.  The real loss is compared in test_step_vs_reference_golden_* above."""
+        l, _ = loss_fn(o, b, torsion_w=0.0)
+        raw, gt = o["unorm_angles"], b["torsion_angles_sin_cos"].to(o["unorm_angles"].dtype)
+        m = b["torsion_angles_mask"].to(raw.dtype)[..., None]
+        sel = (slice(None), -1) if lead else (-1,)
+        return l + (((raw - gt) ** 2) * m)[sel].mean()
+
+    loss = readout(experiment.loss_fn, {k: v[None] for k, v in out.items()}, batch, True)
+    loss.backward()
+    O.EMULATE_BF16_OPERANDS, O.RELU_MASK_FEED = True, [m.clone() for m in masks]
+    try:
+        Pq = {k: v.clone().requires_grad_(True) for k, v in synthetic.seeded_state_dict(seed_w).items()}
+        wc = {k: v.cpu() for k, v in w.items()}
+        oo = O.full_score_network(Pq, O.Schedules(), wc)
+        lq = readout(O.loss_fn, oo, wc, False)
+        assert not O.RELU_MASK_FEED, "the oracle consumed fewer masks than the engine recorded"
+        lq.backward()
+    finally:
+        O.EMULATE_BF16_OPERANDS, O.RELU_MASK_FEED = False, None
+    assert abs(float(loss) - float(lq)) < 1e-2 * abs(float(lq))
+    for k in ("unorm_angles", "rigid_update"):
+        assert rel_l2(out[k], oo[k]) < 2e-2, k
+    assert rel_l2(out["angles"], oo["angles"]) < 5e-2          # normalised: short raw vectors amplify (see readout)
+    errs = {}
+    for name, p in model.named_parameters():
+        if p.grad is None or Pq[name].grad is None or float(Pq[name].grad.norm()) < 1e-6:
+            continue
+        errs[name] = rel_l2(p.grad, Pq[name].grad)
+    vals = sorted(errs.values())
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print(f"[mask-aligned {gname}] rel-L2 median {vals[len(vals) // 2]:.4f} max {worst[1]:.4f} ({worst[0]})")
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("   worst:", ", ".join(f"{k.replace('score_model.', '')} {v:.4f}" for k, v in top))
+    bad = {k: v for k, v in errs.items() if v >= 3e-2}
+    assert not bad and vals[len(vals) // 2] < 2e-2, (bad, vals[len(vals) // 2])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# production-shape conv launches vs fp64 on samples
+# ------------------------------------------------------------------------------------------------------------------
+
+def _pack(w, dev):
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib, ops
+    CO, CI = w.shape[:2]
+    wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+    return wf, wd
+
+
+def _patch_rows(xpad, cells):
+    """xpad: padded grid [Wn,Fp,Wp,C] (border zero); cells [k,3] (window, frame, residue) -> fp64 [k, 25, C]: the 5x5
+    neighbourhood of each cell, tap index = (df+2)*5 + (dn+2)."""
+    w, f, n = cells[:, 0], cells[:, 1], cells[:, 2]
+    rows = []
+    for df in range(5):
+        for dn in range(5):
+            rows.append(xpad[w, f + df, n + dn].double())
+    return torch.stack(rows, 1)
+
+
+def _sample_cells(Wn, F, N, k, gen):
+    cells = torch.stack([torch.randint(0, Wn, (k,), generator=gen), torch.randint(0, F, (k,), generator=gen),
+                         torch.randint(0, N, (k,), generator=gen)], 1)
+    # force the grid corners / edges in (padding taps) and the tile seams of the 256-row M tiles
+    cells[0] = torch.tensor([0, 0, 0])
+    cells[1] = torch.tensor([Wn - 1, F - 1, N - 1])
+    cells[2] = torch.tensor([0, F - 1, 0])
+    cells[3] = torch.tensor([Wn - 1, 0, N - 1])
+    cells[4] = torch.tensor([3, min(1, F - 1), 255 % N])
+    cells[5] = torch.tensor([3, min(2, F - 1), 0])
+    return cells
+
+
+@pytest.mark.parametrize("CI,CO", [(1280, 640), (640, 1280)])
+def test_conv_fwd_dgrad_wgrad_config3_grid_vs_fp64(CI, CO):
+    """One conv layer of the tower on the config-3 grid (M = 8*32*256 = 65536 rows): forward (bias + ReLU epilogue),
+    data gradient (tap-flipped weights, ReLU-mask epilogue) and weight / bias gradient (dfold_mfma_gemm320_kernel role 2,
+    the transposed-accumulator form for 1280 -> 640) against fp64 sums over the same bf16 operands on sampled cells and
+    weight slices."""
+    from dynamicpdb_amd import ops
+    dev = torch.device(DEV)
+    Wn, F, N = 8, 32, 256
+    g = ops.Grid(Wn, F, N, dev)
+    gen = torch.Generator(device="cpu").manual_seed(5 + CI)
+    w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+    bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+    wf, wd = _pack(w, dev)
+    wq = w.to(torch.bfloat16).double()                                  # [CO,CI,5,5]
+    x, gy = g.alloc(CI), g.alloc(CO)
+    g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(torch.bfloat16))
+    g.interior(gy).copy_((torch.randn(Wn, F, N, CO, generator=gen) * 0.1).to(torch.bfloat16))
+    cells = _sample_cells(Wn, F, N, 96, gen).to(dev)
+    # ---- forward
+    y = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, y, relu=True)
+    patch = _patch_rows(x, cells)                                        # [k,25,CI]
+    ref = torch.einsum("ktc,oct->ko", patch, wq.reshape(CO, CI, 25)) + bias.double()
+    got = y[cells[:, 0], cells[:, 1] + 2, cells[:, 2] + 2].double()
+    assert rel_l2(got, ref.clamp_min(0)) < 4e-3, ("fwd", rel_l2(got, ref.clamp_min(0)))
+    assert float(y[:, :2].abs().max()) == 0 and float(y[:, :, -2:].abs().max()) == 0
+    # ---- data gradient: dx[cell, ci] = sum_{tap,co} gy[cell - tap, co] w[co, ci, tap]  (then the ReLU mask of x)
+    dx = g.alloc(CI)
+    ops.conv5x5_fwd(g, gy, wd, None, dx, relu=False, relu_mask=x)
+    gpatch = _patch_rows(gy, cells)                                      # gy at cell + (df-2, dn-2)
+    wflip = wq.flip(2, 3).reshape(CO, CI, 25)                            # tap (df,dn) pairs with w[.., 4-df, 4-dn]
+    refd = torch.einsum("kto,oct->kc", gpatch, wflip)
+    mask = (x[cells[:, 0], cells[:, 1] + 2, cells[:, 2] + 2] > 0).double()
+    gotd = dx[cells[:, 0], cells[:, 1] + 2, cells[:, 2] + 2].double()
+    assert rel_l2(gotd, refd * mask) < 4e-3, ("dgrad", rel_l2(gotd, refd * mask))
+    # ---- weight / bias gradient: dW[co,ci,df,dn] = sum_cells gy[cell,co] x[cell + (df-2,dn-2), ci]
+    tower_like = ops.Workspace(dev)
+    big, small = max(CI, CO), min(CI, CO)
+    dwg = torch.zeros((big, 25, small), dtype=torch.float32, device=dev)
+    db = torch.zeros(CO, dtype=torch.float32, device=dev)
+    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=True, bias_grad=db)
+    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=True, bias_grad=db)      # accumulates (shared tower: 4 uses)
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib
+    gw = torch.empty((CO, CI, 5, 5), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().dfold_conv_wgrad_unpack(ops._p(dwg), ops._p(gw), c_int32(CO), c_int32(CI), c_int32(0),
+                                                  c_int32(1 if CI > CO else 0), _lib.stream()), "unpack")
+    gyi = g.interior(gy).double().reshape(-1, CO)                        # [M,CO]
+    ci_sel = torch.tensor([0, 1, 63, 64, 319, 320, CI - 1], device=dev)
+    for (df, dn) in ((0, 0), (2, 2), (4, 4), (0, 4), (3, 1)):
+        xs = x[:, df:df + F, dn:dn + N][..., ci_sel].double().reshape(-1, len(ci_sel))   # x at cell + (df-2, dn-2)
+        refw = 2 * gyi.t() @ xs                                           # [CO, sel]
+        assert rel_l2(gw[:, ci_sel, df, dn], refw) < 2e-3, ("wgrad", df, dn, rel_l2(gw[:, ci_sel, df, dn], refw))
+    assert rel_l2(db, 2 * gyi.sum(0)) < 2e-3
+
+
+def test_conv_splitk_narrow_launch_config3_vs_fp64():
+    """The narrow launches of the training-step mode at production shape (8 windows x N_res 256, 5 output frames of 32,
+    640 -> 1280 and 1280 -> 640 channels): deterministic split-K (partial tiles in a workspace, last arriver reduces) against
+    fp64 sums on sampled cells."""
+    from dynamicpdb_amd import ops
+    dev = torch.device(DEV)
+    Wn, F, N = 8, 32, 256
+    g = ops.Grid(Wn, F, N, dev)
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    for (CI, CO) in ((1280, 640), (640, 1280)):
+        w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+        bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+        wf, _ = _pack(w, dev)
+        wq = w.to(torch.bfloat16).double()
+        x = g.alloc(CI)
+        g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(torch.bfloat16))
+        ws = ops.Workspace(dev)
+        nf = 5 if CO == 640 else 1          # 80 resp. 32 output tiles for 256 CUs: the cost model splits K
+        S = ops.conv_splitk(Wn * nf * N, CO, CI, dev)
+        assert S > 1, (CI, CO)
+        y = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, y, relu=True, f_lo=F - nf, nf=nf, ws=ws)
+        cells = _sample_cells(Wn, nf, N, 64, gen)
+        cells[:, 1] += F - nf
+        cells = cells.to(dev)
+        ref = torch.einsum("ktc,oct->ko", _patch_rows(x, cells), wq.reshape(CO, CI, 25)) + bias.double()
+        got = y[cells[:, 0], cells[:, 1] + 2, cells[:, 2] + 2].double()
+        assert rel_l2(got, ref.clamp_min(0)) < 4e-3, (CI, CO, S)
+        assert float(y[:, : 2 + F - nf].abs().max()) == 0

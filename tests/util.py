@@ -37,3 +37,21 @@ def window_from_golden(g, device="cpu"):
         if k.startswith("in_"):
             w[k[3:]] = torch.tensor(v).to(device)
     return w
+
+
+DIFFUSER_KEYS = ("rigids_t", "rot_score", "trans_score", "rot_score_scaling", "trans_score_scaling")
+
+
+def compact_window(g):
+    """Inputs of a compact (BASELINE-sized) golden: everything but the diffuser-dependent tensors is regenerated from
+    the seed by dynamicpdb_amd.synthetic.synthetic_window and pinned by the stored float64 checksums.
+    Returns (window dict of CPU tensors, (F, N, seed_w, grad_stride))."""
+    from dynamicpdb_amd import synthetic
+    F, N, seed_w, seed_x, stride = [int(v) for v in g["meta"]]
+    w = synthetic.synthetic_window(seed_x, F, N, t=float(g["t"][0]), diffuser=None)
+    sums = np.array([float(np.asarray(w[k].numpy(), dtype=np.float64).sum()) for k in sorted(w)])
+    assert np.array_equal(sums, g["in_checksum"]), "synthetic_window no longer reproduces the minted inputs"
+    for k in DIFFUSER_KEYS:
+        w[k] = torch.tensor(g["in_" + k])
+    w["rigids_t"] = w["rigids_t"].float()
+    return w, (F, N, seed_w, stride)
