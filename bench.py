@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Bench contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one
-rank per GPU over RCCL).  A "step" is one update_fn of the DFOLDv2 trajectory-prediction path (zero_grad, forward,
+"""Bench contract: `python bench.py --gpus N --steps K --warmup W`, one rank per GPU over RCCL: for N>1 either launched
+by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in the environment) or
+started bare, in which case it re-executes itself under that launcher with N ranks.  A "step" is one update_fn of the DFOLDv2 trajectory-prediction path (zero_grad, forward,
 loss, backward, gradient all-reduce, Adam/amsgrad step) on one batch of synthetic trajectory windows per rank
 (weak scaling).  Rank 0 prints ONE JSON line:
 
@@ -39,7 +40,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--nres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=2)
+    ap.add_argument("--cpu-baseline-frames", type=int, default=8)
+    ap.add_argument("--selftest-dist", action="store_true",
+                    help="only rendezvous (nccl with GPUs, gloo without), all-reduce one number, report n_gpus")
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
     ap.add_argument("--mode", choices=("all_frames", "last_frame"), default="all_frames",
                     help="what the MAIN timed region runs (profiling aid; the contract's headline is all_frames)")
@@ -94,9 +97,11 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
 
 
-def cpu_baseline(F, N, seed_w=0, budget_s=60.0):
-    """The oracle (CPU port of the reference path) fwd + loss + bwd on host cores, bounded sample: 1 warm-up + up to 2
-    timed iterations of one window of F frames, stopping once `budget_s` of CPU work has been spent."""
+def cpu_baseline(F, N, seed_w=0):
+    """The oracle (CPU port of the reference path; kind "port" -- the reference itself is not on the GPU box) running the
+    reference's update_fn on host cores: zero_grad + forward + loss + backward + Adam(amsgrad) step
+    (train_DFOLD_dynamics.py:660-667), ONE window of F frames x N_res = N.  Bounded sample: one cheap 2-frame iteration to
+    warm up the thread pool / primitive caches, then one timed iteration at F frames."""
     from oracle import dfold_oracle as O
     from dynamicpdb_amd import synthetic
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
@@ -104,40 +109,78 @@ def cpu_baseline(F, N, seed_w=0, budget_s=60.0):
         cores = len(os.sched_getaffinity(0))      # cores this process may actually use (cgroup / affinity aware)
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    threads = max(1, min(cores, 128))
     torch.set_num_threads(threads)
-    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
-    diffuser = SE3Diffuser(conf.diffuser)
     sd = synthetic.seeded_state_dict(seed_w)
-    w = synthetic.synthetic_window(7, F, N, t=0.5, diffuser=diffuser)
-    times, t_start = [], time.time()
-    for it in range(3):
-        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(P.values()), lr=1e-4, amsgrad=True)
+    times = {}
+    for frames in (2, F):
+        conf = synthetic.default_conf(frames, cache_dir="/tmp/dfold_igso3_cache/")
+        w = synthetic.synthetic_window(7, frames, N, t=0.5, diffuser=SE3Diffuser(conf.diffuser))
         t0 = time.time()
+        opt.zero_grad(set_to_none=True)
         out = O.full_score_network(P, O.Schedules(), w)
         loss, _ = O.loss_fn(out, w)
         loss.backward()
-        times.append(time.time() - t0)
-        print(f"[bench cpu_baseline] iteration {it}: {times[-1]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
-        if time.time() - t_start > budget_s:
-            break
-    t = min(times[1:]) if len(times) > 1 else times[0]
+        opt.step()
+        times[frames] = time.time() - t0
+        print(f"[bench cpu_baseline] {frames}-frame window: {times[frames]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
+    t = times[F]
     return {"value": round(F / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fwd+loss+bwd, 1 window of {F} frames x N_res={N}, best of {max(1, len(times) - 1)} after "
-                      f"{'1 warm-up' if len(times) > 1 else 'no warm-up'} ({t:.2f} s/iter, torch CPU threads={threads}, "
-                      f"{cores} usable cores)"}
+            "sample": f"oracle update_fn (zero_grad+fwd+loss+bwd+Adam amsgrad), 1 window of {F} frames x N_res={N}, one timed "
+                      f"iteration ({t:.2f} s) after a 2-frame warm-up iteration ({times[2]:.2f} s); torch CPU threads={threads}, "
+                      f"{cores} usable cores"}
+
+
+def respawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` (one rank per GPU)."""
+    port = os.environ.get("MASTER_PORT", str(29400 + os.getpid() % 1000))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
+def selftest_dist(args, world, rank):
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    x = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        x = x.cuda()
+    dist.all_reduce(x)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": dist.get_world_size(), "backend": backend, "allreduce_sum": float(x)}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
     T0 = time.perf_counter()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)                      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.selftest_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            return selftest_dist(args, world, rank)
+        print(json.dumps({"selftest": True, "n_gpus": 1}), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import __graft_entry__
@@ -166,16 +209,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first_loss = None
     for _ in range(args.warmup):
-        trainer.update_fn(batch)
+        l0, _ = trainer.update_fn(batch)
         torch.cuda.synchronize()
+        first_loss = float(l0) if first_loss is None else first_loss
         tlog("warm-up step done")
     sync()
     t0 = time.perf_counter()
+    losses = []
     for _ in range(args.steps):
         loss, aux = trainer.update_fn(batch)
+        losses.append(loss)                      # device scalars: no host sync inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
+    if first_loss is None:
+        first_loss = float(losses[0])
     tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -213,7 +262,10 @@ def main():
                                    "update_fn (fwd+loss+bwd+grad all-reduce+Adam amsgrad), random-init seeded weights"
                                    % (N, F, B),
                        "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world, "mode": args.mode},
-            "loss": round(float(loss), 5),
+            # the same batch every step: the loss of the first step taken (warm-up included) and of the last timed step
+            # show the optimizer descending (every forward sees the parameters the previous step wrote)
+            "loss": {"first_step": round(first_loss, 5), "last_step": round(float(loss), 5),
+                     "steps_between": args.warmup + args.steps - 1},
             "roofline": roof,
             "last_frame_mode": None if el2 is None else {
                 "value": round(world * B * F * args.steps / el2, 2), "unit": "frames/s",
@@ -224,7 +276,7 @@ def main():
                         "4x fewer conv FLOPs at F=32"},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_frames, N)
+            line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

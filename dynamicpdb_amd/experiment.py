@@ -48,13 +48,17 @@ def loss_fn(out, batch, trans_w=100.0, rot_w=7.0, torsion_w=1.0, rot_t_threshold
 
 
 class Trainer:
-    """update_fn of the reference (zero_grad, loss_fn, backward, optimizer step) for one rank's shard of windows,
-    with gradient averaging across ranks.  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
+    """update_fn of the reference (zero_grad, loss_fn, backward, optimizer step; train_DFOLD_dynamics.py:660-667) for one
+    rank's shard of windows, with gradient averaging across ranks overlapped with backward (dp.GradReducer; the reference
+    uses DistributedDataParallel, :615).  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
 
-    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=256 << 20, last_frame_only=True):
+    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=32 << 20, last_frame_only=True, force_reduce=False):
         """last_frame_only: run the model in its training-step mode (the live loss terms of loss_fn and the frame
         updates read the last frame of each window only, so the conv tower evaluates just that frame's dependency
-        cone; identical loss and gradients, see DFOLDIpaScore.forward).  False = every frame, as the reference."""
+        cone; identical loss and gradients, see DFOLDIpaScore.forward).  False = every frame, as the reference.
+        force_reduce: run the gradient collectives even in a single-rank world (coverage of the multi-GPU path on one
+        GPU)."""
+        from .dp import GradReducer
         self.model = model
         self.last_frame_only = last_frame_only
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -64,51 +68,23 @@ class Trainer:
         else:
             self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
         self.loss_kwargs = loss_kwargs or {}
-        self.bucket_bytes = bucket_bytes
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.reducer = GradReducer(self.params, bucket_bytes=bucket_bytes, force=force_reduce).attach(model)
+        self.world = self.reducer.world
 
-    def allreduce_grads(self):
-        """Average gradients over ranks in large flat buckets (xGMI rings are per-link bound: few, big
-        collectives).  Parameters without a gradient (the reference's 91,540 dead ones) are skipped on every rank
-        identically, so no find_unused_parameters graph walk is needed."""
-        if self.world == 1:
-            return
-        grads = [p.grad for p in self.params if p.grad is not None]
-        bucket, size, handles = [], 0, []
-
-        def flush():
-            nonlocal bucket, size
-            if not bucket:
-                return
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-            handles.append((h, flat, bucket))
-            bucket, size = [], 0
-
-        for g in grads:
-            bucket.append(g)
-            size += g.numel() * g.element_size()
-            if size >= self.bucket_bytes:
-                flush()
-        flush()
-        for h, flat, bucket in handles:
-            h.wait()
-            flat.div_(self.world)
-            off = 0
-            for g in bucket:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
-
-    def update_fn(self, batch, step_optimizer=True):
-        self.opt.zero_grad(set_to_none=True)
+    def begin_step(self):
+        """zero_grad + re-arm the per-step state (gradient buckets, the shared conv tower's accumulators)"""
         for m in self.model.modules():
             t = getattr(m, "_tower", None)
             if t is not None:
                 t.reset_step()
+        self.reducer.begin_step()
+
+    def update_fn(self, batch, step_optimizer=True):
+        self.begin_step()
         out = self.model(batch, last_frame_only=self.last_frame_only)
         loss, aux = loss_fn(out, batch, **self.loss_kwargs)
-        loss.backward()
-        self.allreduce_grads()
+        loss.backward()                 # buckets are reduced as their gradients complete (hooks / conv tower)
+        self.reducer.finish()
         if step_optimizer:
             self.opt.step()
         return loss.detach(), aux

@@ -208,7 +208,7 @@ def linear_gln(x, weight, bias, silu):
 class ConvTowerFn(Function):
     """ConvNet (src/model/ipa_pytorch_dynamic.py:664-706) on bf16 [W,F,N,C].  `tower` is the shared
     ops.ConvTower; weight gradients of all applications in a step are accumulated inside it (GEMM layout,
-    fp32) and handed to autograd once, by the application whose backward runs last."""
+    fp32) and added to the parameters' .grad layer by layer during the backward of the application that runs last."""
 
     @staticmethod
     def forward(ctx, x, tower, last_frame_only, track, *params):
@@ -239,14 +239,14 @@ class ConvTowerFn(Function):
             g.interior(gt)[:, -1:].copy_(gy[:, -1:])
         else:
             g.interior(gt).copy_(gy)
-        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last)
+        # the application whose backward runs last hands each layer's summed gradient to the parameters' .grad as soon as
+        # that layer's last weight-gradient product is done (ops.ConvTower.finalize_layer) -- not through autograd's
+        # return values, so that a data-parallel reducer can start on the top layers while the bottom ones still compute
+        last = tower.pending <= 1
+        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=last)
         ctx.saved = None
-        tower.pending -= 1
-        grads = [None] * (2 * len(tower.weights))
-        if tower.pending <= 0:
-            tower.pending = 0
-            grads = tower.collect_grads()
-        return (g.interior(g0).contiguous(), None, None, None, *grads)
+        tower.pending = max(0, tower.pending - 1)
+        return (g.interior(g0).contiguous(), None, None, None, *([None] * (2 * len(tower.weights))))
 
 
 # ------------------------------------------------------------------------------------------------

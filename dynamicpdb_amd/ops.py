@@ -357,6 +357,8 @@ class ConvTower:
         self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
         self.ws = Workspace(dev)
         self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
+        self.fresh = [True] * len(weights)   # accumulator j holds nothing yet this step: its first wgrad overwrites
+        self.on_final = None      # callback(param) after a layer's gradient has been handed to .grad (dp.GradReducer)
         self._stamp = None
 
     def refresh(self):
@@ -366,17 +368,30 @@ class ConvTower:
             self.pack()
             self._stamp = stamp
 
-    def collect_grads(self):
-        """[dW0, db0, dW1, db1, ...] in the reference parameter layout; resets the accumulators."""
-        L = _lib.lib()
-        out = []
-        for w, dwg, db in zip(self.weights, self.dwg, self.db):
-            gw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
-            check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(gw), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
-                                            c_int32(1 if w.shape[1] > w.shape[0] else 0), stream()), "dfold_conv_wgrad_unpack")
-            out += [gw, db.clone()]
-        self.zero_grad()
-        return out
+    def finalize_layer(self, j):
+        """Hand the accumulated gradient of conv layer j to the parameters' .grad (reference layout [CO,CI,5,5]; added to
+        an existing .grad like autograd's own accumulation) and re-arm its accumulators.  Called once per step and layer,
+        right after the LAST weight-gradient product into accumulator j -- for the layers of the top of the tower that is
+        long before the backward of the step ends, which is what lets a data-parallel reducer overlap their all-reduce
+        with the remaining backward work (dp.GradReducer, `on_final`)."""
+        w, b, dwg, db = self.weights[j], self.biases[j], self.dwg[j], self.db[j]
+        if self.fresh[j]:
+            return                                   # nothing was accumulated (layer not reached this step)
+        acc = w.grad is not None
+        if not acc:
+            w.grad = torch.empty_like(w)
+        check(_lib.lib().dfold_conv_wgrad_unpack(_p(dwg), _p(w.grad), c_int32(w.shape[0]), c_int32(w.shape[1]),
+                                                 c_int32(1 if acc else 0), c_int32(1 if w.shape[1] > w.shape[0] else 0),
+                                                 stream()), "dfold_conv_wgrad_unpack")
+        if b.grad is None:
+            b.grad = db.clone()
+        else:
+            b.grad.add_(db)
+        db.zero_()
+        self.fresh[j] = True
+        if self.on_final is not None:
+            self.on_final(w)
+            self.on_final(b)
 
     def pack(self):
         L = _lib.lib()
@@ -385,13 +400,14 @@ class ConvTower:
                   "dfold_conv_weight_pack")
 
     def zero_grad(self):
-        for t in self.dwg + self.db:
+        for t in self.db:
             t.zero_()
+        self.fresh = [True] * len(self.weights)
 
     def reset_step(self):
         """Start of a training step: forget applications whose backward never ran (an exception between forward and
         backward, a forward whose loss was dropped) so that their count and partial sums cannot leak into this step."""
-        if self.pending:
+        if self.pending or not all(self.fresh):
             self.pending = 0
             self.zero_grad()
 
@@ -427,8 +443,16 @@ class ConvTower:
             h = hn
         return h, saved
 
-    def backward(self, g, saved, gtop, last_frame_only=False):
+    def _wgrad(self, g, j, x, gy, f_lo, nf, finalize):
+        conv5x5_wgrad(g, x, gy, self.dwg[j], self.ws, accumulate=not self.fresh[j], bias_grad=self.db[j], f_lo=f_lo, nf=nf)
+        self.fresh[j] = False
+        if finalize:
+            self.finalize_layer(j)
+
+    def backward(self, g, saved, gtop, last_frame_only=False, finalize=False):
         """gtop: dL/dh4 on the padded grid (border zero).  Accumulates dwg/db, returns dL/dh0.
+        finalize: this is the last application of the step whose backward runs (ConvTowerFn counts them): every layer's
+        gradient is handed to .grad right after its weight-gradient product here (finalize_layer).
         last_frame_only: gtop is nonzero on frame F-1 only (see cone()); gradients are propagated inside the cone,
         where they are the only nonzero ones.  The scratch grids are re-zeroed first: below the (growing) frame range of
         each step they must read as the zeros the full computation would produce, not as a previous call's values."""
@@ -447,11 +471,11 @@ class ConvTower:
             if last_frame_only and i == 0:
                 n0 = min(g.F, 17)
                 l0 = g.F - n0
-            conv5x5_wgrad(g, u, dv, self.dwg[2 * i + 1], ws, bias_grad=self.db[2 * i + 1], f_lo=l2, nf=n2)
+            self._wgrad(g, 2 * i + 1, u, dv, l2, n2, finalize)
             du = ws.get("du", tuple(u.shape))
             sws = ws if last_frame_only else None
             conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws)
-            conv5x5_wgrad(g, hprev, du, self.dwg[2 * i], ws, bias_grad=self.db[2 * i], f_lo=l1, nf=n1)
+            self._wgrad(g, 2 * i, hprev, du, l1, n1, finalize)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
                 conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2],
@@ -462,11 +486,6 @@ class ConvTower:
         return gi
 
     def finalize_grads(self):
-        """GEMM-layout fp32 accumulators -> .grad of the reference-layout parameters."""
-        L = _lib.lib()
-        for w, b, dwg, db in zip(self.weights, self.biases, self.dwg, self.db):
-            if w.grad is None:
-                w.grad = torch.zeros_like(w)
-            check(L.dfold_conv_wgrad_unpack(_p(dwg), _p(w.grad), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
-                                            c_int32(1 if w.shape[1] > w.shape[0] else 0), stream()), "dfold_conv_wgrad_unpack")
-            b.grad = db.clone()
+        """GEMM-layout fp32 accumulators -> .grad of the reference-layout parameters (all layers)."""
+        for j in range(len(self.weights)):
+            self.finalize_layer(j)

@@ -149,29 +149,69 @@ def test_batched_loss_matches_oracle():
         assert abs(float(aux[k]) - float(aux_ref[k])) < 1e-6 * max(1.0, abs(float(aux_ref[k])))
 
 
+class _Toy(torch.nn.Module):
+    """CPU stand-in with the structural features of the real model that matter to the reducer: a layer applied several
+    times per step (the rigid embedder / the shared conv tower), a parameter that never receives a gradient (the
+    reference's 91,540 dead ones), a large tensor that exceeds the bucket size on its own."""
+
+    def __init__(self):
+        super().__init__()
+        self.inp = torch.nn.Linear(8, 16)
+        self.shared = torch.nn.Linear(16, 16)
+        self.big = torch.nn.Linear(16, 300)
+        self.out = torch.nn.Linear(300, 3)
+        self.dead = torch.nn.Linear(4, 4)
+
+    def forward(self, batch, last_frame_only=False):
+        h = torch.tanh(self.inp(batch["x"]))
+        for _ in range(3):
+            h = torch.tanh(self.shared(h))
+        return self.out(torch.tanh(self.big(h)))
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from dynamicpdb_amd import experiment
-    torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
-    dead = torch.nn.Linear(4, 4)                           # never receives a gradient (like the reference's 91,540 dead params)
-    holder = torch.nn.ModuleList([model, dead])
-    tr = experiment.Trainer(holder, lr=1e-2, bucket_bytes=256)   # tiny buckets: several collectives
-    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
-    tr.opt.zero_grad(set_to_none=True)
-    model(x).pow(2).mean().backward()
-    local = [p.grad.clone() for p in model.parameters()]
-    tr.allreduce_grads()
-    q.put((rank, [g.numpy() for g in local], [p.grad.numpy().copy() for p in model.parameters()],
-           [p.grad is None for p in dead.parameters()]))
+    experiment_loss = experiment.loss_fn
+    experiment.loss_fn = lambda out, batch, **kw: (out.pow(2).mean(), {})      # toy read-out instead of the SE(3) loss
+    try:
+        torch.manual_seed(0)
+        model = _Toy()
+        ref = _Toy()
+        ref.load_state_dict(model.state_dict())
+        tr = experiment.Trainer(model, lr=1e-2, bucket_bytes=1024, last_frame_only=False)   # tiny buckets: several collectives
+        ref_opt = torch.optim.Adam([p for p in ref.parameters()], lr=1e-2, amsgrad=True)
+        rows = []
+        for step in range(3):                       # step 0 = discovery, then bucketed / hook-driven steps
+            xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + 10 * step + r)) for r in range(world)]
+            loss, _ = tr.update_fn({"x": xs[rank]}, step_optimizer=True)
+            # reference: the mean over ranks of the per-rank gradients, computed locally from every rank's shard
+            ref_opt.zero_grad(set_to_none=True)
+            for r in range(world):
+                (ref(dict(x=xs[r])).pow(2).mean() / world).backward()
+            want = [None if p.grad is None else p.grad.clone() for p in ref.parameters()]
+            got = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+            ref_opt.step()
+            rows.append((step, [None if g is None else g.numpy() for g in got], [None if g is None else g.numpy() for g in want]))
+        red = tr.reducer
+        info = dict(n_buckets=len(red.buckets), views=all(p.grad is None or p.grad.untyped_storage().data_ptr() ==
+                                                          red.flat.untyped_storage().data_ptr() for p in model.parameters()),
+                    expected_shared=red._expected[id(model.shared.weight)],
+                    params_equal=all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(model.parameters(), ref.parameters())))
+        q.put((rank, rows, info))
+    finally:
+        experiment.loss_fn = experiment_loss
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_data_parallel_gradient_average_gloo_world2():
+    """2 gloo ranks, 3 steps: after every step each rank holds the mean over ranks of the per-rank gradients (discovery
+    step and hook-driven bucketed steps alike), gradients are views of the one flat buffer, the layer applied 3x per step
+    completes once (autograd sums its uses before the single accumulation), the dead parameter keeps grad None, and the optimizer trajectories match a single-process reference."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -179,15 +219,32 @@ def test_data_parallel_gradient_average_gloo_world2():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    mean = [(a + b) / 2 for a, b in zip(res[0][1], res[1][1])]
-    for r in res:
-        for got, want in zip(r[2], mean):
-            assert np.allclose(got, want, rtol=1e-6, atol=1e-8)
-        assert all(r[3])
+    for rank, rows, info in res:
+        for step, got, want in rows:
+            for g, w in zip(got, want):
+                assert (g is None) == (w is None), (rank, step)
+                if g is not None:
+                    assert np.allclose(g, w, rtol=1e-5, atol=1e-7), (rank, step)
+        assert info["n_buckets"] >= 3 and info["views"] and info["expected_shared"] == 1 and info["params_equal"], info
+
+
+def test_bench_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run with 2 ranks
+    (here: the rendezvous self-test on CPU / gloo) and reports n_gpus = 2."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 2000))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-dist"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["selftest"] and abs(line["allreduce_sum"] - 3.0) < 1e-9
 
 
 def test_conv_tower_cone_ranges_and_splitk_model(monkeypatch):

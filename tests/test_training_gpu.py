@@ -153,3 +153,56 @@ def test_score_heads_vs_reference_golden():
         ts = diffuser.calc_trans_score(rt[..., 4:], r0[..., 4:], tt[:, None, None], use_torch=True)
         reft = g[f"fm{i}_calc_trans_score"]
         assert max_abs(ts, reft) < 1e-4 * max(1.0, float(np.abs(reft).max())), i
+
+
+def test_gradient_reducer_path_on_one_gpu():
+    """The multi-GPU gradient path exercised on one GPU (RCCL world of 1, collectives forced): gradients live in one flat
+    buffer, every bucket is launched DURING backward (conv layers from the tower's per-layer finalisation, the rest from
+    autograd hooks) in the order the gradients complete, and the step equals the plain single-rank step."""
+    import os
+    import torch.distributed as dist
+    from dynamicpdb_amd import experiment
+    dev = torch.device(DEV)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        F, N, B = 6, 16, 2
+        res = {}
+        for forced in (False, True):
+            model, diffuser = _build(F, 3, dev)
+            batch = _batch(diffuser, B, F, N, dev, seed=70)
+            tr = experiment.Trainer(model, lr=1e-3, last_frame_only=True, force_reduce=forced, bucket_bytes=8 << 20)
+            launched_before_finish = None
+            if forced:
+                fin = tr.reducer.finish
+
+                def spy():
+                    nonlocal launched_before_finish
+                    if tr.reducer.flat is not None:
+                        launched_before_finish = list(tr.reducer._launched)
+                    fin()
+                tr.reducer.finish = spy
+            losses = [float(tr.update_fn(batch)[0]) for _ in range(3)]
+            res[forced] = (losses, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                           {n: p.detach().clone() for n, p in model.named_parameters()})
+            if forced:
+                red = tr.reducer
+                assert red.flat is not None and len(red.buckets) >= 8
+                assert launched_before_finish is not None and all(launched_before_finish), launched_before_finish
+                base = red.flat.untyped_storage().data_ptr()
+                assert all(p.grad is None or p.grad.untyped_storage().data_ptr() == base for p in model.parameters())
+                # the shared tower's layers complete top-down (layer 7 first), long before the embedders / expand layers
+                P = dict(model.named_parameters())
+                order = [red._bucket_of[id(P[f"score_model.trunk.conv_0.conv{i}.{j}.weight"])] for i in (4, 3, 2, 1) for j in (2, 0)]
+                assert order == sorted(order) and len(set(order)) == 8, order
+                assert red._bucket_of[id(P["expand_edge.weight"])] > order[-1]
+                dead = [n for n, p in model.named_parameters() if p.grad is None]
+                assert dead and all(n.startswith("embedding_layer.") or "linear_rbf" in n or n.endswith("linear_b.bias") for n in dead)
+        for a, b in zip(res[False][0], res[True][0]):
+            assert abs(a - b) < 2e-3 * abs(a), (res[False][0], res[True][0])
+        assert set(res[False][1]) == set(res[True][1])
+        for n in res[False][1]:
+            assert rel_l2(res[True][1][n], res[False][1][n]) < 2e-2, n
+    finally:
+        dist.destroy_process_group()
