@@ -1,0 +1,725 @@
+// Fused forward kernels of the triangle pair operators for c_z = c_hidden = 128 (triangle multiplication) and
+// c_in = 128, 4 heads x 32 (triangle attention) -- the configuration the reference instantiates
+// (openfold/config.py:347-350; operators openfold/model/triangular_multiplicative_update.py:26-126,
+// openfold/model/triangular_attention.py:31-139, Attention openfold/model/primitives.py:299-448).
+//
+// The pair tensor [B, N, N, 128] is streamed through the chip ONCE per stage; everything between two HBM passes
+// happens in registers / LDS:
+//
+//   pair_proj_kernel<0>   LayerNorm_in -> 5 projections (a_p|a_g|b_p|b_g|g: one 640-wide MFMA product per 64-cell
+//                         tile) -> sigmoid gates * mask -> a|b written as bf16 K-contiguous PLANES [B][256][N][NP]
+//                         (the layout the ik,jk->ij contraction consumes: no transposes), output gate sigmoid(g) bf16.
+//   (contraction)         x_c = a_c b_c^T per (batch, channel) on the bf16 MFMA engine (dfold_gemm_bf16, batched).
+//   trimul_out_kernel     x planes -> LDS transpose -> LayerNorm_out -> linear_z (MFMA) -> * gate -> out.
+//
+//   pair_proj_kernel<1>   LayerNorm -> q|k|v|g projections + the 4-wide triangle-bias projection; q, k, sigmoid(g)
+//                         channel-last bf16, v as key-contiguous planes [B][I][128][NP], bias fp32 [B][4][N][NP].
+//   triatt_core_kernel    per (batch, row i, 128-query block): flash-style attention over the keys of row i for the 4
+//                         heads (S^T = K Q^T on MFMA 16x16x32 so that the probabilities come out of the accumulators
+//                         directly in B-operand layout for O^T = V^T P^T; online softmax in fp32, triangle bias and
+//                         mask bias streamed), output gate, linear_o (MFMA) -> out.  No [I,H,N,N] logits in HBM.
+//
+// Work decomposition of the projection / output kernels: persistent workgroups (one per CU, 8 waves) loop over
+// 64-cell tiles; the projection WEIGHTS LIVE IN REGISTERS for the whole kernel (wave w owns output channels
+// [16w, 16w+16) of every 128-wide group as MFMA B fragments: 5 x 4 x 4 = 80 VGPRs), so a tile costs only its own
+// 32 KB of pair-tensor reads; the next tile's rows are prefetched into registers while the current tile's MFMAs
+// run.  Results are staged through LDS and leave as 16-byte vectors (128-byte plane segments / whole channel rows).
+#include "dfold_common.h"
+#include "../../include/dfold_hip.h"
+#include <math.h>
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+__device__ __forceinline__ float sigm_f(float y) { return 1.f / (1.f + __expf(-y)); }
+
+static int pf_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS tile of MFMA A rows: [rows][128 bf16] = 256 B per row, the 16-byte chunk index XORed with (row & 15):
+// conflict-free for the 16x16x32 fragment reads (ds_read_b128 lane groups {0-3,12-15,20-27} ... cover 16 distinct
+// rows x 2 adjacent chunks) and for the 4-byte LayerNorm writes.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int a_tile_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+#define PP_TILE 64
+#define PP_SPITCH 144   // plane staging: 64 cells * 2 B + 16
+#define PP_GPITCH 272   // channel-last staging: 128 ch * 2 B + 16
+
+struct PairProjParams {
+  const void* x;
+  const float* mask;
+  const float* gamma;
+  const float* beta;
+  const bf16_t* W;
+  const float* bias;
+  const float* wtri;
+  bf16_t* o0;
+  bf16_t* o1;
+  bf16_t* o2;
+  bf16_t* o3;
+  float* f0;
+  int B, N, NP, swap;
+  float eps;
+};
+
+// MODE 0: triangle multiplication (o0 = planes [B][256][N][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
+// MODE 1: triangle attention      (o0 = q, o1 = k, o3 = gate: [B][N][N][128]; o2 = vT [B][N][128][NP]; f0 = tri [B][4][N][NP])
+#define PP_LDS0 (16384 + 256 + 256 * PP_SPITCH + 64 * PP_GPITCH)
+#define PP_LDS1 (16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 1024)
+
+template <int MODE, bool XBF16>
+__global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) {
+  constexpr int NG = MODE == 0 ? 5 : 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsA = smem;
+  // MODE 0
+  float* const ldsM = (float*)(smem + 16384);
+  char* const ldsS = smem + 16384 + 256;
+  char* const ldsG0 = ldsS + 256 * PP_SPITCH;
+  // MODE 1
+  char* const ldsQ = smem + 16384;
+  char* const ldsK = ldsQ + 64 * PP_GPITCH;
+  char* const ldsG1 = ldsK + 64 * PP_GPITCH;
+  char* const ldsV = ldsG1 + 64 * PP_GPITCH;
+  float* const ldsT = (float*)(ldsV + 128 * PP_SPITCH);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int N = p.N, NP = p.NP;
+
+  // projection weights of this wave as MFMA B fragments (B[n][k], k contiguous): resident for the whole kernel
+  bf16x8 wf[NG][4];
+  float bv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int n = g * 128 + 16 * w + l15;
+    bv[g] = p.bias[n];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[g][ks] = *(const bf16x8*)(p.W + (long)n * 128 + ks * 32 + l4 * 8);
+  }
+  const float2 gam = ((const float2*)p.gamma)[lane], bet = ((const float2*)p.beta)[lane];
+  float2 wt[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) wt[h] = MODE == 1 ? ((const float2*)p.wtri)[h * 64 + lane] : make_float2(0.f, 0.f);
+
+  const int tpl = NP / PP_TILE;
+  const long ntiles = (long)p.B * N * tpl;
+
+  float2 zr[8];
+  float mk = 0.f;
+  auto issue = [&](long t) {
+    const int pt = (int)(t % tpl);
+    const long bl = t / tpl;
+    const int line = (int)(bl % N), b = (int)(bl / N);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pos = pt * PP_TILE + w * 8 + q;
+      float2 v = make_float2(0.f, 0.f);
+      if (pos < N) {
+        const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+        if (XBF16) {
+          const uint32_t u = ((const uint32_t*)p.x)[cell * 64 + lane];
+          v = make_float2(bf_lo(u), bf_hi(u));
+        } else {
+          v = ((const float2*)p.x)[cell * 64 + lane];
+        }
+      }
+      zr[q] = v;
+    }
+    if (MODE == 0) {
+      mk = 0.f;
+      const int pos = pt * PP_TILE + w * 8 + (lane & 7);
+      if (lane < 8 && pos < N) {
+        const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+        mk = p.mask[cell];
+      }
+    }
+  };
+
+  long t = blockIdx.x;
+  if (t < ntiles) issue(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int pt = (int)(t % tpl);
+    const long bl = t / tpl;
+    const int line = (int)(bl % N), b = (int)(bl / N);
+
+    // ---- S0: LayerNorm of this wave's 8 cells (one cell per pass, lane = channels 2l, 2l+1) -> bf16 A tile ----
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = w * 8 + q;
+      const float mean = wave_sum(zr[q].x + zr[q].y) * (1.f / 128.f);
+      const float d0 = zr[q].x - mean, d1 = zr[q].y - mean;
+      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+      const float rstd = rsqrtf(var + p.eps);
+      const float v0 = d0 * rstd * gam.x + bet.x, v1 = d1 * rstd * gam.y + bet.y;
+      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) = pack2bf(v0, v1);
+      if (MODE == 1) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float th = wave_sum(v0 * wt[h].x + v1 * wt[h].y);
+          if (lane == 0) ldsT[h * 64 + row] = th;
+        }
+      }
+      if (MODE == 0 && p.f0 != nullptr) {
+        const int pos = pt * PP_TILE + row;
+        if (lane == 0 && pos < N) {
+          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+          p.f0[2 * cell] = mean;
+          p.f0[2 * cell + 1] = rstd;
+        }
+      }
+    }
+    if (MODE == 0 && lane < 8) ldsM[w * 8 + lane] = mk;
+    __syncthreads();
+
+    // ---- S1: prefetch the next tile's rows (in flight during the MFMA phase) ----
+    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+
+    // ---- S2: projections on MFMA 16x16x32, gates, staging ----
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 acc[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
+      }
+      // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
+      const int cell0 = rt * 16 + l4 * 4;
+      const int ch = 16 * w + l15;
+      if (MODE == 0) {
+        const f32x4 m = *(const f32x4*)(ldsM + cell0);
+        float a[4], bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
+          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
+          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(sigm_f(acc[4][r] + bv[4]));
+        }
+        *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+        *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(bb[0], bb[1]), pack2bf(bb[2], bb[3]));
+      } else {
+        float vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(acc[0][r] + bv[0]);
+          *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(acc[1][r] + bv[1]);
+          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(sigm_f(acc[3][r] + bv[3]));
+          vv[r] = acc[2][r] + bv[2];
+        }
+        *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
+      }
+    }
+    __syncthreads();
+
+    // ---- S3: stream the staged tile out as 16-byte vectors ----
+    const int pos0 = pt * PP_TILE;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
+        const uint4 val = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
+        *(uint4*)(p.o0 + (((long)b * 256 + pl) * N + line) * NP + pos0 + v * 8) = val;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
+        const int pos = pos0 + cr;
+        if (pos < N) {
+          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+          *(uint4*)(p.o1 + cell * 128 + v * 8) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
+        const int pos = pos0 + cr;
+        if (pos < N) {
+          const long cell = ((long)b * N + line) * N + pos;
+          *(uint4*)(p.o0 + cell * 128 + v * 8) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
+          *(uint4*)(p.o1 + cell * 128 + v * 8) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
+          *(uint4*)(p.o3 + cell * 128 + v * 8) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
+        *(uint4*)(p.o2 + (((long)b * N + line) * 128 + pl) * NP + pos0 + v * 8) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
+      }
+      if (tid < 64) {
+        const int h = tid >> 4, v = tid & 15;
+        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + h * 64 + v * 4);
+      }
+    }
+    // no barrier here: the next S0 only writes ldsA / ldsM / ldsT, which every wave stopped reading at the barrier
+    // above ... except ldsT, read in S3 -> protect it
+    if (MODE == 1) __syncthreads();
+  }
+}
+
+static int pair_proj_launch(int mode, const PairProjParams& p, int x_is_bf16, hipStream_t st) {
+  const long ntiles = (long)p.B * p.N * (p.NP / PP_TILE);
+  long grid = ntiles < pf_num_cus() ? ntiles : pf_num_cus();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)pair_proj_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS0);
+    (void)hipFuncSetAttribute((const void*)pair_proj_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS0);
+    (void)hipFuncSetAttribute((const void*)pair_proj_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS1);
+    (void)hipFuncSetAttribute((const void*)pair_proj_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS1);
+    attr_done = true;
+  }
+  if (mode == 0) {
+    if (x_is_bf16)
+      DFOLD_LAUNCH((pair_proj_kernel<0, true>), dim3((unsigned)grid), dim3(512), PP_LDS0, st, p);
+    else
+      DFOLD_LAUNCH((pair_proj_kernel<0, false>), dim3((unsigned)grid), dim3(512), PP_LDS0, st, p);
+  } else {
+    if (x_is_bf16)
+      DFOLD_LAUNCH((pair_proj_kernel<1, true>), dim3((unsigned)grid), dim3(512), PP_LDS1, st, p);
+    else
+      DFOLD_LAUNCH((pair_proj_kernel<1, false>), dim3((unsigned)grid), dim3(512), PP_LDS1, st, p);
+  }
+  return dfold_check_launch();
+}
+
+static bool pf_dims_ok(int B, int N, int NP) { return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * N < (1L << 40); }
+
+extern "C" int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma,
+                                     const float* ln_beta, const void* w_cat_bf16, const float* bias_cat, void* planes_bf16,
+                                     void* gate_bf16, float* stats, int32_t B, int32_t N, int32_t NP, int32_t incoming,
+                                     float eps, void* stream) {
+  if (!z || !mask || !ln_gamma || !ln_beta || !w_cat_bf16 || !bias_cat || !planes_bf16 || !gate_bf16 || !pf_dims_ok(B, N, NP))
+    return DFOLD_EINVAL;
+  PairProjParams p;
+  p.x = z; p.mask = mask; p.gamma = ln_gamma; p.beta = ln_beta; p.W = (const bf16_t*)w_cat_bf16; p.bias = bias_cat;
+  p.wtri = nullptr; p.o0 = (bf16_t*)planes_bf16; p.o1 = (bf16_t*)gate_bf16; p.o2 = nullptr; p.o3 = nullptr; p.f0 = stats;
+  p.B = B; p.N = N; p.NP = NP; p.swap = incoming ? 1 : 0; p.eps = eps;
+  return pair_proj_launch(0, p, z_is_bf16, (hipStream_t)stream);
+}
+
+extern "C" int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta,
+                                     const void* w_cat_bf16, const float* bias_cat, const float* w_tri, void* q_bf16,
+                                     void* k_bf16, void* vT_bf16, void* gate_bf16, float* tri, int32_t B, int32_t N,
+                                     int32_t NP, int32_t ending, float eps, void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w_cat_bf16 || !bias_cat || !w_tri || !q_bf16 || !k_bf16 || !vT_bf16 || !gate_bf16 ||
+      !tri || !pf_dims_ok(B, N, NP))
+    return DFOLD_EINVAL;
+  PairProjParams p;
+  p.x = x; p.mask = nullptr; p.gamma = ln_gamma; p.beta = ln_beta; p.W = (const bf16_t*)w_cat_bf16; p.bias = bias_cat;
+  p.wtri = w_tri; p.o0 = (bf16_t*)q_bf16; p.o1 = (bf16_t*)k_bf16; p.o2 = (bf16_t*)vT_bf16; p.o3 = (bf16_t*)gate_bf16;
+  p.f0 = tri; p.B = B; p.N = N; p.NP = NP; p.swap = ending ? 1 : 0; p.eps = eps;
+  return pair_proj_launch(1, p, x_is_bf16, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Triangle multiplication, output stage: x planes [B][128][N][NP] (bf16, from the contraction) -> LayerNorm_out over
+// the 128 channels of every cell -> linear_z -> * gate -> out [B][N][N][128] (fp32 or bf16)
+// (triangular_multiplicative_update.py:119-124).
+// ------------------------------------------------------------------------------------------------------------------
+#define TO_XPITCH 260   // transposed x tile: 128 ch * 2 B + 4 (2-way conflicts on the dword writes = free)
+#define TO_OPITCH 528   // fp32 out staging: 128 * 4 + 16
+#define TO_LDS (64 * TO_XPITCH + 16384 + 64 * PP_GPITCH + 64 * TO_OPITCH)
+
+struct TriMulOutParams {
+  const bf16_t* xpl;
+  const bf16_t* gate;
+  const float* gamma;
+  const float* beta;
+  const bf16_t* Wz;
+  const float* bz;
+  void* out;
+  int B, N, NP, out_bf16;
+  float eps;
+};
+
+__global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsX = smem;
+  char* const ldsA = smem + 64 * TO_XPITCH;
+  char* const ldsG = ldsA + 16384;
+  char* const ldsO = ldsG + 64 * PP_GPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int N = p.N, NP = p.NP;
+
+  bf16x8 wz[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wz[ks] = *(const bf16x8*)(p.Wz + (long)(16 * w + l15) * 128 + ks * 32 + l4 * 8);
+  const float bz = p.bz[16 * w + l15];
+  const float2 gam = ((const float2*)p.gamma)[lane], bet = ((const float2*)p.beta)[lane];
+
+  const int tpl = NP / PP_TILE;
+  const long ntiles = (long)p.B * N * tpl;
+  const int pr = tid >> 3, xv8 = tid & 7;   // x planes: channel pair (2pr, 2pr+1), cells 8*xv8 .. +8
+
+  uint4 xv[2], gv[2];
+  auto issue = [&](long t) {
+    const int jt = (int)(t % tpl);
+    const long bl = t / tpl;
+    const int i = (int)(bl % N), b = (int)(bl / N);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+      xv[c2] = *(const uint4*)(p.xpl + (((long)b * 128 + 2 * pr + c2) * N + i) * NP + jt * PP_TILE + xv8 * 8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
+      const int pos = jt * PP_TILE + cr;
+      gv[k] = make_uint4(0, 0, 0, 0);
+      if (pos < N) gv[k] = *(const uint4*)(p.gate + (((long)b * N + i) * N + pos) * 128 + v * 8);
+    }
+  };
+
+  long t = blockIdx.x;
+  if (t < ntiles) issue(t);
+  for (; t < ntiles; t += gridDim.x) {
+    const int jt = (int)(t % tpl);
+    const long bl = t / tpl;
+    const int i = (int)(bl % N), b = (int)(bl / N);
+
+    // ---- S0a: x tile transposed into [cell][channel] (two channels per dword), gate tile ----
+    {
+      const bf16_t* e0 = (const bf16_t*)&xv[0];
+      const bf16_t* e1 = (const bf16_t*)&xv[1];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        *(uint32_t*)(ldsX + (xv8 * 8 + q) * TO_XPITCH + pr * 4) = (uint32_t)e0[q] | ((uint32_t)e1[q] << 16);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
+        *(uint4*)(ldsG + cr * PP_GPITCH + v * 16) = gv[k];
+      }
+    }
+    __syncthreads();
+    // ---- S0b: LayerNorm over channels -> bf16 A tile ----
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = w * 8 + q;
+      const uint32_t u = *(const uint32_t*)(ldsX + row * TO_XPITCH + lane * 4);
+      const float x0 = bf_lo(u), x1 = bf_hi(u);
+      const float mean = wave_sum(x0 + x1) * (1.f / 128.f);
+      const float d0 = x0 - mean, d1 = x1 - mean;
+      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+      const float rstd = rsqrtf(var + p.eps);
+      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) =
+          pack2bf(d0 * rstd * gam.x + bet.x, d1 * rstd * gam.y + bet.y);
+    }
+    __syncthreads();
+    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+
+    // ---- S2: linear_z on MFMA, gate, fp32 staging ----
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = MFMA16(*(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4)), wz[ks], acc);
+      const int cell0 = rt * 16 + l4 * 4, ch = 16 * w + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float g = bf2f(*(const bf16_t*)(ldsG + (cell0 + r) * PP_GPITCH + ch * 2));
+        *(float*)(ldsO + (cell0 + r) * TO_OPITCH + ch * 4) = (acc[r] + bz) * g;
+      }
+    }
+    __syncthreads();
+    // ---- S3: stream out (whole 512-byte rows) ----
+    if (!p.out_bf16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int id = tid + 512 * k, cr = id >> 5, v = id & 31;
+        const int pos = jt * PP_TILE + cr;
+        if (pos < N)
+          *(uint4*)((float*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 4) = *(const uint4*)(ldsO + cr * TO_OPITCH + v * 16);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
+        const int pos = jt * PP_TILE + cr;
+        if (pos < N) {
+          const f32x4 lo = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32);
+          const f32x4 hi = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32 + 16);
+          *(uint4*)((bf16_t*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 8) =
+              make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]));
+        }
+      }
+    }
+    // next S0a writes ldsX / ldsG (last read before the barrier above); ldsO is rewritten only after two more barriers
+  }
+}
+
+extern "C" int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const float* ln_gamma,
+                                    const float* ln_beta, const void* w_z_bf16, const float* b_z, void* out,
+                                    int32_t out_is_bf16, int32_t B, int32_t N, int32_t NP, float eps, void* stream) {
+  if (!x_planes_bf16 || !gate_bf16 || !ln_gamma || !ln_beta || !w_z_bf16 || !b_z || !out || !pf_dims_ok(B, N, NP)) return DFOLD_EINVAL;
+  TriMulOutParams p;
+  p.xpl = (const bf16_t*)x_planes_bf16; p.gate = (const bf16_t*)gate_bf16; p.gamma = ln_gamma; p.beta = ln_beta;
+  p.Wz = (const bf16_t*)w_z_bf16; p.bz = b_z; p.out = out; p.B = B; p.N = N; p.NP = NP; p.out_bf16 = out_is_bf16 ? 1 : 0;
+  p.eps = eps;
+  const long ntiles = (long)B * N * (NP / PP_TILE);
+  const long grid = ntiles < pf_num_cus() ? ntiles : pf_num_cus();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)trimul_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TO_LDS);
+    attr_done = true;
+  }
+  DFOLD_LAUNCH(trimul_out_kernel, dim3((unsigned)grid), dim3(512), TO_LDS, (hipStream_t)stream, p);
+  return dfold_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Triangle attention core: one workgroup per (batch, row i, block of 128 queries), 8 waves x 16 queries.
+//   logits[q, key] = scale * q_h . k_h + tri[h, q, key] + inf * (mask[i, key] - 1)      (triangular_attention.py:105-113)
+//   o = softmax_key(logits) v_h ;  og = o * gate ;  out = og W_o^T + b_o                (primitives.py:219-243, 385-448)
+// Keys are walked in chunks of 256 with an online softmax (any N); per chunk and head K [256][32] and V^T [32][256]
+// sit in LDS, shared by the 8 waves.
+// ------------------------------------------------------------------------------------------------------------------
+#define TC_VPITCH 528
+#define TC_LDS_K 0
+#define TC_LDS_V 16384
+#define TC_LDS_WO (16384 + 32 * TC_VPITCH)           // 33280
+#define TC_LDS_OG (TC_LDS_WO + 32768)                // 66048
+#define TC_LDS_MB (TC_LDS_OG + 32768)                // 98816
+#define TC_LDS (TC_LDS_MB + 1024)                    // 99840
+#define TC_WSTAGE 4160                               // per-wave out staging inside the K|V region (33280 / 8)
+
+struct TriAttCoreParams {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* vT;
+  const bf16_t* gate;
+  const float* tri;
+  const float* mask;
+  const bf16_t* Wo;
+  const float* bo;
+  void* out;
+  int B, N, NP, ending, out_bf16;
+  float inf, scale;
+};
+
+__device__ __forceinline__ float xor16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(512) void triatt_core_kernel(const TriAttCoreParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsK = smem + TC_LDS_K;
+  char* const ldsV = smem + TC_LDS_V;
+  char* const ldsWO = smem + TC_LDS_WO;
+  char* const ldsOG = smem + TC_LDS_OG;
+  float* const ldsMB = (float*)(smem + TC_LDS_MB);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int N = p.N, NP = p.NP;
+  const int qblocks = (N + 127) / 128;
+  const int qb = blockIdx.x % qblocks;
+  const long bi = blockIdx.x / qblocks;
+  const int i = (int)(bi % N), b = (int)(bi / N);
+  const long rowbase = ((long)b * N + i) * N;      // first cell of row i (x' coordinates)
+  const int q0 = qb * 128 + w * 16;
+  const int myq = q0 + l15;
+  const bool qok = myq < N;
+  const int kswz = (-(l15 >> 2)) & 3;
+
+  // W_o -> LDS (A-tile swizzle)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int id = tid + 512 * j, row = id >> 4, c = id & 15;
+    *(uint4*)(ldsWO + a_tile_off(row, c)) = *(const uint4*)(p.Wo + row * 128 + c * 8);
+  }
+  const int nchunks = (N + 255) / 256;
+
+#pragma unroll 1
+  for (int h = 0; h < 4; ++h) {
+    bf16x8 qf;
+    {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qok) v = *(const uint4*)(p.q + (rowbase + myq) * 128 + h * 32 + l4 * 8);
+      qf = *(bf16x8*)&v;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 oacc[2];
+    oacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    oacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kc = 0; kc < nchunks; ++kc) {
+      __syncthreads();   // everybody is done with the previous K / V / mask-bias tiles
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int id = tid + 512 * j;
+        {  // K tile: 256 keys x 4 chunks of 8 channels
+          const int r = id >> 2, c = id & 3, key = kc * 256 + r;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (key < N) v = *(const uint4*)(p.k + (rowbase + key) * 128 + h * 32 + c * 8);
+          *(uint4*)(ldsK + r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4)) = v;
+        }
+        {  // V^T tile: 32 channels x 32 chunks of 8 keys
+          const int cr = id >> 5, v8 = id & 31, key = kc * 256 + v8 * 8;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (key < NP) v = *(const uint4*)(p.vT + ((rowbase / N) * 128 + h * 32 + cr) * NP + key);
+          *(uint4*)(ldsV + cr * TC_VPITCH + v8 * 16) = v;
+        }
+      }
+      if (tid < 256) {
+        const int key = kc * 256 + tid;
+        float mb = -INFINITY;
+        if (key < N) {
+          const float mv = p.ending ? p.mask[((long)b * N + key) * N + i] : p.mask[rowbase + key];
+          mb = p.inf * (mv - 1.f);
+        }
+        ldsMB[tid] = mb;
+      }
+      __syncthreads();
+
+      // S^T[key][q] = K_h Q_h^T : A rows = keys, B columns = this wave's 16 queries, K = 32 channels (one MFMA per 16 keys)
+      f32x4 s[16];
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const bf16x8 a = *(const bf16x8*)(ldsK + (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4));
+        s[kb] = MFMA16(a, qf, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // lane holds query l15, keys kb*16 + l4*4 + r
+      float mc = -INFINITY;
+      const float* trow = p.tri + (((long)b * 4 + h) * N + (qok ? myq : 0)) * NP;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const int keyb = kc * 256 + kb * 16 + l4 * 4;
+        // pad keys (>= NP only when NP is not a multiple of 256) read a valid finite bias; their mask bias is -inf
+        const f32x4 tb = *(const f32x4*)(trow + (keyb < NP ? keyb : 0));
+        const f32x4 mb = *(const f32x4*)(ldsMB + kb * 16 + l4 * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kb][r] = s[kb][r] * p.scale + tb[r] + mb[r];
+          mc = fmaxf(mc, s[kb][r]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mc = xor16_max(mc);
+      const float mn = fmaxf(m_run, mc);
+      const float resc = __expf(m_run - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kb][r] = __expf(s[kb][r] - mn);
+          ps += s[kb][r];
+        }
+      ps = xor16_sum(ps);
+      l_run = l_run * resc + ps;
+      m_run = mn;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[cb][r] *= resc;
+      // O^T[c][q] += V^T[c][keys] P^T[keys][q]; MFMA k-slot e of lane group l4 <-> key (2ks + (e>>2))*16 + l4*4 + (e&3)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        uint4 pb;
+        pb.x = pack2bf(s[2 * ks][0], s[2 * ks][1]);
+        pb.y = pack2bf(s[2 * ks][2], s[2 * ks][3]);
+        pb.z = pack2bf(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+        pb.w = pack2bf(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const char* vr = ldsV + (cb * 16 + l15) * TC_VPITCH + ks * 64 + l4 * 8;
+          const uint2 lo = *(const uint2*)vr;
+          const uint2 hi = *(const uint2*)(vr + 32);
+          uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          oacc[cb] = MFMA16(*(bf16x8*)&av, *(bf16x8*)&pb, oacc[cb]);
+        }
+      }
+    }
+    // head epilogue: normalise, gate, stage into this wave's rows of the linear_o operand tile
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      uint2 g2 = make_uint2(0, 0);
+      if (qok) g2 = *(const uint2*)(p.gate + (rowbase + myq) * 128 + h * 32 + cb * 16 + l4 * 4);
+      const float o0 = oacc[cb][0] * inv * bf_lo(g2.x), o1 = oacc[cb][1] * inv * bf_hi(g2.x);
+      const float o2 = oacc[cb][2] * inv * bf_lo(g2.y), o3 = oacc[cb][3] * inv * bf_hi(g2.y);
+      const int row = w * 16 + l15, chunk = h * 4 + cb * 2 + (l4 >> 1);
+      *(uint2*)(ldsOG + a_tile_off(row, chunk) + ((l4 & 1) << 3)) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+    }
+  }
+  __syncthreads();   // all waves left the K / V tiles (reused as output staging); W_o and og tiles complete
+
+  // linear_o: out[q][o] = sum_hc og[q][hc] W_o[o][hc] + b_o[o]
+  f32x4 oa[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) oa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 a = *(const bf16x8*)(ldsOG + a_tile_off(w * 16 + l15, ks * 4 + l4));
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+      oa[nb] = MFMA16(a, *(const bf16x8*)(ldsWO + a_tile_off(nb * 16 + l15, ks * 4 + l4)), oa[nb]);
+  }
+  char* const st = smem + w * TC_WSTAGE;   // 16 queries x 64 channels fp32, wave-private
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) {
+      const int nb = half * 4 + n4;
+      const float bo = p.bo[nb * 16 + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(float*)(st + (l4 * 4 + r) * 256 + (n4 * 16 + l15) * 4) = oa[nb][r] + bo;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = lane + 64 * j, row = id >> 4, c = id & 15;
+      const int qq = q0 + row;
+      const f32x4 v = *(const f32x4*)(st + row * 256 + c * 16);
+      if (qq < N) {
+        const long cell = p.ending ? ((long)b * N + qq) * N + i : rowbase + qq;
+        if (!p.out_bf16)
+          *(f32x4*)((float*)p.out + cell * 128 + half * 64 + c * 4) = v;
+        else
+          *(uint2*)((bf16_t*)p.out + cell * 128 + half * 64 + c * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, const void* vT_bf16, const void* gate_bf16,
+                                     const float* tri, const float* mask, const void* w_o_bf16, const float* b_o, void* out,
+                                     int32_t out_is_bf16, int32_t B, int32_t N, int32_t NP, int32_t ending, float inf,
+                                     float scale, void* stream) {
+  if (!q_bf16 || !k_bf16 || !vT_bf16 || !gate_bf16 || !tri || !mask || !w_o_bf16 || !b_o || !out || !pf_dims_ok(B, N, NP))
+    return DFOLD_EINVAL;
+  const long nwg = (long)B * N * ((N + 127) / 128);
+  if (nwg > 0x7fffffffL) return DFOLD_EINVAL;
+  TriAttCoreParams p;
+  p.q = (const bf16_t*)q_bf16; p.k = (const bf16_t*)k_bf16; p.vT = (const bf16_t*)vT_bf16; p.gate = (const bf16_t*)gate_bf16;
+  p.tri = tri; p.mask = mask; p.Wo = (const bf16_t*)w_o_bf16; p.bo = b_o; p.out = out;
+  p.B = B; p.N = N; p.NP = NP; p.ending = ending ? 1 : 0; p.out_bf16 = out_is_bf16 ? 1 : 0; p.inf = inf; p.scale = scale;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)triatt_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
+    attr_done = true;
+  }
+  DFOLD_LAUNCH(triatt_core_kernel, dim3((unsigned)nwg), dim3(512), TC_LDS, (hipStream_t)stream, p);
+  return dfold_check_launch();
+}

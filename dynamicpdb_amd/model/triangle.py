@@ -1,10 +1,13 @@
 """Drop-in triangle pair operators (reference: vendored OpenFold modules
 openfold/model/triangular_multiplicative_update.py:26-126 and openfold/model/triangular_attention.py:31-139 with
 Attention openfold/model/primitives.py:299-448).  Same class names, constructor arguments, forward signatures and
-state_dict keys; forward and backward run on the HIP engine (MFMA contractions + the row/pointwise kernels of
-csrc/triangle.hip).  Inputs are [N, N, c] pair tensors (a leading batch axis is looped)."""
+state_dict keys.  Forward at the reference's sizes (c_z = c_hidden = 128; c_in = 128, 4 heads x 32): the fused
+HBM-streaming kernels of csrc/pair_fused.hip (three launches per triangle multiplication, two per triangle attention,
+real batch axis, any N_res); backward (and other channel counts): the MFMA contractions + row/pointwise kernels of
+csrc/triangle.hip, re-deriving the forward intermediates (nothing but the inputs is kept between forward and backward)."""
 import math
-from ctypes import c_int32, c_int64
+import os
+from ctypes import c_int32, c_int64, c_void_p
 
 import torch
 import torch.nn as nn
@@ -153,6 +156,80 @@ class TriangleMultiplicationFn(Function):
                 sp(dwcat, 4), sp(dbcat, 4), dw_z, db_z, dg_out, db_out)
 
 
+def _use_fused():
+    return os.environ.get("DFOLD_TRI_FUSED", "1") != "0"
+
+
+def _np64(N):
+    return (N + 63) // 64 * 64
+
+
+def _recompute_grads(fn, x, mask, dout, head_args, params, transpose=False):
+    """Backward of the fused forwards: run the unfused chain (`fn`, which keeps its intermediates) per batch item on the
+    saved inputs and differentiate it.  N_res is zero-padded (masked) to a multiple of 8 for the chain's 16-byte rows:
+    padded cells carry mask 0 and receive a zero output gradient, so they contribute exactly nothing."""
+    import torch.nn.functional as Fn_
+    B, N = x.shape[0], x.shape[1]
+    N8 = (N + 7) // 8 * 8
+    with torch.enable_grad():
+        xs = x.detach().float().requires_grad_(True)
+        ps = [p.detach().requires_grad_(True) for p in params]
+        ys = []
+        for b in range(B):
+            xb, mb = xs[b], mask[b].float()
+            if transpose:
+                xb, mb = xb.transpose(0, 1), mb.transpose(0, 1)
+            if N8 != N:
+                xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
+                mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
+            yb = fn.apply(xb.contiguous(), mb.contiguous(), *head_args, *ps)[:N, :N]
+            ys.append(yb.transpose(0, 1) if transpose else yb)
+        y = torch.stack(ys)
+        return torch.autograd.grad(y, [xs] + ps, dout.reshape(y.shape).float(), allow_unused=True)
+
+
+class TriMulFusedFn(Function):
+    """z [B,N,N,128] fp32|bf16, mask [B,N,N] -> same shape/dtype as z: three launches (csrc/pair_fused.hip):
+    LayerNorm + 640-wide projection + gates -> a|b planes and the output gate; x_c = a_c b_c^T batched over (B, channel)
+    on the MFMA engine; LayerNorm_out + linear_z + gate."""
+
+    @staticmethod
+    def forward(ctx, z, mask, outgoing, wcat, bcat, wz, *params):
+        L = _lib.lib()
+        (g_in, b_in, w_ap, b_ap, w_ag, b_ag, w_bp, b_bp, w_bg, b_bg, w_g, b_g, w_z, b_z, g_out, b_out) = params
+        B, N = z.shape[0], z.shape[1]
+        NP = _np64(N)
+        dev = z.device
+        zc = z.contiguous()
+        if zc.dtype not in (torch.float32, BF16):
+            zc = zc.float()
+        maskf = mask.contiguous().float()
+        planes = torch.empty((B, 256, N, NP), dtype=BF16, device=dev)
+        gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+        f32 = lambda t: t.detach().float().contiguous()
+        check(L.dfold_trimul_proj_fwd(_p(zc), c_int32(1 if zc.dtype == BF16 else 0), _p(maskf), _p(f32(g_in)), _p(f32(b_in)),
+                                      _p(wcat), _p(bcat), _p(planes), _p(gate), c_void_p(0), c_int32(B), c_int32(N),
+                                      c_int32(NP), c_int32(0 if outgoing else 1), ctypes_float(1e-5), stream()),
+              "dfold_trimul_proj_fwd")
+        xpl = torch.empty((B, 128, N, NP), dtype=BF16, device=dev)
+        pl = N * NP
+        gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(NP), c_rows=rows_plain(NP), ldb=NP, nbatch=B * 128, nb1=128,
+             sa=(256 * pl, pl), sb=(256 * pl, pl), sc=(128 * pl, pl), b_off=128 * pl)           # x_c = a_c b_c^T  (:113-118)
+        out = torch.empty((B, N, N, 128), dtype=zc.dtype, device=dev)
+        check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(f32(g_out)), _p(f32(b_out)), _p(wz), _p(f32(b_z)), _p(out),
+                                     c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
+                                     ctypes_float(1e-5), stream()), "dfold_trimul_out_fwd")
+        ctx.save_for_backward(zc, maskf, *params)
+        ctx.outgoing = outgoing
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        zc, maskf, *params = ctx.saved_tensors
+        g = _recompute_grads(TriangleMultiplicationFn, zc, maskf, dout, (ctx.outgoing,), params)
+        return (g[0].to(zc.dtype), None, None, None, None, None, *g[1:])
+
+
 class TriangleMultiplicativeUpdate(nn.Module):
     def __init__(self, c_z, c_hidden, _outgoing=True):
         super().__init__()
@@ -176,11 +253,38 @@ class TriangleMultiplicativeUpdate(nn.Module):
             self.linear_g.weight, self.linear_g.bias, self.linear_z.weight, self.linear_z.bias,
             self.layer_norm_out.weight, self.layer_norm_out.bias)
 
+    def _params(self):
+        return (self.layer_norm_in.weight, self.layer_norm_in.bias,
+                self.linear_a_p.weight, self.linear_a_p.bias, self.linear_a_g.weight, self.linear_a_g.bias,
+                self.linear_b_p.weight, self.linear_b_p.bias, self.linear_b_g.weight, self.linear_b_g.bias,
+                self.linear_g.weight, self.linear_g.bias, self.linear_z.weight, self.linear_z.bias,
+                self.layer_norm_out.weight, self.layer_norm_out.bias)
+
+    def _packed(self):
+        """bf16 [a_p|a_g|b_p|b_g|g] weight block, fp32 bias block, bf16 linear_z weight; rebuilt when a parameter changes"""
+        ps = self._params()
+        stamp = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pack", None) is None or self._pack[0] != stamp:
+            with torch.no_grad():
+                wcat = torch.cat([self.linear_a_p.weight, self.linear_a_g.weight, self.linear_b_p.weight,
+                                  self.linear_b_g.weight, self.linear_g.weight], 0).to(BF16).contiguous()
+                bcat = torch.cat([self.linear_a_p.bias, self.linear_a_g.bias, self.linear_b_p.bias, self.linear_b_g.bias,
+                                  self.linear_g.bias]).float().contiguous()
+                wz = self.linear_z.weight.to(BF16).contiguous()
+            self._pack = (stamp, wcat, bcat, wz)
+        return self._pack[1:]
+
     def forward(self, z, mask=None):
         if not z.is_cuda:
             raise RuntimeError("dynamicpdb_amd triangle operators need an MI355X device tensor (no CPU fallback)")
         if mask is None:
             mask = z.new_ones(z.shape[:-1])
+        if self.c_z == 128 and self.c_hidden == 128 and _use_fused():
+            zs, ms = z.reshape((-1,) + z.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
+            y = TriMulFusedFn.apply(zs, ms, self._outgoing, *self._packed(), *self._params())
+            return y.reshape(z.shape)
+        if z.shape[-2] % 8:
+            raise ValueError("the unfused triangle path needs N_res % 8 == 0")
         if z.dim() == 3:
             return self._one(z, mask)
         lead = z.shape[:-3]
@@ -305,6 +409,49 @@ class TriangleAttentionFn(Function):
                 dwcat[3 * HC:], dbcat[3 * HC:], dw_o, db_o)
 
 
+class TriAttFusedFn(Function):
+    """x [B,N,N,128] fp32|bf16 (NOT transposed for the ending node: the kernels index x^T), mask [B,N,N] -> like x.
+    Two launches (csrc/pair_fused.hip): LayerNorm + q|k|v|g projections + triangle bias; flash-style gated attention per
+    row + linear_o.  No [I,H,N,N] logits in HBM."""
+
+    @staticmethod
+    def forward(ctx, x, mask, starting, inf, wcat, bcat, wo, *params):
+        L = _lib.lib()
+        (g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o) = params
+        B, N = x.shape[0], x.shape[1]
+        NP = _np64(N)
+        dev = x.device
+        xc = x.contiguous()
+        if xc.dtype not in (torch.float32, BF16):
+            xc = xc.float()
+        maskf = mask.contiguous().float()
+        f32 = lambda t: t.detach().float().contiguous()
+        q = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+        k = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+        gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+        vT = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
+        tri = torch.empty((B, 4, N, NP), dtype=torch.float32, device=dev)
+        ending = 0 if starting else 1
+        check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(f32(g_ln)), _p(f32(b_ln)), _p(wcat),
+                                      _p(bcat), _p(f32(w_tri)), _p(q), _p(k), _p(vT), _p(gate), _p(tri), c_int32(B),
+                                      c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), stream()),
+              "dfold_triatt_proj_fwd")
+        out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
+        check(L.dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(maskf), _p(wo), _p(f32(b_o)), _p(out),
+                                      c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
+                                      c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)), stream()),
+              "dfold_triatt_core_fwd")
+        ctx.save_for_backward(xc, maskf, *params)
+        ctx.starting, ctx.inf = starting, inf
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, maskf, *params = ctx.saved_tensors
+        g = _recompute_grads(TriangleAttentionFn, xc, maskf, dout, (4, ctx.inf), params, transpose=not ctx.starting)
+        return (g[0].to(xc.dtype), None, None, None, None, None, None, *g[1:])
+
+
 class _Attention(nn.Module):
     """parameter container with the reference's names (openfold/model/primitives.py:299-361)"""
 
@@ -332,11 +479,33 @@ class TriangleAttention(nn.Module):
                                          self.linear.weight, m.linear_q.weight, m.linear_k.weight, m.linear_v.weight,
                                          m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
 
+    def _packed(self):
+        m = self.mha
+        ps = (m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_g.weight, m.linear_g.bias, m.linear_o.weight)
+        stamp = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pack", None) is None or self._pack[0] != stamp:
+            with torch.no_grad():
+                wcat = torch.cat([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_g.weight], 0).to(BF16).contiguous()
+                hc = m.linear_q.weight.shape[0]
+                bcat = torch.cat([torch.zeros(3 * hc, device=wcat.device), m.linear_g.bias.float()]).contiguous()
+                wo = m.linear_o.weight.to(BF16).contiguous()
+            self._pack = (stamp, wcat, bcat, wo)
+        return self._pack[1:]
+
     def forward(self, x, mask=None, chunk_size=None, use_memory_efficient_kernel=False, use_lma=False, inplace_safe=False):
         if not x.is_cuda:
             raise RuntimeError("dynamicpdb_amd triangle operators need an MI355X device tensor (no CPU fallback)")
         if mask is None:
             mask = x.new_ones(x.shape[:-1])
+        if self.c_in == 128 and self.c_hidden == 32 and self.no_heads == 4 and _use_fused():
+            m = self.mha
+            xs, ms = x.reshape((-1,) + x.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
+            y = TriAttFusedFn.apply(xs, ms, self.starting, self.inf, *self._packed(), self.layer_norm.weight,
+                                    self.layer_norm.bias, self.linear.weight, m.linear_q.weight, m.linear_k.weight,
+                                    m.linear_v.weight, m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
+            return y.reshape(x.shape)
+        if x.shape[-2] % 8:
+            raise ValueError("the unfused triangle path needs N_res % 8 == 0")
         if not self.starting:
             x, mask = x.transpose(-2, -3), mask.transpose(-1, -2)
         if x.dim() == 3:

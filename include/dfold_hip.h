@@ -193,6 +193,36 @@ int dfold_triatt_softmax_bwd(const float* P, float* dP, void* dS_bf16, int64_t r
 int dfold_sum_leading(const float* x, float* out, int32_t I, int64_t n, int64_t stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused forward of the triangle operators for c_z = c_hidden = 128 / c_in = 128, 4 heads x 32 (csrc/pair_fused.hip).
+ * Pair tensors are [B][N][N][128]; NP = N rounded up to a multiple of 64 is the pitch of the K-contiguous planes.
+ * ---------------------------------------------------------------------------------------------- */
+/* Triangle multiplication, stage 1 (triangular_multiplicative_update.py:92-104,122): LayerNorm_in, the five projections
+ * (w_cat rows a_p|a_g|b_p|b_g|g, [640][128] bf16; bias_cat [640]), gates and mask ->
+ *   planes bf16 [B][256][N][NP]: plane[ch][i][k] = a[i,k,ch] (outgoing) or a[k,i,ch] (incoming), ch < 128; b in 128..255
+ *   (pad columns k >= N zero-filled); gate bf16 [B][N][N][128] = sigmoid(linear_g(LN(z))); stats [B*N*N][2] or NULL */
+int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
+                          const void* w_cat_bf16, const float* bias_cat, void* planes_bf16, void* gate_bf16, float* stats,
+                          int32_t B, int32_t N, int32_t NP, int32_t incoming, float eps, void* stream);
+/* stage 3 (:119-124): x planes bf16 [B][128][N][NP] (x_c = a_c b_c^T from dfold_gemm_bf16) -> LayerNorm_out -> linear_z
+ * -> * gate -> out [B][N][N][128] fp32 | bf16 */
+int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const float* ln_gamma, const float* ln_beta,
+                         const void* w_z_bf16, const float* b_z, void* out, int32_t out_is_bf16, int32_t B, int32_t N,
+                         int32_t NP, float eps, void* stream);
+/* Triangle attention, stage 1 (triangular_attention.py:92-113, primitives.py:363-383): LayerNorm, q|k|v|g projections
+ * (w_cat [512][128] bf16, bias_cat [512] = 0|0|0|b_g), triangle bias (w_tri fp32 [4][128]).  ending != 0: the operator
+ * acts on x' = x^T (cell (i,j) of every output = cell (j,i) of x).  q, k, gate(=sigmoid) bf16 [B][N][N][128];
+ * vT bf16 [B][N][128][NP] (keys contiguous); tri fp32 [B][4][N][NP] */
+int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const void* w_cat_bf16,
+                          const float* bias_cat, const float* w_tri, void* q_bf16, void* k_bf16, void* vT_bf16, void* gate_bf16,
+                          float* tri, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps, void* stream);
+/* stage 2 (primitives.py:219-243,385-448): per row i gated multi-head attention over the keys of that row with the
+ * triangle bias and inf*(mask-1), flash-style (no logits in HBM), then linear_o; out [B][N][N][128] fp32 | bf16 in the
+ * coordinates of x (transposed back for ending != 0); mask fp32 [B][N][N] in the coordinates of x */
+int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, const void* vT_bf16, const void* gate_bf16, const float* tri,
+                          const float* mask, const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, int32_t B,
+                          int32_t N, int32_t NP, int32_t ending, float inf, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * First layer of the feature embedders (force/vel/index/rigid/angle_embeder[0:2], src/model/ipa_pytorch_dynamic.py:
  * 757-796): h = SiLU(x W^T + b), x fp32 [P,k] (k <= 16), W fp32 [256,k], h bf16 [P,256].  Backward accumulates
  * dW / db with fp32 atomics (caller zeroes them); dx (fp32 [P,k]) may be NULL.

@@ -1,0 +1,269 @@
+"""GPU parity of the fused triangle kernels (csrc/pair_fused.hip), stage by stage against fp32 torch math on the same
+device inputs (so that a failure names the kernel), and end to end against the CPU oracle / the unfused HIP chain at
+ragged sizes, with a batch axis, across key-chunk boundaries (N > 256) and for bf16 pair tensors.
+
+Tolerances: every stage rounds its outputs to bf16 once (rel-L2 ~ 2^-9 = 2e-3 .. 4e-3); end to end as DESIGN.md
+(1.5e-2 forward, 3e-2 gradients)."""
+import math
+from ctypes import c_int32, c_void_p
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16 = torch.bfloat16
+
+
+def _rand_module(m, seed):
+    rng = np.random.default_rng(seed)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            w = rng.standard_normal(tuple(v.shape), dtype=np.float32) / np.sqrt(v.shape[-1])
+        elif k.endswith("weight"):
+            w = 1.0 + 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        else:
+            w = 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        sd[k] = torch.tensor(w)
+    m.load_state_dict(sd)
+    return m
+
+
+def _inputs(B, N, seed, holes=0.1):
+    rng = np.random.default_rng(seed)
+    z = torch.tensor(rng.standard_normal((B, N, N, 128), dtype=np.float32) * 1.5 + 0.3)
+    mask = torch.tensor((rng.uniform(size=(B, N, N)) > holes).astype(np.float32))
+    return z, mask
+
+
+def _ln(x, w, b):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+@pytest.mark.parametrize("N,incoming", [(64, 0), (40, 1), (27, 0)])
+def test_trimul_proj_stage(N, incoming):
+    """dfold_trimul_proj_fwd: a|b planes (layout, orientation, zero-filled pad columns) and the output gate."""
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd._lib import check, stream
+    from dynamicpdb_amd.model import triangle as T
+    from dynamicpdb_amd.model.functional import ctypes_float
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device(DEV)
+    B = 2
+    m = _rand_module(T.TriangleMultiplicationOutgoing(128, 128), 5).to(dev)
+    z, mask = _inputs(B, N, 3)
+    z, mask = z.to(dev), mask.to(dev)
+    wcat, bcat, _ = m._packed()
+    NP = (N + 63) // 64 * 64
+    planes = torch.full((B, 256, N, NP), 7.0, dtype=BF16, device=dev)
+    gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+    stats = torch.empty((B * N * N, 2), dtype=torch.float32, device=dev)
+    f32 = lambda t: t.detach().float().contiguous()
+    check(_lib.lib().dfold_trimul_proj_fwd(_p(z), c_int32(0), _p(mask), _p(f32(m.layer_norm_in.weight)),
+                                           _p(f32(m.layer_norm_in.bias)), _p(wcat), _p(bcat), _p(planes), _p(gate), _p(stats),
+                                           c_int32(B), c_int32(N), c_int32(NP), c_int32(incoming), ctypes_float(1e-5), stream()),
+          "dfold_trimul_proj_fwd")
+    with torch.no_grad():
+        zn = _ln(z, m.layer_norm_in.weight, m.layer_norm_in.bias)
+        a = m.linear_a_p(zn) * torch.sigmoid(m.linear_a_g(zn)) * mask[..., None]
+        b = m.linear_b_p(zn) * torch.sigmoid(m.linear_b_g(zn)) * mask[..., None]
+        g = torch.sigmoid(m.linear_g(zn))
+        ab = torch.cat([a, b], -1)                                  # [B, r, s, 256]
+        ref = ab.permute(0, 3, 2, 1) if incoming else ab.permute(0, 3, 1, 2)   # plane[ch][line][pos]
+    assert rel_l2(planes[..., :N].float(), ref) < 8e-3, rel_l2(planes[..., :N].float(), ref)
+    assert float(planes[..., N:].float().abs().max()) == 0.0 if NP > N else True
+    assert rel_l2(gate.float(), g) < 6e-3
+    mean = z.mean(-1).reshape(-1)
+    assert rel_l2(stats[:, 0], mean) < 1e-5 and rel_l2(stats[:, 1], 1.0 / torch.sqrt(z.var(-1, unbiased=False) + 1e-5).reshape(-1)) < 1e-4
+
+
+@pytest.mark.parametrize("N", [64, 27])
+def test_trimul_out_stage(N):
+    """dfold_trimul_out_fwd on given x planes / gate: LayerNorm_out + linear_z + gate, fp32 and bf16 outputs."""
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd._lib import check, stream
+    from dynamicpdb_amd.model import triangle as T
+    from dynamicpdb_amd.model.functional import ctypes_float
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device(DEV)
+    B = 2
+    m = _rand_module(T.TriangleMultiplicationOutgoing(128, 128), 6).to(dev)
+    rng = np.random.default_rng(8)
+    NP = (N + 63) // 64 * 64
+    x = torch.tensor(rng.standard_normal((B, 128, N, NP), dtype=np.float32) * 3.0 + 0.5).to(dev).to(BF16)
+    gate = torch.tensor(rng.uniform(size=(B, N, N, 128)).astype(np.float32)).to(dev).to(BF16)
+    _, _, wz = m._packed()
+    f32 = lambda t: t.detach().float().contiguous()
+    with torch.no_grad():
+        xc = x[..., :N].float().permute(0, 2, 3, 1)                 # [B, i, j, c]
+        ref = m.linear_z(_ln(xc, m.layer_norm_out.weight, m.layer_norm_out.bias)) * gate.float()
+    for out_bf16 in (0, 1):
+        out = torch.empty((B, N, N, 128), dtype=BF16 if out_bf16 else torch.float32, device=dev)
+        check(_lib.lib().dfold_trimul_out_fwd(_p(x), _p(gate), _p(f32(m.layer_norm_out.weight)), _p(f32(m.layer_norm_out.bias)),
+                                              _p(wz), _p(f32(m.linear_z.bias)), _p(out), c_int32(out_bf16), c_int32(B),
+                                              c_int32(N), c_int32(NP), ctypes_float(1e-5), stream()), "dfold_trimul_out_fwd")
+        assert rel_l2(out.float(), ref) < (8e-3 if out_bf16 else 6e-3), (out_bf16, rel_l2(out.float(), ref))
+
+
+def _att_stage_inputs(m, x, ending):
+    """fp32 torch math of the attention input stage in x' coordinates (x' = x^T for the ending node)."""
+    with torch.no_grad():
+        xp = x.transpose(1, 2) if ending else x
+        xn = _ln(xp, m.layer_norm.weight, m.layer_norm.bias)
+        a = m.mha
+        return (a.linear_q(xn), a.linear_k(xn), a.linear_v(xn), torch.sigmoid(a.linear_g(xn)),
+                m.linear(xn).permute(0, 3, 1, 2))                   # tri [B, H, q, k]
+
+
+@pytest.mark.parametrize("N,ending", [(64, 0), (40, 1)])
+def test_triatt_proj_stage(N, ending):
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd._lib import check, stream
+    from dynamicpdb_amd.model import triangle as T
+    from dynamicpdb_amd.model.functional import ctypes_float
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device(DEV)
+    B = 2
+    m = _rand_module(T.TriangleAttentionStartingNode(128, 32, 4), 9).to(dev)
+    x, _ = _inputs(B, N, 4)
+    x = x.to(dev)
+    wcat, bcat, _ = m._packed()
+    NP = (N + 63) // 64 * 64
+    q = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+    k, gate = torch.empty_like(q), torch.empty_like(q)
+    vT = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
+    tri = torch.empty((B, 4, N, NP), dtype=torch.float32, device=dev)
+    f32 = lambda t: t.detach().float().contiguous()
+    check(_lib.lib().dfold_triatt_proj_fwd(_p(x), c_int32(0), _p(f32(m.layer_norm.weight)), _p(f32(m.layer_norm.bias)), _p(wcat),
+                                           _p(bcat), _p(f32(m.linear.weight)), _p(q), _p(k), _p(vT), _p(gate), _p(tri),
+                                           c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), stream()),
+          "dfold_triatt_proj_fwd")
+    rq, rk, rv, rg, rt = _att_stage_inputs(m, x, ending)
+    assert rel_l2(q.float(), rq) < 6e-3 and rel_l2(k.float(), rk) < 6e-3 and rel_l2(gate.float(), rg) < 6e-3
+    assert rel_l2(vT[..., :N].float(), rv.permute(0, 1, 3, 2)) < 6e-3          # [B, i, hc, key]
+    assert rel_l2(tri[..., :N], rt) < 1e-2, rel_l2(tri[..., :N], rt)          # the bias is computed from fp32 LN values
+
+
+@pytest.mark.parametrize("N,ending", [(64, 0), (40, 1), (300, 0)])
+def test_triatt_core_stage(N, ending):
+    """dfold_triatt_core_fwd on given q/k/vT/gate/bias: flash softmax across key chunks (N = 300: two chunks, the second
+    partial; three query blocks, the last partial), masked keys, output gate, linear_o, transposed store."""
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd._lib import check, stream
+    from dynamicpdb_amd.model import triangle as T
+    from dynamicpdb_amd.model.functional import ctypes_float
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device(DEV)
+    B = 1 if N > 256 else 2
+    m = _rand_module(T.TriangleAttentionStartingNode(128, 32, 4), 10).to(dev)
+    rng = np.random.default_rng(12)
+    NP = (N + 63) // 64 * 64
+    mk = lambda *s: torch.tensor(rng.standard_normal(s, dtype=np.float32)).to(dev)
+    q, k = mk(B, N, N, 128).to(BF16), mk(B, N, N, 128).to(BF16)
+    vT = mk(B, N, 128, NP).to(BF16)
+    gate = torch.tensor(rng.uniform(size=(B, N, N, 128)).astype(np.float32)).to(dev).to(BF16)
+    tri = mk(B, 4, N, NP)
+    mask = torch.tensor((rng.uniform(size=(B, N, N)) > 0.2).astype(np.float32)).to(dev)      # coordinates of x
+    _, _, wo = m._packed()
+    out = torch.empty((B, N, N, 128), dtype=torch.float32, device=dev)
+    check(_lib.lib().dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(mask), _p(wo),
+                                           _p(m.mha.linear_o.bias.detach().float().contiguous()), _p(out), c_int32(0), c_int32(B),
+                                           c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e9),
+                                           ctypes_float(1.0 / math.sqrt(32.0)), stream()), "dfold_triatt_core_fwd")
+    with torch.no_grad():
+        mp = mask.transpose(1, 2) if ending else mask                          # mask'[i, key]
+        qh = q.float().reshape(B, N, N, 4, 32)
+        kh = k.float().reshape(B, N, N, 4, 32)
+        vh = vT[..., :N].float().reshape(B, N, 4, 32, N)                        # [B, i, h, c, key]
+        lg = torch.einsum("biqhc,bikhc->bihqk", qh, kh) / math.sqrt(32.0)
+        lg = lg + (1e9 * (mp - 1))[:, :, None, None, :] + tri[..., :N][:, None]
+        p = torch.softmax(lg, -1)
+        o = torch.einsum("bihqk,bihck->biqhc", p, vh).reshape(B, N, N, 128) * gate.float()
+        ref = m.mha.linear_o(o)
+        if ending:
+            ref = ref.transpose(1, 2)
+    assert rel_l2(out, ref) < 8e-3, rel_l2(out, ref)
+
+
+def _names():
+    from dynamicpdb_amd.model import triangle as T
+    return dict(tri_mul_out=lambda: T.TriangleMultiplicationOutgoing(128, 128),
+                tri_mul_in=lambda: T.TriangleMultiplicationIncoming(128, 128),
+                tri_att_start=lambda: T.TriangleAttentionStartingNode(128, 32, 4),
+                tri_att_end=lambda: T.TriangleAttentionEndingNode(128, 32, 4))
+
+
+def _oracle(name, P, z, mask):
+    from oracle import dfold_oracle as O
+    if name.startswith("tri_mul"):
+        return O.triangle_multiplication(P, z, mask, outgoing=name.endswith("out"))
+    return O.triangle_attention(P, z, mask, starting=name.endswith("start"))
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
+def test_fused_ragged_batched_vs_oracle(name):
+    """N_res = 27 (not a multiple of 8), two batch items, fp32 and bf16 pair tensors."""
+    dev = torch.device(DEV)
+    m = _rand_module(_names()[name](), 21)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(dev)
+    z, mask = _inputs(2, 27, 31)
+    ref = torch.stack([_oracle(name, P, z[b], mask[b]) for b in range(2)])
+    with torch.no_grad():
+        y = m(z.to(dev), mask=mask.to(dev))
+        yb = m(z.to(dev).to(BF16), mask=mask.to(dev))
+    assert y.dtype == torch.float32 and yb.dtype == BF16
+    assert rel_l2(y, ref) < 1.5e-2, rel_l2(y, ref)
+    assert rel_l2(yb.float(), ref) < 2.5e-2, rel_l2(yb.float(), ref)       # input and output rounded to bf16 as well
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
+def test_fused_equals_unfused_chain_fwd_bwd(name, monkeypatch):
+    """The fused forward + re-derived backward against the unfused HIP chain at N_res = 72 (pitch 128: a half-empty
+    second tile per line) -- outputs and every gradient."""
+    dev = torch.device(DEV)
+    N = 72
+    z, mask = _inputs(1, N, 41)
+    gy = torch.tensor(np.random.default_rng(42).standard_normal((N, N, 128), dtype=np.float32))
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DFOLD_TRI_FUSED", fused)
+        m = _rand_module(_names()[name](), 22).to(dev)
+        zz = z[0].to(dev).requires_grad_(True)
+        y = m(zz, mask=mask[0].to(dev))
+        y.backward(gy.to(dev))
+        res[fused] = (y.detach(), zz.grad, {k: p.grad for k, p in m.named_parameters()})
+    assert rel_l2(res["1"][0], res["0"][0]) < 1e-2, rel_l2(res["1"][0], res["0"][0])
+    assert rel_l2(res["1"][1], res["0"][1]) < 1e-5                              # same backward chain on the same inputs
+    for k in res["0"][2]:
+        assert rel_l2(res["1"][2][k], res["0"][2][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_att_end"])
+def test_fused_long_chain_properties(name):
+    """N_res = 320 (two key chunks / five tiles per line), no oracle: (a) a batch of two equals two single calls bit for
+    bit, (b) masked-out cells do not influence the other outputs of triangle attention (their keys carry zero weight),
+    (c) outputs are finite."""
+    dev = torch.device(DEV)
+    N = 320
+    m = _rand_module(_names()[name](), 23).to(dev)
+    z, mask = _inputs(2, N, 51, holes=0.05)
+    z, mask = z.to(dev), mask.to(dev)
+    with torch.no_grad():
+        y = m(z, mask=mask)
+        y0, y1 = m(z[0], mask=mask[0]), m(z[1], mask=mask[1])
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[0], y0) and torch.equal(y[1], y1)
+    if name.startswith("tri_att"):
+        z2 = z.clone()
+        dead = mask[0, :, 7] == 0          # ending node attends along columns: keys (k, 7) of column 7
+        z2[0, dead, 7] += 100.0
+        with torch.no_grad():
+            y2 = m(z2, mask=mask)
+        keep = ~dead
+        # the perturbed cells only change their own output rows (their q / gate), not the other queries of the column
+        assert rel_l2(y2[0, keep, 7], y[0, keep, 7]) < 1e-6
