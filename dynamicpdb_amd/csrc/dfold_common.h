@@ -20,6 +20,18 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// hardware conversions (gfx950 v_cvt_pk_bf16_f32, round-to-nearest-even: same bits as f2bf for finite inputs)
+typedef __attribute__((ext_vector_type(2))) __bf16 dfold_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float dfold_f32x2;
+__device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
+  dfold_f32x2 v = {lo, hi};
+  dfold_bf16x2 b = __builtin_convertvector(v, dfold_bf16x2);
+  return *(uint32_t*)&b;
+}
+__device__ __forceinline__ bf16_t f2bf_hw(float f) {
+  __bf16 b = (__bf16)f;
+  return *(bf16_t*)&b;
+}
 __device__ __forceinline__ float bf_lo(uint32_t pair) { return __uint_as_float(pair << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t pair) { return __uint_as_float(pair & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {

@@ -28,9 +28,11 @@
 #include "../../include/dfold_hip.h"
 #include <math.h>
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
-__device__ __forceinline__ float sigm_f(float y) { return 1.f / (1.f + __expf(-y)); }
+__device__ __forceinline__ float sigm_f(float y) { return __builtin_amdgcn_rcpf(1.f + __expf(-y)); }
 
 static int pf_num_cus() {
   static int n = 0;
@@ -74,26 +76,26 @@ struct PairProjParams {
 
 // MODE 0: triangle multiplication (o0 = planes [B][256][N][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
 // MODE 1: triangle attention      (o0 = q, o1 = k, o3 = gate: [B][N][N][128]; o2 = vT [B][N][128][NP]; f0 = tri [B][4][N][NP])
-#define PP_LDS0 (16384 + 256 + 256 * PP_SPITCH + 64 * PP_GPITCH)
-#define PP_LDS1 (16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 1024)
+#define PP_LDS0 (2 * 16384 + 512 + 256 * PP_SPITCH + 64 * PP_GPITCH)
+#define PP_LDS1 (2 * 16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 2048)
 
 template <int MODE, bool XBF16>
 __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) {
   constexpr int NG = MODE == 0 ? 5 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const ldsA = smem;
+  char* const ldsA2 = smem;                        // two A tiles (tile parity)
   // MODE 0
-  float* const ldsM = (float*)(smem + 16384);
-  char* const ldsS = smem + 16384 + 256;
+  float* const ldsM2 = (float*)(smem + 32768);     // two mask rows
+  char* const ldsS = smem + 32768 + 512;
   char* const ldsG0 = ldsS + 256 * PP_SPITCH;
   // MODE 1
-  char* const ldsQ = smem + 16384;
+  char* const ldsQ = smem + 32768;
   char* const ldsK = ldsQ + 64 * PP_GPITCH;
   char* const ldsG1 = ldsK + 64 * PP_GPITCH;
   char* const ldsV = ldsG1 + 64 * PP_GPITCH;
   float* const ldsT = (float*)(ldsV + 128 * PP_SPITCH);
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int N = p.N, NP = p.NP;
 
@@ -113,14 +115,14 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   for (int h = 0; h < 4; ++h) wt[h] = MODE == 1 ? ((const float2*)p.wtri)[h * 64 + lane] : make_float2(0.f, 0.f);
 
   const int tpl = NP / PP_TILE;
-  const long ntiles = (long)p.B * N * tpl;
+  const unsigned ntiles = (unsigned)p.B * (unsigned)N * (unsigned)tpl;   // < 2^31, checked by the launcher
 
   float2 zr[8];
   float mk = 0.f;
-  auto issue = [&](long t) {
-    const int pt = (int)(t % tpl);
-    const long bl = t / tpl;
-    const int line = (int)(bl % N), b = (int)(bl / N);
+  auto issue = [&](unsigned t) __attribute__((always_inline)) {
+    const int pt = (int)(t % (unsigned)tpl);
+    const unsigned bl = t / (unsigned)tpl;
+    const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int pos = pt * PP_TILE + w * 8 + q;
@@ -146,86 +148,8 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     }
   };
 
-  long t = blockIdx.x;
-  if (t < ntiles) issue(t);
-  for (; t < ntiles; t += gridDim.x) {
-    const int pt = (int)(t % tpl);
-    const long bl = t / tpl;
-    const int line = (int)(bl % N), b = (int)(bl / N);
-
-    // ---- S0: LayerNorm of this wave's 8 cells (one cell per pass, lane = channels 2l, 2l+1) -> bf16 A tile ----
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int row = w * 8 + q;
-      const float mean = wave_sum(zr[q].x + zr[q].y) * (1.f / 128.f);
-      const float d0 = zr[q].x - mean, d1 = zr[q].y - mean;
-      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-      const float rstd = rsqrtf(var + p.eps);
-      const float v0 = d0 * rstd * gam.x + bet.x, v1 = d1 * rstd * gam.y + bet.y;
-      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) = pack2bf(v0, v1);
-      if (MODE == 1) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const float th = wave_sum(v0 * wt[h].x + v1 * wt[h].y);
-          if (lane == 0) ldsT[h * 64 + row] = th;
-        }
-      }
-      if (MODE == 0 && p.f0 != nullptr) {
-        const int pos = pt * PP_TILE + row;
-        if (lane == 0 && pos < N) {
-          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
-          p.f0[2 * cell] = mean;
-          p.f0[2 * cell + 1] = rstd;
-        }
-      }
-    }
-    if (MODE == 0 && lane < 8) ldsM[w * 8 + lane] = mk;
-    __syncthreads();
-
-    // ---- S1: prefetch the next tile's rows (in flight during the MFMA phase) ----
-    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
-
-    // ---- S2: projections on MFMA 16x16x32, gates, staging ----
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      f32x4 acc[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
-      }
-      // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
-      const int cell0 = rt * 16 + l4 * 4;
-      const int ch = 16 * w + l15;
-      if (MODE == 0) {
-        const f32x4 m = *(const f32x4*)(ldsM + cell0);
-        float a[4], bb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
-          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
-          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(sigm_f(acc[4][r] + bv[4]));
-        }
-        *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
-        *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(bb[0], bb[1]), pack2bf(bb[2], bb[3]));
-      } else {
-        float vv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(acc[0][r] + bv[0]);
-          *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(acc[1][r] + bv[1]);
-          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf(sigm_f(acc[3][r] + bv[3]));
-          vv[r] = acc[2][r] + bv[2];
-        }
-        *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
-      }
-    }
-    __syncthreads();
-
-    // ---- S3: stream the staged tile out as 16-byte vectors ----
+  // ---- stream a staged tile out as 16-byte vectors (128-byte plane segments / whole channel rows) ----
+  auto stream_out = [&](int b, int line, int pt, int par) __attribute__((always_inline)) {
     const int pos0 = pt * PP_TILE;
     if (MODE == 0) {
 #pragma unroll
@@ -262,13 +186,102 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       }
       if (tid < 64) {
         const int h = tid >> 4, v = tid & 15;
-        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + h * 64 + v * 4);
+        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4);
       }
     }
-    // no barrier here: the next S0 only writes ldsA / ldsM / ldsT, which every wave stopped reading at the barrier
-    // above ... except ldsT, read in S3 -> protect it
-    if (MODE == 1) __syncthreads();
+  };
+
+  // Per tile t: [LayerNorm(t) -> A[par]] | barrier | [prefetch rows of t+1] [stores of tile t-1 from the staging
+  // area] | barrier | [MFMA + gates(t) -> staging].  Loads and stores are both issued right before the MFMA phase and
+  // nothing waits on the memory counter until the next tile's LayerNorm, so neither latency sits on the critical path
+  // (the compiler waits vmcnt(0) wherever loads and stores are mixed).  A / mask / bias tiles alternate by tile parity.
+  unsigned t = blockIdx.x;
+  if (t < ntiles) issue(t);
+  int pb = 0, pline = 0, ppt = 0, par = 0;
+  bool have_prev = false;
+  for (; t < ntiles; t += gridDim.x) {
+    const int pt = (int)(t % (unsigned)tpl);
+    const unsigned bl = t / (unsigned)tpl;
+    const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
+    char* const ldsA = ldsA2 + par * 16384;
+    float* const ldsM = ldsM2 + par * 64;
+
+    // ---- S0: LayerNorm of this wave's 8 cells (one cell per pass, lane = channels 2l, 2l+1) -> bf16 A tile ----
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = w * 8 + q;
+      const float mean = wave_sum(zr[q].x + zr[q].y) * (1.f / 128.f);
+      const float d0 = zr[q].x - mean, d1 = zr[q].y - mean;
+      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+      const float rstd = rsqrtf(var + p.eps);
+      const float v0 = d0 * rstd * gam.x + bet.x, v1 = d1 * rstd * gam.y + bet.y;
+      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) = pack2bf_hw(v0, v1);
+      if (MODE == 1) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float th = wave_sum(v0 * wt[h].x + v1 * wt[h].y);
+          if (lane == 0) ldsT[par * 256 + h * 64 + row] = th * 1.44269504088896341f;   // consumed in the log2 domain
+        }
+      }
+      if (MODE == 0 && p.f0 != nullptr) {
+        const int pos = pt * PP_TILE + row;
+        if (lane == 0 && pos < N) {
+          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+          p.f0[2 * cell] = mean;
+          p.f0[2 * cell + 1] = rstd;
+        }
+      }
+    }
+    if (MODE == 0 && lane < 8) ldsM[w * 8 + lane] = mk;
+    __syncthreads();
+
+    // ---- S1: prefetch the next tile's rows, stream the previous tile out (both in flight during the MFMA phase) ----
+    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+    if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
+    __syncthreads();
+
+    // ---- S2: projections on MFMA 16x16x32, gates, staging ----
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f32x4 acc[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
+      }
+      // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
+      const int cell0 = rt * 16 + l4 * 4;
+      const int ch = 16 * w + l15;
+      if (MODE == 0) {
+        const f32x4 m = *(const f32x4*)(ldsM + cell0);
+        float a[4], bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
+          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
+          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[4][r] + bv[4]));
+        }
+        *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]));
+        *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(bb[0], bb[1]), pack2bf_hw(bb[2], bb[3]));
+      } else {
+        float vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[0][r] + bv[0]);
+          *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[1][r] + bv[1]);
+          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[3][r] + bv[3]));
+          vv[r] = acc[2][r] + bv[2];
+        }
+        *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(vv[0], vv[1]), pack2bf_hw(vv[2], vv[3]));
+      }
+    }
+    pb = b; pline = line; ppt = pt; par ^= 1; have_prev = true;
   }
+  __syncthreads();
+  if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
 }
 
 static int pair_proj_launch(int mode, const PairProjParams& p, int x_is_bf16, hipStream_t st) {
@@ -296,7 +309,9 @@ static int pair_proj_launch(int mode, const PairProjParams& p, int x_is_bf16, hi
   return dfold_check_launch();
 }
 
-static bool pf_dims_ok(int B, int N, int NP) { return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * N < (1L << 40); }
+static bool pf_dims_ok(int B, int N, int NP) {
+  return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * (NP / PP_TILE) < (1L << 31) && (long)B * N * N < (1L << 40);
+}
 
 extern "C" int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma,
                                      const float* ln_beta, const void* w_cat_bf16, const float* bias_cat, void* planes_bf16,
@@ -332,7 +347,7 @@ extern "C" int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const flo
 // ------------------------------------------------------------------------------------------------------------------
 #define TO_XPITCH 260   // transposed x tile: 128 ch * 2 B + 4 (2-way conflicts on the dword writes = free)
 #define TO_OPITCH 528   // fp32 out staging: 128 * 4 + 16
-#define TO_LDS (64 * TO_XPITCH + 16384 + 64 * PP_GPITCH + 64 * TO_OPITCH)
+#define TO_LDS (64 * TO_XPITCH + 16384 + 2 * 64 * PP_GPITCH + 64 * TO_OPITCH)
 
 struct TriMulOutParams {
   const bf16_t* xpl;
@@ -350,9 +365,9 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsX = smem;
   char* const ldsA = smem + 64 * TO_XPITCH;
-  char* const ldsG = ldsA + 16384;
-  char* const ldsO = ldsG + 64 * PP_GPITCH;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* const ldsG2 = ldsA + 16384;               // two gate tiles (tile parity)
+  char* const ldsO = ldsG2 + 2 * 64 * PP_GPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int N = p.N, NP = p.NP;
 
@@ -363,14 +378,14 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
   const float2 gam = ((const float2*)p.gamma)[lane], bet = ((const float2*)p.beta)[lane];
 
   const int tpl = NP / PP_TILE;
-  const long ntiles = (long)p.B * N * tpl;
+  const unsigned ntiles = (unsigned)p.B * (unsigned)N * (unsigned)tpl;
   const int pr = tid >> 3, xv8 = tid & 7;   // x planes: channel pair (2pr, 2pr+1), cells 8*xv8 .. +8
 
   uint4 xv[2], gv[2];
-  auto issue = [&](long t) {
-    const int jt = (int)(t % tpl);
-    const long bl = t / tpl;
-    const int i = (int)(bl % N), b = (int)(bl / N);
+  auto issue = [&](unsigned t) __attribute__((always_inline)) {
+    const int jt = (int)(t % (unsigned)tpl);
+    const unsigned bl = t / (unsigned)tpl;
+    const int i = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
       xv[c2] = *(const uint4*)(p.xpl + (((long)b * 128 + 2 * pr + c2) * N + i) * NP + jt * PP_TILE + xv8 * 8);
@@ -383,12 +398,41 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
     }
   };
 
-  long t = blockIdx.x;
+  auto stream_out = [&](int b, int i, int jt) __attribute__((always_inline)) {   // whole 512-byte rows
+    if (!p.out_bf16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int id = tid + 512 * k, cr = id >> 5, v = id & 31;
+        const int pos = jt * PP_TILE + cr;
+        if (pos < N)
+          *(uint4*)((float*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 4) = *(const uint4*)(ldsO + cr * TO_OPITCH + v * 16);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
+        const int pos = jt * PP_TILE + cr;
+        if (pos < N) {
+          const f32x4 lo = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32);
+          const f32x4 hi = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32 + 16);
+          *(uint4*)((bf16_t*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 8) =
+              make_uint4(pack2bf_hw(lo[0], lo[1]), pack2bf_hw(lo[2], lo[3]), pack2bf_hw(hi[0], hi[1]), pack2bf_hw(hi[2], hi[3]));
+        }
+      }
+    }
+  };
+
+  // Per tile t: [x / gate tiles(t) -> LDS] | barrier | [LayerNorm -> A] [prefetch t+1] [stores of tile t-1] | barrier |
+  // [MFMA + gate -> fp32 staging]; see pair_proj_kernel for why the stores ride one tile behind.
+  unsigned t = blockIdx.x;
   if (t < ntiles) issue(t);
+  int pb = 0, pi = 0, pjt = 0, par = 0;
+  bool have_prev = false;
   for (; t < ntiles; t += gridDim.x) {
-    const int jt = (int)(t % tpl);
-    const long bl = t / tpl;
-    const int i = (int)(bl % N), b = (int)(bl / N);
+    const int jt = (int)(t % (unsigned)tpl);
+    const unsigned bl = t / (unsigned)tpl;
+    const int i = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
+    char* const ldsG = ldsG2 + par * 64 * PP_GPITCH;
 
     // ---- S0a: x tile transposed into [cell][channel] (two channels per dword), gate tile ----
     {
@@ -415,10 +459,11 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
       const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
       const float rstd = rsqrtf(var + p.eps);
       *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) =
-          pack2bf(d0 * rstd * gam.x + bet.x, d1 * rstd * gam.y + bet.y);
+          pack2bf_hw(d0 * rstd * gam.x + bet.x, d1 * rstd * gam.y + bet.y);
     }
-    __syncthreads();
     if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+    if (have_prev) stream_out(pb, pi, pjt);
+    __syncthreads();
 
     // ---- S2: linear_z on MFMA, gate, fp32 staging ----
 #pragma unroll
@@ -433,31 +478,10 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
         *(float*)(ldsO + (cell0 + r) * TO_OPITCH + ch * 4) = (acc[r] + bz) * g;
       }
     }
-    __syncthreads();
-    // ---- S3: stream out (whole 512-byte rows) ----
-    if (!p.out_bf16) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int id = tid + 512 * k, cr = id >> 5, v = id & 31;
-        const int pos = jt * PP_TILE + cr;
-        if (pos < N)
-          *(uint4*)((float*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 4) = *(const uint4*)(ldsO + cr * TO_OPITCH + v * 16);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
-        const int pos = jt * PP_TILE + cr;
-        if (pos < N) {
-          const f32x4 lo = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32);
-          const f32x4 hi = *(const f32x4*)(ldsO + cr * TO_OPITCH + v * 32 + 16);
-          *(uint4*)((bf16_t*)p.out + (((long)b * N + i) * N + pos) * 128 + v * 8) =
-              make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3]));
-        }
-      }
-    }
-    // next S0a writes ldsX / ldsG (last read before the barrier above); ldsO is rewritten only after two more barriers
+    pb = b; pi = i; pjt = jt; par ^= 1; have_prev = true;
   }
+  __syncthreads();
+  if (have_prev) stream_out(pb, pi, pjt);
 }
 
 extern "C" int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const float* ln_gamma,
@@ -480,20 +504,21 @@ extern "C" int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Triangle attention core: one workgroup per (batch, row i, block of 128 queries), 8 waves x 16 queries.
+// Triangle attention core: one workgroup per (batch, row i, block of 64 queries), 4 waves x 16 queries; 50 KB of LDS
+// and <= 256 VGPRs so that two workgroups share a CU (their memory phases overlap each other's compute).
 //   logits[q, key] = scale * q_h . k_h + tri[h, q, key] + inf * (mask[i, key] - 1)      (triangular_attention.py:105-113)
 //   o = softmax_key(logits) v_h ;  og = o * gate ;  out = og W_o^T + b_o                (primitives.py:219-243, 385-448)
-// Keys are walked in chunks of 256 with an online softmax (any N); per chunk and head K [256][32] and V^T [32][256]
-// sit in LDS, shared by the 8 waves.
+// Keys are walked in chunks of 256 with an online softmax (any N); per (head, chunk) step K [256][32] and V^T [32][256]
+// sit in LDS, shared by the 4 waves; the next step's tiles are fetched into registers while the current one computes.
 // ------------------------------------------------------------------------------------------------------------------
 #define TC_VPITCH 528
 #define TC_LDS_K 0
 #define TC_LDS_V 16384
-#define TC_LDS_WO (16384 + 32 * TC_VPITCH)           // 33280
-#define TC_LDS_OG (TC_LDS_WO + 32768)                // 66048
-#define TC_LDS_MB (TC_LDS_OG + 32768)                // 98816
-#define TC_LDS (TC_LDS_MB + 1024)                    // 99840
-#define TC_WSTAGE 4160                               // per-wave out staging inside the K|V region (33280 / 8)
+#define TC_LDS_OG (16384 + 32 * TC_VPITCH)           // 33280
+#define TC_LDS_MB (TC_LDS_OG + 16384)                // 49664
+#define TC_LDS (TC_LDS_MB + 1024)                    // 50688
+#define TC_WSTAGE 8320                               // per-wave out staging inside the K|V region (33280 / 4)
+#define TC_OPITCH 520                                // 16 query rows x (128 ch * 4 B + 8)
 
 struct TriAttCoreParams {
   const bf16_t* q;
@@ -518,111 +543,134 @@ __device__ __forceinline__ float xor16_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-__global__ __launch_bounds__(512) void triatt_core_kernel(const TriAttCoreParams p) {
+__global__ __launch_bounds__(256, 2) void triatt_core_kernel(const TriAttCoreParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsK = smem + TC_LDS_K;
   char* const ldsV = smem + TC_LDS_V;
-  char* const ldsWO = smem + TC_LDS_WO;
   char* const ldsOG = smem + TC_LDS_OG;
   float* const ldsMB = (float*)(smem + TC_LDS_MB);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int N = p.N, NP = p.NP;
-  const int qblocks = (N + 127) / 128;
-  const int qb = blockIdx.x % qblocks;
-  const long bi = blockIdx.x / qblocks;
-  const int i = (int)(bi % N), b = (int)(bi / N);
+  const unsigned qblocks = (unsigned)(N + 63) / 64u;
+  const int qb = (int)(blockIdx.x % qblocks);
+  const unsigned bi = blockIdx.x / qblocks;
+  const int i = (int)(bi % (unsigned)N), b = (int)(bi / (unsigned)N);
   const long rowbase = ((long)b * N + i) * N;      // first cell of row i (x' coordinates)
-  const int q0 = qb * 128 + w * 16;
+  const long vbase = ((long)b * N + i) * 128;      // first V^T row of row i
+  const int q0 = qb * 64 + w * 16;
   const int myq = q0 + l15;
   const bool qok = myq < N;
   const int kswz = (-(l15 >> 2)) & 3;
-
-  // W_o -> LDS (A-tile swizzle)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int id = tid + 512 * j, row = id >> 4, c = id & 15;
-    *(uint4*)(ldsWO + a_tile_off(row, c)) = *(const uint4*)(p.Wo + row * 128 + c * 8);
-  }
   const int nchunks = (N + 255) / 256;
+  const float sl2 = p.scale * 1.44269504088896341f, inv_sl2 = 1.f / sl2;
+
+  // register-staged prefetch of the next (head, chunk) step: K / V^T tiles, the mask row, and -- when the step opens a
+  // new head -- this lane's query fragment and gate values.  Branch-free (clamped addresses; whatever a clamped lane
+  // reads is finite and meets a -inf mask bias / a zero probability) and with no arithmetic on the loaded values, so
+  // that nothing waits on the memory counter before the commit one whole compute phase later.
+  u32x4 kr[4], vr[4], qn;
+  u32x2 gn[2];
+  float mvr;
+  auto fetch = [&](int h, int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = tid + 256 * j;
+      const int r = id >> 2, c = id & 3, key = kc * 256 + r;           // K tile: 256 keys x 4 chunks of 8 channels
+      kr[j] = *(const u32x4*)(p.k + (rowbase + (key < N ? key : 0)) * 128 + h * 32 + c * 8);
+      const int cr = id >> 5, v8 = id & 31, key8 = kc * 256 + v8 * 8;  // V^T tile: 32 channels x 32 chunks of 8 keys
+      vr[j] = *(const u32x4*)(p.vT + (vbase + h * 32 + cr) * NP + (key8 < NP ? key8 : 0));
+    }
+    const int key = kc * 256 + tid;
+    const int kk = key < N ? key : 0;
+    mvr = p.ending ? p.mask[((long)b * N + kk) * N + i] : p.mask[rowbase + kk];
+    if (kc == 0) {
+      const long qrow = (rowbase + (qok ? myq : 0)) * 128 + h * 32;
+      qn = *(const u32x4*)(p.q + qrow + l4 * 8);
+      gn[0] = *(const u32x2*)(p.gate + qrow + l4 * 4);
+      gn[1] = *(const u32x2*)(p.gate + qrow + 16 + l4 * 4);
+    }
+  };
+  bf16x8 qf;
+  u32x2 g2[2];
+  auto commit = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = tid + 256 * j;
+      const int r = id >> 2, c = id & 3;
+      *(u32x4*)(ldsK + r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4)) = kr[j];
+      const int cr = id >> 5, v8 = id & 31;
+      *(u32x4*)(ldsV + cr * TC_VPITCH + v8 * 16) = vr[j];
+    }
+    ldsMB[tid] = (kc * 256 + tid < N) ? p.inf * (mvr - 1.f) * inv_sl2 : -INFINITY;
+    if (kc == 0) {
+      qf = __builtin_bit_cast(bf16x8, qn);
+      g2[0] = gn[0];
+      g2[1] = gn[1];
+    }
+  };
+
+  fetch(0, 0);
+  commit(0);
 
 #pragma unroll 1
   for (int h = 0; h < 4; ++h) {
-    bf16x8 qf;
-    {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (qok) v = *(const uint4*)(p.q + (rowbase + myq) * 128 + h * 32 + l4 * 8);
-      qf = *(bf16x8*)&v;
-    }
+    const float* trow = p.tri + (((long)b * 4 + h) * N + (qok ? myq : 0)) * NP;
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 oacc[2];
     oacc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     oacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 qh = qf;          // this head's query fragment / gates (qf, g2 are overwritten by the last commit)
+    const u32x2 gh0 = g2[0], gh1 = g2[1];
 #pragma unroll 1
     for (int kc = 0; kc < nchunks; ++kc) {
-      __syncthreads();   // everybody is done with the previous K / V / mask-bias tiles
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int id = tid + 512 * j;
-        {  // K tile: 256 keys x 4 chunks of 8 channels
-          const int r = id >> 2, c = id & 3, key = kc * 256 + r;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (key < N) v = *(const uint4*)(p.k + (rowbase + key) * 128 + h * 32 + c * 8);
-          *(uint4*)(ldsK + r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4)) = v;
-        }
-        {  // V^T tile: 32 channels x 32 chunks of 8 keys
-          const int cr = id >> 5, v8 = id & 31, key = kc * 256 + v8 * 8;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (key < NP) v = *(const uint4*)(p.vT + ((rowbase / N) * 128 + h * 32 + cr) * NP + key);
-          *(uint4*)(ldsV + cr * TC_VPITCH + v8 * 16) = v;
-        }
-      }
-      if (tid < 256) {
-        const int key = kc * 256 + tid;
-        float mb = -INFINITY;
-        if (key < N) {
-          const float mv = p.ending ? p.mask[((long)b * N + key) * N + i] : p.mask[rowbase + key];
-          mb = p.inf * (mv - 1.f);
-        }
-        ldsMB[tid] = mb;
-      }
-      __syncthreads();
-
-      // S^T[key][q] = K_h Q_h^T : A rows = keys, B columns = this wave's 16 queries, K = 32 channels (one MFMA per 16 keys)
-      f32x4 s[16];
-#pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
-        const bf16x8 a = *(const bf16x8*)(ldsK + (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4));
-        s[kb] = MFMA16(a, qf, ((f32x4){0.f, 0.f, 0.f, 0.f}));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // lane holds query l15, keys kb*16 + l4*4 + r
-      float mc = -INFINITY;
-      const float* trow = p.tri + (((long)b * 4 + h) * N + (qok ? myq : 0)) * NP;
+      __syncthreads();   // the tiles of this step are in LDS
+      // triangle bias of this step first (16 independent 16-byte loads per lane, L2 resident), then the next step's
+      // tiles: the counter is in order, so waiting for the bias below leaves the prefetch in flight
+      f32x4 tb[16];
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {
         const int keyb = kc * 256 + kb * 16 + l4 * 4;
         // pad keys (>= NP only when NP is not a multiple of 256) read a valid finite bias; their mask bias is -inf
-        const f32x4 tb = *(const f32x4*)(trow + (keyb < NP ? keyb : 0));
-        const f32x4 mb = *(const f32x4*)(ldsMB + kb * 16 + l4 * 4);
+        tb[kb] = *(const f32x4*)(trow + (keyb < NP ? keyb : 0));
+      }
+      const bool more = (kc + 1 < nchunks) || (h + 1 < 4);
+      const int nh = (kc + 1 < nchunks) ? h : ((h + 1) & 3), nkc = (kc + 1 < nchunks) ? kc + 1 : 0;
+      fetch(nh, nkc);   // unconditional (the last step re-reads head 0 and drops it): behind a branch the compiler would
+                        // have to assume the loads were NOT issued and wait vmcnt(0) for the bias instead of vmcnt(12)
+      __builtin_amdgcn_sched_barrier(0);
+      // S^T[key][q] = K_h Q_h^T : A rows = keys, B columns = this wave's 16 queries, K = 32 channels (one MFMA per 16 keys).
+      // The accumulator starts at the mask bias of its 4 keys (stored pre-divided by scale*log2e), so that
+      // logit*log2e = acc * (scale*log2e) + tri*log2e costs one fma per element (tri is stored pre-multiplied).
+      f32x4 s[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[kb][r] = s[kb][r] * p.scale + tb[r] + mb[r];
-          mc = fmaxf(mc, s[kb][r]);
-        }
+      for (int kb = 0; kb < 16; ++kb) {
+        const bf16x8 a = *(const bf16x8*)(ldsK + (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4));
+        s[kb] = MFMA16(a, qh, *(const f32x4*)(ldsMB + kb * 16 + l4 * 4));
       }
       __builtin_amdgcn_sched_barrier(0);
-      mc = xor16_max(mc);
+      // lane holds query l15, keys kb*16 + l4*4 + r; four independent max / sum chains (no fp reassociation by the compiler)
+      f32x4 mc4 = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kb][r] = __builtin_fmaf(s[kb][r], sl2, tb[kb][r]);
+          mc4[r] = fmaxf(mc4[r], s[kb][r]);
+        }
+      }
+      const float mc = xor16_max(fmaxf(fmaxf(mc4[0], mc4[1]), fmaxf(mc4[2], mc4[3])));
       const float mn = fmaxf(m_run, mc);
-      const float resc = __expf(m_run - mn);
-      float ps = 0.f;
+      const float resc = __builtin_amdgcn_exp2f(m_run - mn);
+      f32x4 ps4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[kb][r] = __expf(s[kb][r] - mn);
-          ps += s[kb][r];
+          s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - mn);
+          ps4[r] += s[kb][r];
         }
+      float ps = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
       ps = xor16_sum(ps);
       l_run = l_run * resc + ps;
       m_run = mn;
@@ -633,36 +681,37 @@ __global__ __launch_bounds__(512) void triatt_core_kernel(const TriAttCoreParams
       // O^T[c][q] += V^T[c][keys] P^T[keys][q]; MFMA k-slot e of lane group l4 <-> key (2ks + (e>>2))*16 + l4*4 + (e&3)
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        uint4 pb;
-        pb.x = pack2bf(s[2 * ks][0], s[2 * ks][1]);
-        pb.y = pack2bf(s[2 * ks][2], s[2 * ks][3]);
-        pb.z = pack2bf(s[2 * ks + 1][0], s[2 * ks + 1][1]);
-        pb.w = pack2bf(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+        const u32x4 pb = {pack2bf_hw(s[2 * ks][0], s[2 * ks][1]), pack2bf_hw(s[2 * ks][2], s[2 * ks][3]),
+                          pack2bf_hw(s[2 * ks + 1][0], s[2 * ks + 1][1]), pack2bf_hw(s[2 * ks + 1][2], s[2 * ks + 1][3])};
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const char* vr = ldsV + (cb * 16 + l15) * TC_VPITCH + ks * 64 + l4 * 8;
-          const uint2 lo = *(const uint2*)vr;
-          const uint2 hi = *(const uint2*)(vr + 32);
-          uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          oacc[cb] = MFMA16(*(bf16x8*)&av, *(bf16x8*)&pb, oacc[cb]);
+          const char* vp = ldsV + (cb * 16 + l15) * TC_VPITCH + ks * 64 + l4 * 8;
+          const u32x2 lo = *(const u32x2*)vp;
+          const u32x2 hi = *(const u32x2*)(vp + 32);
+          const u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+          oacc[cb] = MFMA16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, pb), oacc[cb]);
         }
       }
+      __syncthreads();   // everybody is done with this step's tiles
+      if (more) commit(nkc);
     }
     // head epilogue: normalise, gate, stage into this wave's rows of the linear_o operand tile
-    const float inv = 1.f / l_run;
+    const float inv = __builtin_amdgcn_rcpf(l_run);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      uint2 g2 = make_uint2(0, 0);
-      if (qok) g2 = *(const uint2*)(p.gate + (rowbase + myq) * 128 + h * 32 + cb * 16 + l4 * 4);
-      const float o0 = oacc[cb][0] * inv * bf_lo(g2.x), o1 = oacc[cb][1] * inv * bf_hi(g2.x);
-      const float o2 = oacc[cb][2] * inv * bf_lo(g2.y), o3 = oacc[cb][3] * inv * bf_hi(g2.y);
+      const u32x2 gg = cb == 0 ? gh0 : gh1;
+      const float o0 = oacc[cb][0] * inv * bf_lo(gg.x), o1 = oacc[cb][1] * inv * bf_hi(gg.x);
+      const float o2 = oacc[cb][2] * inv * bf_lo(gg.y), o3 = oacc[cb][3] * inv * bf_hi(gg.y);
       const int row = w * 16 + l15, chunk = h * 4 + cb * 2 + (l4 >> 1);
-      *(uint2*)(ldsOG + a_tile_off(row, chunk) + ((l4 & 1) << 3)) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+      *(uint2*)(ldsOG + a_tile_off(row, chunk) + ((l4 & 1) << 3)) = make_uint2(pack2bf_hw(o0, o1), pack2bf_hw(o2, o3));
     }
   }
-  __syncthreads();   // all waves left the K / V tiles (reused as output staging); W_o and og tiles complete
+  // the last step ended with a barrier: every wave has left the K / V tiles (reused as output staging below); the og
+  // rows are wave-private (written and read by the same wave)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 
-  // linear_o: out[q][o] = sum_hc og[q][hc] W_o[o][hc] + b_o[o]
+  // linear_o: out[q][o] = sum_hc og[q][hc] W_o[o][hc] + b_o[o]; W_o fragments straight from global (32 KB, L2 resident)
   f32x4 oa[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) oa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -671,35 +720,31 @@ __global__ __launch_bounds__(512) void triatt_core_kernel(const TriAttCoreParams
     const bf16x8 a = *(const bf16x8*)(ldsOG + a_tile_off(w * 16 + l15, ks * 4 + l4));
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
-      oa[nb] = MFMA16(a, *(const bf16x8*)(ldsWO + a_tile_off(nb * 16 + l15, ks * 4 + l4)), oa[nb]);
+      oa[nb] = MFMA16(a, *(const bf16x8*)(p.Wo + (nb * 16 + l15) * 128 + ks * 32 + l4 * 8), oa[nb]);
   }
-  char* const st = smem + w * TC_WSTAGE;   // 16 queries x 64 channels fp32, wave-private
+  char* const st = smem + w * TC_WSTAGE;   // 16 queries x 128 channels fp32, wave-private
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int nb = 0; nb < 8; ++nb) {
+    const float bo = p.bo[nb * 16 + l15];
 #pragma unroll
-    for (int n4 = 0; n4 < 4; ++n4) {
-      const int nb = half * 4 + n4;
-      const float bo = p.bo[nb * 16 + l15];
+    for (int r = 0; r < 4; ++r) *(float*)(st + (l4 * 4 + r) * TC_OPITCH + (nb * 16 + l15) * 4) = oa[nb][r] + bo;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *(float*)(st + (l4 * 4 + r) * 256 + (n4 * 16 + l15) * 4) = oa[nb][r] + bo;
+  for (int j = 0; j < 8; ++j) {
+    const int id = lane + 64 * j, row = id >> 5, c = id & 31;      // 16 rows x 32 chunks of 4 channels
+    const int qq = q0 + row;
+    const uint2 v0 = *(const uint2*)(st + row * TC_OPITCH + c * 16);
+    const uint2 v1 = *(const uint2*)(st + row * TC_OPITCH + c * 16 + 8);
+    if (qq < N) {
+      const long cell = p.ending ? ((long)b * N + qq) * N + i : rowbase + qq;
+      if (!p.out_bf16)
+        *(uint4*)((float*)p.out + cell * 128 + c * 4) = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      else
+        *(uint2*)((bf16_t*)p.out + cell * 128 + c * 4) =
+            make_uint2(pack2bf_hw(__uint_as_float(v0.x), __uint_as_float(v0.y)), pack2bf_hw(__uint_as_float(v1.x), __uint_as_float(v1.y)));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int id = lane + 64 * j, row = id >> 4, c = id & 15;
-      const int qq = q0 + row;
-      const f32x4 v = *(const f32x4*)(st + row * 256 + c * 16);
-      if (qq < N) {
-        const long cell = p.ending ? ((long)b * N + qq) * N + i : rowbase + qq;
-        if (!p.out_bf16)
-          *(f32x4*)((float*)p.out + cell * 128 + half * 64 + c * 4) = v;
-        else
-          *(uint2*)((bf16_t*)p.out + cell * 128 + half * 64 + c * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -709,17 +754,12 @@ extern "C" int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, con
                                      float scale, void* stream) {
   if (!q_bf16 || !k_bf16 || !vT_bf16 || !gate_bf16 || !tri || !mask || !w_o_bf16 || !b_o || !out || !pf_dims_ok(B, N, NP))
     return DFOLD_EINVAL;
-  const long nwg = (long)B * N * ((N + 127) / 128);
+  const long nwg = (long)B * N * ((N + 63) / 64);
   if (nwg > 0x7fffffffL) return DFOLD_EINVAL;
   TriAttCoreParams p;
   p.q = (const bf16_t*)q_bf16; p.k = (const bf16_t*)k_bf16; p.vT = (const bf16_t*)vT_bf16; p.gate = (const bf16_t*)gate_bf16;
   p.tri = tri; p.mask = mask; p.Wo = (const bf16_t*)w_o_bf16; p.bo = b_o; p.out = out;
   p.B = B; p.N = N; p.NP = NP; p.ending = ending ? 1 : 0; p.out_bf16 = out_is_bf16 ? 1 : 0; p.inf = inf; p.scale = scale;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)triatt_core_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
-    attr_done = true;
-  }
-  DFOLD_LAUNCH(triatt_core_kernel, dim3((unsigned)nwg), dim3(512), TC_LDS, (hipStream_t)stream, p);
+  DFOLD_LAUNCH(triatt_core_kernel, dim3((unsigned)nwg), dim3(256), TC_LDS, (hipStream_t)stream, p);
   return dfold_check_launch();
 }

@@ -211,12 +211,13 @@ int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const
 /* Triangle attention, stage 1 (triangular_attention.py:92-113, primitives.py:363-383): LayerNorm, q|k|v|g projections
  * (w_cat [512][128] bf16, bias_cat [512] = 0|0|0|b_g), triangle bias (w_tri fp32 [4][128]).  ending != 0: the operator
  * acts on x' = x^T (cell (i,j) of every output = cell (j,i) of x).  q, k, gate(=sigmoid) bf16 [B][N][N][128];
- * vT bf16 [B][N][128][NP] (keys contiguous); tri fp32 [B][4][N][NP] */
+ * vT bf16 [B][N][128][NP] (keys contiguous); tri fp32 [B][4][N][NP] = log2(e) * bias (the core's softmax runs on exp2) */
 int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const void* w_cat_bf16,
                           const float* bias_cat, const float* w_tri, void* q_bf16, void* k_bf16, void* vT_bf16, void* gate_bf16,
                           float* tri, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps, void* stream);
 /* stage 2 (primitives.py:219-243,385-448): per row i gated multi-head attention over the keys of that row with the
- * triangle bias and inf*(mask-1), flash-style (no logits in HBM), then linear_o; out [B][N][N][128] fp32 | bf16 in the
+ * triangle bias (tri as written by dfold_triatt_proj_fwd, i.e. pre-multiplied by log2 e) and inf*(mask-1), flash-style
+ * (no logits in HBM), then linear_o; out [B][N][N][128] fp32 | bf16 in the
  * coordinates of x (transposed back for ending != 0); mask fp32 [B][N][N] in the coordinates of x */
 int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, const void* vT_bf16, const void* gate_bf16, const float* tri,
                           const float* mask, const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, int32_t B,

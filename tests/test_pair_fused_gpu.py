@@ -145,7 +145,8 @@ def test_triatt_proj_stage(N, ending):
     rq, rk, rv, rg, rt = _att_stage_inputs(m, x, ending)
     assert rel_l2(q.float(), rq) < 6e-3 and rel_l2(k.float(), rk) < 6e-3 and rel_l2(gate.float(), rg) < 6e-3
     assert rel_l2(vT[..., :N].float(), rv.permute(0, 1, 3, 2)) < 6e-3          # [B, i, hc, key]
-    assert rel_l2(tri[..., :N], rt) < 1e-2, rel_l2(tri[..., :N], rt)          # the bias is computed from fp32 LN values
+    # the bias is computed from fp32 LN values and stored pre-multiplied by log2(e) (the core works in the log2 domain)
+    assert rel_l2(tri[..., :N], rt * math.log2(math.e)) < 1e-2, rel_l2(tri[..., :N], rt * math.log2(math.e))
 
 
 @pytest.mark.parametrize("N,ending", [(64, 0), (40, 1), (300, 0)])
@@ -170,7 +171,8 @@ def test_triatt_core_stage(N, ending):
     mask = torch.tensor((rng.uniform(size=(B, N, N)) > 0.2).astype(np.float32)).to(dev)      # coordinates of x
     _, _, wo = m._packed()
     out = torch.empty((B, N, N, 128), dtype=torch.float32, device=dev)
-    check(_lib.lib().dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(mask), _p(wo),
+    tri_l2 = (tri * math.log2(math.e)).contiguous()      # ABI: the bias arrives pre-multiplied by log2(e)
+    check(_lib.lib().dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri_l2), _p(mask), _p(wo),
                                            _p(m.mha.linear_o.bias.detach().float().contiguous()), _p(out), c_int32(0), c_int32(B),
                                            c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e9),
                                            ctypes_float(1.0 / math.sqrt(32.0)), stream()), "dfold_triatt_core_fwd")
