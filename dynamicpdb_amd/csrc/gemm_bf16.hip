@@ -45,6 +45,8 @@ struct GemmParams {
   long sa0, sa1, sb0, sb1, sc0, sc1;
   int M, N, nseg, seglen, nb1, flags;
   float alpha;
+  int prio;              // wave-priority scheme of the 256x320 kernel (DFOLD_GEMM_PRIO, see the kernel)
+  int conv_f0, conv_F;   // 5x5 conv: grid frame of logical frame 0 / frames of the grid (conv_F = 0: no tap skipping)
   float* ws;    // split-K partial tiles (nullptr: no split)
   int* cnt;     // split-K arrival counters, one per output tile
 };
@@ -497,7 +499,24 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     if (n >= p.N) n = p.N - 1;
     boff[t] = (unsigned)((n * p.ldb + kofs) * 2);
   }
-  const int nsteps = p.nseg * (p.seglen / BK);
+  // 5x5 conv: a tile whose rows all lie in one window only needs the frame taps df with 0 <= frame + df - 2 < F for some
+  // row of the tile; the others read nothing but the zero border of the grid.  Pure scalar set-up (the tile origin is
+  // wave-uniform): the K walk below simply starts df_lo taps in and wraps after ndf of them.
+  int df_lo = 0, ndf = p.seg_div_mid;
+  if (ROLE == 1 && p.conv_F > 0) {
+    const unsigned mlast = (unsigned)((m0 + BM3 - 1 < p.M ? m0 + BM3 - 1 : p.M - 1));
+    const unsigned wf0 = (unsigned)m0 / (unsigned)p.am.n, wf1 = mlast / (unsigned)p.am.n;
+    const unsigned w0 = wf0 / (unsigned)p.am.f, w1 = wf1 / (unsigned)p.am.f;
+    if (w0 == w1) {
+      const int f0 = p.conv_f0 + (int)(wf0 - w0 * (unsigned)p.am.f), f1 = p.conv_f0 + (int)(wf1 - w1 * (unsigned)p.am.f);
+      const int lo = 2 - f1 > 0 ? 2 - f1 : 0, hi = p.conv_F + 2 - f0 < 5 ? p.conv_F + 2 - f0 : 5;
+      if (hi > lo) {
+        df_lo = lo;
+        ndf = hi - lo;
+      }
+    }
+  }
+  const int nsteps = (ROLE == 1 && p.conv_F > 0) ? (p.nseg / p.seg_div_mid) * ndf * (p.seglen / BK) : p.nseg * (p.seglen / BK);
 
   // Tile cursor: (pa, pb) = operand byte pointers of the tile staged next, advanced INCREMENTALLY and branch-free with
   // integer masks (sign-bit tricks keep every step on the scalar ALU: the closed form seg0 + hi*s0 + mid*s1 + lo*s2 + kk
@@ -507,11 +526,11 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   // After the last tile the pointers stay put: the final, unused prefetch re-reads valid memory into the idle buffer.
   const long BK2 = BK * 2;
   const long ea1 = (p.a_seg_s2 - p.seglen) * 2, ea2 = (p.a_seg_s1 - (long)p.seg_div * p.a_seg_s2) * 2,
-             ea3 = (p.a_seg_s0 - (long)p.seg_div_mid * p.a_seg_s1) * 2;
+             ea3 = (p.a_seg_s0 - (long)ndf * p.a_seg_s1) * 2;
   const long eb1 = (p.b_seg_s2 - p.seglen) * 2, eb2 = (p.b_seg_s1 - (long)p.seg_div * p.b_seg_s2) * 2,
-             eb3 = (p.b_seg_s0 - (long)p.seg_div_mid * p.b_seg_s1) * 2;
-  const char* pa = A + p.a_seg0 * 2;
-  const char* pb = B + p.b_seg0 * 2;
+             eb3 = (p.b_seg_s0 - (long)ndf * p.b_seg_s1) * 2;
+  const char* pa = A + (p.a_seg0 + (long)df_lo * p.a_seg_s1) * 2;
+  const char* pb = B + (p.b_seg0 + (long)df_lo * p.b_seg_s1) * 2;
   int st_mid = 0, st_lo = 0, st_kk = 0, st_left = nsteps;
   auto stage = [&](int buf) {
     const char* sa = pa;
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     const unsigned w1 = (unsigned)(p.seg_div - 1 - lo) >> 31;      // lo >= seg_div
     lo &= (int)(w1 - 1u);
     int mid = st_mid + (int)w1;
-    const unsigned w2 = (unsigned)(p.seg_div_mid - 1 - mid) >> 31; // mid >= seg_div_mid
+    const unsigned w2 = (unsigned)(ndf - 1 - mid) >> 31;           // mid >= ndf (= seg_div_mid unless frame taps are skipped)
     mid &= (int)(w2 - 1u);
     st_kk = kk;
     st_lo = lo;
@@ -574,6 +593,11 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   };
 
   stage(0);
+  // Static wave priority (s_setprio is scalar and ignores EXEC: the guard is wave-uniform).  1 (default): the late group
+  // B outranks group A for the whole K loop (+2.3 % on the conv launches, scripts/exp_conv_prio.py); 2: the reverse
+  // (-0.3 %); 0: none.  Per-cluster flips inside the loop need scalar branches there, which break the pinned
+  // MFMA / DMA / LDS-read interleave (3x slower).
+  if ((p.prio == 1 && w >= 4) || (p.prio == 2 && w < 4)) __builtin_amdgcn_s_setprio(1);
   if (w < 4) {
     // ---- group A (one wave per SIMD): per K step [fragment reads][40 MFMAs], DMA pieces between the MFMAs ----
     for (int s = 0; s < nsteps; ++s) {
@@ -735,6 +759,13 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
   p.ws = nullptr; p.cnt = nullptr;
+  p.conv_f0 = (d->conv_frames >> 16) & 0x7fff; p.conv_F = d->conv_frames & 0xffff;
+  static int prio_mode = -1;
+  if (prio_mode < 0) {
+    const char* e = getenv("DFOLD_GEMM_PRIO");
+    prio_mode = e ? atoi(e) : 1;
+  }
+  p.prio = prio_mode;
   const int role = (d->a_rows.mode == 1 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
   const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
   const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);

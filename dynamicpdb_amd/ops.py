@@ -53,7 +53,7 @@ def seg_table(values, device):
 
 def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
          a_seg=None, b_seg=None, seg_div=1, seg_div_mid=0, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
-         a_off=0, b_off=0, c_off=0, splitk=1, splitk_ws=None, splitk_cnt=None):
+         a_off=0, b_off=0, c_off=0, splitk=1, splitk_ws=None, splitk_cnt=None, conv_frames=0):
     """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
     assert A.dtype == BF16 and B.dtype == BF16
     if C.dtype == BF16:
@@ -80,7 +80,7 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.ldb = ldb
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
     d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
-    d.splitk, d.reserved0 = splitk, 0
+    d.splitk, d.conv_frames = splitk, conv_frames
     d.splitk_ws, d.splitk_cnt = _p(splitk_ws if splitk > 1 else None), _p(splitk_cnt if splitk > 1 else None)
     check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
     return C
@@ -246,6 +246,10 @@ def conv_splitk(M, CO, CI, device):
     return best
 
 
+# DFOLD_CONV_SKIP_PAD=0: walk the all-padding frame taps of the edge tiles too (A/B measurement of the skip)
+_SKIP_PAD_TAPS = os.environ.get("DFOLD_CONV_SKIP_PAD", "1") != "0"
+
+
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
                 f_lo=0, nf=None, ws=None):
     """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO].
@@ -273,7 +277,7 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
                       splitk_cnt=ws.get("splitk_cnt", (4 * _N_CU[x.device],), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
                 c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
-                seg_div=5, seg_div_mid=5, flags=flags)
+                seg_div=5, seg_div_mid=5, flags=flags, conv_frames=(f_lo << 16) | g.F if _SKIP_PAD_TAPS else 0)
 
 
 def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):

@@ -83,7 +83,11 @@ typedef struct {
      and after the call) sums the S partials in fixed order and runs the epilogue -- narrow launches (few output rows,
      long K) then fill the 256 CUs.  splitk_ws: >= S * tiles * 256 * Ntile fp32 (tiles = ceil(M/256) * N/Ntile, Ntile = 320). */
   int32_t splitk;
-  int32_t reserved0;
+  /* 5x5 conv launches (a_rows.mode = 1, seg_div = seg_div_mid = 5) may declare where the frame axis of the grid ends:
+     conv_frames = (f_first << 16) | F_total, f_first = grid frame of logical frame 0 of a_rows, F_total = frames of the grid.
+     A 256-row output tile then skips the frame taps that only read the zero border above / below the grid (their
+     products are exact zeros).  0 = walk all 25 taps. */
+  int32_t conv_frames;
   float* splitk_ws;
   int32_t* splitk_cnt;
 } dfold_gemm_desc;
