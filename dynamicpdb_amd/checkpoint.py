@@ -1,0 +1,82 @@
+"""Checkpoint writer / warm start / true resume of the training step.
+
+Reference: `write_checkpoint` (src/data/utils.py:324-362: one torch-pickled dict with the keys model / conf / optimizer /
+epoch / step, called from train_DFOLD_dynamics.py:736-758 as `step_{trained_steps}.pth`) and the warm start
+`Experiment.load_pretrianed_model` (train_DFOLD_dynamics.py:468-499: 'module.' prefixes stripped, tensors whose name or
+shape does not match are skipped, optimizer / epoch / step NOT restored -- the reference cannot resume a run).
+
+Same file format in both directions (a reference checkpoint loads here, a checkpoint written here loads in the
+reference), plus `resume`, which also restores the optimizer (FusedAdam keeps torch.optim.Adam's state layout, so the
+states are interchangeable), the epoch / step counters and the device RNG position: a resumed run continues bit-for-bit."""
+import copy
+import os
+
+import torch
+
+
+def write_checkpoint(ckpt_path, model, conf, optimizer, epoch, step, logger=None, use_torch=True, extra=None):
+    """Signature and file content of the reference's data.utils.write_checkpoint: `model` / `optimizer` are STATE DICTS
+    (the reference passes deep copies, train:746-750).  Written to a temporary file and renamed, so that a crash never
+    leaves a truncated checkpoint behind.  `extra`: optional dict stored under 'extra' (e.g. the device RNG position)."""
+    if not use_torch:
+        raise ValueError("only the torch serialisation (use_torch=True, as the reference's call site) is supported")
+    msg = f'Serializing experiment state to {ckpt_path}'
+    logger.info(msg) if logger is not None else print(msg)
+    os.makedirs(os.path.dirname(os.path.abspath(ckpt_path)), exist_ok=True)
+    payload = {'model': model, 'conf': conf, 'optimizer': optimizer, 'epoch': epoch, 'step': step}
+    if extra is not None:
+        payload['extra'] = extra
+    tmp = f"{ckpt_path}.tmp.{os.getpid()}"
+    torch.save(payload, tmp, pickle_protocol=4)
+    os.replace(tmp, ckpt_path)
+
+
+def read_checkpoint(ckpt_path):
+    return torch.load(ckpt_path, map_location='cpu', weights_only=False)
+
+
+def load_pretrained_model(model, ckpt_path, logger=None):
+    """Warm start as Experiment.load_pretrianed_model: returns True on success; parameters missing from the checkpoint or
+    of a different shape keep their current values."""
+    log = logger.info if logger is not None else print
+    err = logger.error if logger is not None else print
+    try:
+        log(f'Loading checkpoint from {ckpt_path}')
+        ckpt = read_checkpoint(ckpt_path)
+        if ckpt is None or 'model' not in ckpt:
+            err("Checkpoint or model not found in checkpoint file.")
+            return False
+        ckpt_model = ckpt['model']
+        if ckpt_model is None:
+            err("Checkpoint model is None.")
+            return False
+        ckpt_model = {k.replace('module.', ''): v for k, v in ckpt_model.items()}
+        sd = model.state_dict()
+        sd.update({k: v for k, v in ckpt_model.items() if k in sd and v.shape == sd[k].shape})
+        model.load_state_dict(sd)
+        log(f'Warm starting from: {ckpt_path}')
+        return True
+    except Exception as e:  # the reference logs and carries on
+        err(f"Error loading checkpoint: {e}")
+        return False
+
+
+def save(trainer, ckpt_path, conf=None, epoch=0, step=0, rng=None, logger=None):
+    """checkpoint of a dynamicpdb_amd.experiment.Trainer in the reference's format (state dicts moved to the host)"""
+    cpu = lambda o: (o.detach().cpu() if torch.is_tensor(o) else {k: cpu(v) for k, v in o.items()} if isinstance(o, dict)
+                     else [cpu(v) for v in o] if isinstance(o, (list, tuple)) else copy.deepcopy(o))
+    write_checkpoint(ckpt_path, cpu(trainer.model.state_dict()), conf, cpu(trainer.opt.state_dict()), epoch, step,
+                     logger=logger, extra=None if rng is None else {'rng': rng.state()})
+
+
+def resume(trainer, ckpt_path, rng=None, strict=True):
+    """True resume: model (strict), optimizer state (exp_avg / exp_avg_sq / max_exp_avg_sq / step of every parameter), the
+    epoch / step counters and -- if the checkpoint holds one -- the device RNG position.  Returns (epoch, step, conf)."""
+    ckpt = read_checkpoint(ckpt_path)
+    model_sd = {k.replace('module.', ''): v for k, v in ckpt['model'].items()}
+    trainer.model.load_state_dict(model_sd, strict=strict)
+    if ckpt.get('optimizer') is not None:
+        trainer.opt.load_state_dict(ckpt['optimizer'])
+    if rng is not None and ckpt.get('extra') and 'rng' in ckpt['extra']:
+        rng.seed, rng.subseq = ckpt['extra']['rng']['seed'], ckpt['extra']['rng']['subseq']
+    return ckpt.get('epoch', 0), ckpt.get('step', 0), ckpt.get('conf')

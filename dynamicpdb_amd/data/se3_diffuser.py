@@ -117,10 +117,12 @@ class SE3Diffuser:
         return _assemble_rigid(rot_t_1, trans_t_1, device)
 
     def reverse_t7(self, rigids_t, rot_score, trans_score, t, dt, diffuse_mask=None, center=True, noise_scale=1.0,
-                   z_rot=None, z_trans=None):
+                   z_rot=None, z_trans=None, rng=None):
         """Device form of `reverse` on tensor_7 frames [..., N, 7] (one HIP launch, csrc/diffusion.hip).  The normal draws
         default to numpy's global RNG in the reference's order (rotations first, se3_diffuser.py:184-190) so that a seeded
-        run consumes the same random stream as the reference; pass device tensors z_rot / z_trans to draw elsewhere."""
+        run consumes the same random stream as the reference; pass device tensors z_rot / z_trans to inject them, or
+        rng = dynamicpdb_amd.rng.DeviceRNG to draw them on the device (Philox4x32-10, no host round trip; rotations
+        first as well)."""
         from ctypes import c_double, c_int32, c_int64
         from .. import _lib
         from ..ops import _p
@@ -132,9 +134,9 @@ class SE3Diffuser:
         rows = t7.numel() // (7 * N)
         shp3 = tuple(t7.shape[:-1]) + (3,)
         if z_rot is None:
-            z_rot = np.random.normal(size=shp3)
+            z_rot = rng.normal(shp3) if rng is not None else np.random.normal(size=shp3)
         if z_trans is None:
-            z_trans = np.random.normal(size=shp3)
+            z_trans = rng.normal(shp3) if rng is not None else np.random.normal(size=shp3)
         as_dev = lambda x, dt_: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(device=dev, dtype=dt_).contiguous()
         zr, zt = as_dev(z_rot, torch.float64), as_dev(z_trans, torch.float64)
         rs, ts = as_dev(rot_score, torch.float64), as_dev(trans_score, torch.float32)
@@ -152,7 +154,7 @@ class SE3Diffuser:
             out[..., 4:] = t7[..., 4:]
         return out
 
-    def forward_marginal_t7(self, rigids_0, t, diffuse_mask=None, u=None, z_dir=None, z_trans=None):
+    def forward_marginal_t7(self, rigids_0, t, diffuse_mask=None, u=None, z_dir=None, z_trans=None, rng=None):
         """Device form of `forward_marginal` on tensor_7 frames: [F,N,7] with scalar t (the reference's per-item call,
         Dfold_data_loader_dynamic.py:336-345) or [B,F,N,7] with t [B] (one t per window).  One HIP launch for the sampling
         (csrc/diffusion.hip) + the IGSO(3) series launch for the rotation score.  Draws default to numpy's global RNG in
@@ -177,6 +179,10 @@ class SE3Diffuser:
         P = t7.numel() // 7
         per_window = P // W
         lead = tuple(t7.shape[:-1])
+        if rng is not None:            # device draws (DeviceRNG): same order as the host path, one subsequence each
+            z_dir = rng.normal((W, per_window, 3)) if z_dir is None else z_dir
+            u = rng.uniform((W, per_window)) if u is None else u
+            z_trans = rng.normal((W, per_window, 3)) if z_trans is None else z_trans
         if u is None or z_dir is None or z_trans is None:
             zd, uu, zt = [], [], []
             for _ in range(W):

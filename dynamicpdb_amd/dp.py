@@ -146,6 +146,7 @@ class GradReducer:
             dist.broadcast_object_list(obj, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                        group=self.group)
         plan = obj[0]
+        self._plan = plan
         mine = sorted(index[id(p)] for p in live)
         if sorted(i for i, _ in plan) != mine:
             raise RuntimeError("ranks disagree on which parameters receive gradients")

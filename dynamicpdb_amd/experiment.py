@@ -100,12 +100,14 @@ def set_t_feats(diffuser, feats, t, like):
 
 
 def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, aux_traj=False, self_condition=True,
-                 noise_scale=1.0, cfg_drop_rate=0.0, cfg_gamma=2.0, z_draws=None):
+                 noise_scale=1.0, cfg_drop_rate=0.0, cfg_gamma=2.0, z_draws=None, rng=None):
     """Reverse-diffusion sampler, device resident (reference Experiment.inference_fn, train_DFOLD_dynamics.py:1425-1547):
     num_t model forwards; between them one dfold_se3_reverse launch instead of the reference's host round trip
     (D2H, scipy, numpy RNG, H2D, CPU eigh).  `data_init` holds [B,F,N,..] (or reference-shaped [F,N,..]) device tensors
     incl. the prior sample 'rigids_t'.  `z_draws`: optional iterable of (z_rot, z_trans) per reverse step (parity tests);
-    default = numpy global RNG in the reference's draw order.  Returns numpy trajectories flipped to start at t = 0."""
+    `rng`: a dynamicpdb_amd.rng.DeviceRNG -- the draws are generated on the device (Philox4x32-10), nothing crosses
+    PCIe inside the loop; default = numpy global RNG in the reference's draw order (a seeded run then consumes the
+    reference's random stream).  Returns numpy trajectories flipped to start at t = 0."""
     import numpy as np
     model.eval()
     feats = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_init.items()}
@@ -132,7 +134,7 @@ def inference_fn(model, diffuser, data_init, num_t=10, min_t=0.01, center=True, 
                 zr, zt = next(z_iter) if z_iter is not None else (None, None)
                 feats['rigids_t'] = diffuser.reverse_t7(feats['rigids_t'], rot_score, trans_score, float(t), dt,
                                                         diffuse_mask=diffuse_mask, center=center, noise_scale=noise_scale,
-                                                        z_rot=zr, z_trans=zt)
+                                                        z_rot=zr, z_trans=zt, rng=rng)
             else:
                 # last step (t == min_t): the state becomes the network's own frame prediction (:1502-1504).  Like the
                 # reference, `rigid_pred` keeps the PREVIOUS step's prediction here (it is only assigned in the branch

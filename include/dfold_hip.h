@@ -267,6 +267,15 @@ int dfold_se3_reverse(const float* t7, const double* rot_score, const float* tra
                       double dt, double noise_scale, double coordinate_scaling, int32_t center, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Device draws for the diffusion steps (replace the host numpy draws inside the sampling loop, src/data/so3_diffuser.py:
+ * 347-349 and r3_diffuser.py:140-147, and of the forward noising, so3_diffuser.py:233-248 / r3_diffuser.py:96-99):
+ * Philox4x32-10, key = seed, counter = (element / 4, subseq); element e = word e % 4 of its counter block.
+ * uniform: (x + 0.5) * 2^-32 in (0,1); normal: fp64 Box-Muller on word pairs (0,1) and (2,3).  out fp64 [n].
+ * ---------------------------------------------------------------------------------------------- */
+int dfold_philox_normal_f64(double* out, int64_t n, uint64_t seed, uint64_t subseq, void* stream);
+int dfold_philox_uniform_f64(double* out, int64_t n, uint64_t seed, uint64_t subseq, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Forward noising q(x_t | x_0) of tensor_7 frames (replaces SE3Diffuser.forward_marginal, src/data/se3_diffuser.py:43-110
  * -> SO3Diffuser.forward_marginal so3_diffuser.py:311-327 (sample :233-248, sample_igso3 :215-231, compose_rotvec
  * src/data/utils.py:184-195) and R3Diffuser.forward_marginal r3_diffuser.py:81-101).  P = windows*frames*residues frames,

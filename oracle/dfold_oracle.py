@@ -697,3 +697,33 @@ def make_atom14(aatype, pos37, mask37):
             "atom14_alt_gt_positions": torch.einsum("...rac,...rab->...rbc", gt_pos, Mr),
             "atom14_alt_gt_exists": torch.einsum("...ra,...rab->...rb", gt_mask, Mr),
             "atom14_atom_is_ambiguous": T["atom14_is_ambiguous"][aatype].to(mask37.dtype)}
+
+
+# ----------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al., SC'11) -- checker of the device draws (csrc/rng.hip); pinned in tests/test_host_cpu.py to
+# the known-answer vectors of the Random123 distribution.  The reference itself draws with numpy on the host
+# (so3_diffuser.py:347-349, r3_diffuser.py:140-147): the device stream is an engine extension, not a reference stream.
+# ----------------------------------------------------------------------------
+
+def philox4x32_10(ctr, key):
+    c, k = [int(x) for x in ctr], [int(x) for x in key]
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xffffffff, p1 & 0xffffffff, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xffffffff, p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return c
+
+
+def philox_stream(seed, subseq, n, normal):
+    """first n elements of stream (seed, subseq) as csrc/rng.hip defines it: fp64 uniforms (x + 0.5) 2^-32 or Box-Muller
+    normals on the word pairs (0,1), (2,3) of each counter block"""
+    out = np.empty((n + 3) // 4 * 4, np.float64)
+    for b in range((n + 3) // 4):
+        x = philox4x32_10([b & 0xffffffff, b >> 32, subseq & 0xffffffff, subseq >> 32], [seed & 0xffffffff, seed >> 32])
+        u = (np.array(x, np.float64) + 0.5) * 2.0 ** -32
+        if normal:
+            r0, r1 = np.sqrt(-2.0 * np.log(u[0])), np.sqrt(-2.0 * np.log(u[2]))
+            u = np.array([r0 * np.cos(2 * np.pi * u[1]), r0 * np.sin(2 * np.pi * u[1]),
+                          r1 * np.cos(2 * np.pi * u[3]), r1 * np.sin(2 * np.pi * u[3])])
+        out[4 * b:4 * b + 4] = u
+    return out[:n]

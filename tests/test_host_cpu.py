@@ -271,3 +271,61 @@ def test_conv_tower_cone_ranges_and_splitk_model(monkeypatch):
     assert ops.conv_splitk(8 * 3 * 256, 600, 1280, "dev") == 1      # N tile does not divide: not eligible
     monkeypatch.setenv("DFOLD_CONV_SPLITK", "0")
     assert ops.conv_splitk(8 * 3 * 256, 640, 1280, "dev") == 1
+
+
+def test_oracle_philox_known_answers():
+    """The oracle's Philox4x32-10 (checker of csrc/rng.hip) against the known-answer vectors shipped with Random123
+    (kat_vectors: philox4x32-10, counter / key -> 4 words)."""
+    from oracle import dfold_oracle as O
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(O.philox4x32_10(ctr, key)) == want
+    u = O.philox_stream(7, 3, 10, normal=False)
+    assert u.shape == (10,) and (u > 0).all() and (u < 1).all()
+    z = O.philox_stream(7, 3, 4000, normal=True)
+    assert abs(z.mean()) < 0.06 and abs(z.std() - 1) < 0.05
+
+
+def test_checkpoint_format_warm_start_and_true_resume(tmp_path):
+    """checkpoint.write_checkpoint writes the reference's dict (src/data/utils.py:353-362); load_pretrained_model mirrors
+    the reference's warm start ('module.' prefixes, shape filter, train:468-499); checkpoint.resume continues a run
+    bit-for-bit (model + Adam(amsgrad) state + counters)."""
+    from dynamicpdb_amd import checkpoint, experiment
+    experiment_loss = experiment.loss_fn
+    experiment.loss_fn = lambda out, batch, **kw: (out.pow(2).mean(), {})
+    try:
+        torch.manual_seed(1)
+        xs = [{"x": torch.randn(5, 8)} for _ in range(4)]
+        m1 = _Toy()
+        t1 = experiment.Trainer(m1, lr=1e-2, last_frame_only=False)
+        for b in xs[:2]:
+            t1.update_fn(b)
+        path = str(tmp_path / "ckpt" / "step_2.pth")
+        checkpoint.save(t1, path, conf={"name": "toy"}, epoch=1, step=2)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert set(ck) == {"model", "conf", "optimizer", "epoch", "step"} and ck["epoch"] == 1 and ck["step"] == 2
+        assert set(ck["model"]) == set(m1.state_dict()) and "state" in ck["optimizer"] and "param_groups" in ck["optimizer"]
+        tail1 = [float(t1.update_fn(b)[0]) for b in xs[2:]]
+        # true resume into a fresh model / optimizer
+        m2 = _Toy()
+        t2 = experiment.Trainer(m2, lr=1e-2, last_frame_only=False)
+        epoch, step, conf = checkpoint.resume(t2, path)
+        assert (epoch, step, conf) == (1, 2, {"name": "toy"})
+        tail2 = [float(t2.update_fn(b)[0]) for b in xs[2:]]
+        assert tail1 == tail2
+        assert all(torch.equal(a, b) for a, b in zip(m1.parameters(), m2.parameters()))
+        # warm start: DDP-prefixed names, one tensor of another shape is skipped, the rest is loaded
+        sd = {"module." + k: v.clone() for k, v in ck["model"].items()}
+        sd["module.big.weight"] = torch.zeros(7, 3)
+        p2 = str(tmp_path / "ddp.pth")
+        checkpoint.write_checkpoint(p2, sd, None, None, 0, 0)
+        m3 = _Toy()
+        before = m3.big.weight.detach().clone()
+        assert checkpoint.load_pretrained_model(m3, p2)
+        assert torch.equal(m3.big.weight, before) and torch.equal(m3.inp.weight, ck["model"]["inp.weight"])
+        assert not checkpoint.load_pretrained_model(m3, str(tmp_path / "missing.pth"))
+    finally:
+        experiment.loss_fn = experiment_loss

@@ -204,7 +204,37 @@ def test_gradient_reducer_path_on_one_gpu():
         for a, b in zip(res[False][0], res[True][0]):
             assert abs(a - b) < 2e-3 * abs(a), (res[False][0], res[True][0])
         assert set(res[False][1]) == set(res[True][1])
+        gmax = max(float(g.norm()) for g in res[False][1].values())
         for n in res[False][1]:
+            if float(res[False][1][n].norm()) < 1e-7 * gmax:
+                continue                      # numerically dead gradients (1e-13): their relative difference is rounding noise
             assert rel_l2(res[True][1][n], res[False][1][n]) < 2e-2, n
     finally:
         dist.destroy_process_group()
+
+
+def test_checkpoint_resume_continues_the_run_on_device(tmp_path):
+    """checkpoint.save after 2 update_fn steps (FusedAdam, conv-tower bf16 caches), checkpoint.resume into a fresh model:
+    the next two losses and all parameters equal the uninterrupted run (the fused Adam state is torch.optim.Adam's, so the
+    same file also loads into torch.optim.Adam)."""
+    from dynamicpdb_amd import checkpoint, experiment
+    dev = torch.device(DEV)
+    F, N, B = 4, 16, 1
+    model, diffuser = _build(F, 3, dev)
+    batch = _batch(diffuser, B, F, N, dev, seed=90)
+    tr = experiment.Trainer(model, lr=1e-3, last_frame_only=True)
+    for _ in range(2):
+        tr.update_fn(batch)
+    path = str(tmp_path / "step_2.pth")
+    checkpoint.save(tr, path, conf=None, epoch=0, step=2)
+    tail = [float(tr.update_fn(batch)[0]) for _ in range(2)]
+    model2, _ = _build(F, 4, dev)                       # other weights: everything must come from the file
+    tr2 = experiment.Trainer(model2, lr=1e-3, last_frame_only=True)
+    assert checkpoint.resume(tr2, path)[:2] == (0, 2)
+    tail2 = [float(tr2.update_fn(batch)[0]) for _ in range(2)]
+    for a, b in zip(tail, tail2):
+        assert abs(a - b) <= 1e-5 * abs(a), (tail, tail2)       # atomics in the weight-gradient reductions: not bitwise
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        assert rel_l2(q, p) < 1e-4, n
+    opt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in tr2.params], lr=1e-3, amsgrad=True)
+    opt.load_state_dict(checkpoint.read_checkpoint(path)["optimizer"])      # interchangeable state layout
