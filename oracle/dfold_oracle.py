@@ -681,6 +681,40 @@ def pair_transition(P, z, mask=None):
     return linear(P, "linear_2", h) * mask[..., None]
 
 
+def _sub(P, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in P.items() if k.startswith(prefix + ".")}
+
+
+def msa_transition(P, m, mask=None):
+    """Algorithm 9 (openfold/model/evoformer.py:41-117): Linear_2(ReLU(Linear_1(LayerNorm(m)))) * mask."""
+    return pair_transition(P, m, mask)        # same arithmetic on the MSA tensor (its own parameter names coincide)
+
+
+def outer_product_mean(P, m, mask=None, eps=1e-3):
+    """Algorithm 10 (openfold/model/outer_product_mean.py:26-129): m [S,N,c_m], mask [S,N] -> [N,N,c_z]."""
+    if mask is None:
+        mask = m.new_ones(m.shape[:-1])
+    x = torch.nn.functional.layer_norm(m, (m.shape[-1],), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
+    a = linear(P, "linear_1", x) * mask[..., None]                      # [S,N,C]
+    b = linear(P, "linear_2", x) * mask[..., None]
+    outer = torch.einsum("sic,sje->ijce", a, b)                          # :51-56 (a, b transposed to [N,S,C] there)
+    outer = linear(P, "linear_out", outer.reshape(outer.shape[:2] + (-1,)))
+    norm = torch.einsum("si,sj->ij", mask, mask)                         # :125
+    return outer / (eps + norm)[..., None]
+
+
+def evoformer_block_core(P, m, z, msa_mask, pair_mask):
+    """EvoformerBlockCore.forward in eval mode (dropout = identity), openfold/model/evoformer.py:172-212."""
+    m = m + msa_transition(_sub(P, "msa_transition"), m, msa_mask)
+    z = z + outer_product_mean(_sub(P, "outer_product_mean"), m, msa_mask)
+    z = z + triangle_multiplication(_sub(P, "tri_mul_out"), z, pair_mask, outgoing=True)
+    z = z + triangle_multiplication(_sub(P, "tri_mul_in"), z, pair_mask, outgoing=False)
+    z = z + triangle_attention(_sub(P, "tri_att_start"), z, pair_mask, starting=True)
+    z = z + triangle_attention(_sub(P, "tri_att_end"), z, pair_mask, starting=False)
+    z = z + pair_transition(_sub(P, "pair_transition"), z, pair_mask)
+    return m, z
+
+
 def make_atom14(aatype, pos37, mask37):
     """make_atom14_masks + make_atom14_positions (data_transforms.py:572-643, :653-752), restated with the reference's
     permutation-matrix formulation (einsum with the 14x14 renaming matrices)."""

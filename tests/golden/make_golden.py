@@ -223,6 +223,59 @@ def golden_pair_transition(N=24, seed=6):
     print("pair transition golden written", sorted(k for k in fix if k.startswith("P.")))
 
 
+def _rand_sd(m, rng, fix, prefix):
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            w = rng.standard_normal(tuple(v.shape), dtype=np.float32) / np.sqrt(v.shape[-1])
+        elif k.endswith("weight"):
+            w = 1.0 + 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        else:
+            w = 0.1 * rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        sd[k] = torch.tensor(w.astype(np.float32))
+        fix[f"{prefix}P.{k}"] = w.astype(np.float32)
+    m.load_state_dict(sd)
+
+
+def golden_pair_stack(S=6, N=24, seed=17):
+    """OuterProductMean (openfold/model/outer_product_mean.py:26-129) with output / input / parameter gradients, and one
+    EvoformerBlockCore (openfold/model/evoformer.py:120-212) in eval mode (dropout = identity): m, z outputs and the
+    gradients of both inputs.  c_m = 64 keeps the fixture small; c_z = 128, 32-channel outer product, 4 x 32 pair heads as
+    openfold/config.py."""
+    from openfold.model.evoformer import EvoformerBlockCore
+    from openfold.model.outer_product_mean import OuterProductMean
+    rng = np.random.default_rng(seed)
+    fix = {}
+    m = torch.tensor(rng.standard_normal((S, N, 64), dtype=np.float32))
+    z = torch.tensor(rng.standard_normal((N, N, 128), dtype=np.float32))
+    msa_mask = torch.tensor((rng.uniform(size=(S, N)) > 0.15).astype(np.float32))
+    pair_mask = torch.tensor((rng.uniform(size=(N, N)) > 0.1).astype(np.float32))
+    fix.update(m=np_(m), z=np_(z), msa_mask=np_(msa_mask), pair_mask=np_(pair_mask))
+    opm = OuterProductMean(64, 128, 32)
+    _rand_sd(opm, rng, fix, "opm.")
+    mm = m.clone().requires_grad_(True)
+    y = opm(mm, mask=msa_mask)
+    gy = torch.tensor(rng.standard_normal(tuple(y.shape), dtype=np.float32))
+    y.backward(gy)
+    fix.update({"opm.out": np_(y), "opm.gy": np_(gy), "opm.gm": np_(mm.grad)})
+    for k, p_ in opm.named_parameters():
+        fix[f"opm.G.{k}"] = np_(p_.grad)
+    core = EvoformerBlockCore(c_m=64, c_z=128, c_hidden_opm=32, c_hidden_mul=128, c_hidden_pair_att=32, no_heads_msa=8,
+                              no_heads_pair=4, transition_n=2, pair_dropout=0.25, inf=1e9, eps=1e-10)
+    _rand_sd(core, rng, fix, "core.")
+    core.eval()
+    mm, zz = m.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    mo, zo = core(mm, zz, msa_mask=msa_mask, pair_mask=pair_mask)
+    gmo = torch.tensor(rng.standard_normal(tuple(mo.shape), dtype=np.float32))
+    gzo = torch.tensor(rng.standard_normal(tuple(zo.shape), dtype=np.float32))
+    ((mo * gmo).sum() + (zo * gzo).sum()).backward()
+    fix.update({"core.m_out": np_(mo), "core.z_out": np_(zo), "core.gm_out": np_(gmo), "core.gz_out": np_(gzo),
+                "core.gm": np_(mm.grad), "core.gz": np_(zz.grad)})
+    fix["core.gnorm"] = np.array([float(p_.grad.norm()) for _, p_ in core.named_parameters()], np.float64)
+    np.savez_compressed(os.path.join(HERE, f"pair_stack_S{S}_N{N}.npz"), **fix)
+    print("pair stack golden written", len(fix), "arrays")
+
+
 def golden_diffuser(exp, F=3, N=16):
     d = exp.diffuser
     so3, r3 = d._so3_diffuser, d._r3_diffuser
@@ -327,8 +380,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pair_transition":
         golden_pair_transition()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pair_stack":
+        golden_pair_stack()
+        sys.exit(0)
     exp = golden_network()
     golden_diffuser(exp)
     golden_triangle()
     golden_dataset_geom()
     golden_pair_transition()
+    golden_pair_stack()

@@ -237,3 +237,26 @@ def test_atom14_transforms_vs_reference_golden():
             assert np.array_equal(got.astype(want.dtype), want), (name, k)
         assert prot[k].dtype == torch.from_numpy(want).dtype, k          # dtypes of the reference's features
     assert float(np.abs(g["atom14_alt_gt_positions"] - g["atom14_gt_positions"]).max()) > 0       # some residues do swap
+
+
+def test_pair_stack_vs_reference_golden():
+    """oracle OuterProductMean (output + all gradients) and EvoformerBlockCore in eval mode (both outputs, both input
+    gradients, every parameter-gradient norm) vs the reference modules (tests/golden/pair_stack_S6_N24.npz)."""
+    g = load_golden("pair_stack_S6_N24.npz")
+    P = {k[6:]: torch.tensor(v).requires_grad_(True) for k, v in g.items() if k.startswith("opm.P.")}
+    m = torch.tensor(g["m"]).requires_grad_(True)
+    y = O.outer_product_mean(P, m, torch.tensor(g["msa_mask"]))
+    assert rel_l2(y, g["opm.out"]) < 1e-5
+    y.backward(torch.tensor(g["opm.gy"]))
+    assert rel_l2(m.grad, g["opm.gm"]) < 1e-4
+    for k, p in P.items():
+        assert rel_l2(p.grad, g["opm.G." + k]) < 1e-4, k
+    names = [k[7:] for k in g if k.startswith("core.P.")]
+    P = {k: torch.tensor(g["core.P." + k]).requires_grad_(True) for k in names}
+    m, z = torch.tensor(g["m"]).requires_grad_(True), torch.tensor(g["z"]).requires_grad_(True)
+    mo, zo = O.evoformer_block_core(P, m, z, torch.tensor(g["msa_mask"]), torch.tensor(g["pair_mask"]))
+    assert rel_l2(mo, g["core.m_out"]) < 1e-5 and rel_l2(zo, g["core.z_out"]) < 1e-5
+    ((mo * torch.tensor(g["core.gm_out"])).sum() + (zo * torch.tensor(g["core.gz_out"])).sum()).backward()
+    assert rel_l2(m.grad, g["core.gm"]) < 1e-4 and rel_l2(z.grad, g["core.gz"]) < 1e-4
+    gn = np.array([float(P[k].grad.norm()) for k in names])
+    assert np.allclose(gn, g["core.gnorm"], rtol=2e-4, atol=1e-7)
