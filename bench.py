@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--selftest-dist", action="store_true",
                     help="only rendezvous (nccl with GPUs, gloo without), all-reduce one number, report n_gpus")
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
+    ap.add_argument("--no-triangle", action="store_true", help="skip the triangle-operator extra object")
     ap.add_argument("--mode", choices=("all_frames", "last_frame"), default="all_frames",
                     help="what the MAIN timed region runs (profiling aid; the contract's headline is all_frames)")
     return ap.parse_args()
@@ -95,6 +96,38 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": "dfold_mfma_gemm320_kernel<1, 5> (5x5 conv implicit GEMM, forward + dgrad launches)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
+
+
+def triangle_roofline(dev, reps=10):
+    """Extra object (not the headline): forward of the north-star-named triangle operators at N_res 256 / 512 on this
+    GPU: whole-call time (HIP events) vs the algorithmic bytes of SURVEY 8d (read z + write out + mask) over the 8 TB/s
+    HBM peak.  Per-stage numbers and counters: scripts/bench_triangle.py, profiles/r2_triangle_*."""
+    from dynamicpdb_amd.model import triangle as T_
+    out = {}
+    for name, ctor in (("tri_mul_out", lambda: T_.TriangleMultiplicationOutgoing(128, 128)),
+                       ("tri_att_start", lambda: T_.TriangleAttentionStartingNode(128, 32, 4))):
+        for n in (256, 512):
+            torch.manual_seed(0)
+            m = ctor().to(dev)
+            z = torch.randn(1, n, n, 128, device=dev) * 1.5
+            mask = (torch.rand(1, n, n, device=dev) > 0.05).float()
+            with torch.no_grad():
+                for _ in range(3):
+                    m(z, mask=mask)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    m(z, mask=mask)
+                e1.record()
+                torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps * 1e-3
+            alg = n * n * (2 * 128 * 4 + 4)
+            out[f"{name}_n{n}"] = {"ms": round(t * 1e3, 4), "algorithmic_bytes": alg, "GBps": round(alg / t / 1e9, 1),
+                                   "hbm_frac": round(alg / t / 8.0e12, 4)}
+    out["note"] = ("forward, fp32 pair tensor, batch 1, fused kernels of csrc/pair_fused.hip; bound = hbm (8 TB/s); the calls are "
+                   "VALU / issue bound, not HBM bound: counters in profiles/r2_triangle_pmc_*.txt, DESIGN.md section 4")
+    return out
 
 
 def cpu_baseline(F, N, seed_w=0):
@@ -275,6 +308,8 @@ def main():
                         "loss, gradients and parameter update identical to the all-frames step (bit-exact conv results), "
                         "4x fewer conv FLOPs at F=32"},
         }
+        if world == 1 and not args.no_triangle:
+            line["triangle"] = triangle_roofline(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
         print(json.dumps(line), flush=True)

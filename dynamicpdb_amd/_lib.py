@@ -6,7 +6,8 @@ import re
 from ctypes import POINTER, Structure, byref, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdfold_hip.so")
+# DFOLD_LIB: diagnostic builds of the same ABI (kernel experiments); the product loads the in-tree library
+LIB_PATH = os.environ.get("DFOLD_LIB") or os.path.join(_HERE, "csrc", "libdfold_hip.so")
 HEADER = os.path.join(_HERE, "..", "include", "dfold_hip.h")
 
 _lib = None

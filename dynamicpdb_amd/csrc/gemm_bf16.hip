@@ -21,6 +21,19 @@
 #include "../../include/dfold_hip.h"
 #include <stdlib.h>
 
+// Diagnostic builds only (scripts/exp_conv_variants.sh): -DDFOLD_EXP_NOWAIT drops the per-step wait for the LDS-DMA (wrong
+// results; its timing shows how much of the K loop is spent waiting for operand tiles), -DDFOLD_EXP_NOBARRIER drops the
+// per-step barrier as well.
+#if defined(DFOLD_EXP_NOWAIT)
+#define DFOLD_EXP_WAIT do { } while (0)
+#else
+#define DFOLD_EXP_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#if defined(DFOLD_EXP_NOBARRIER)
+#define DFOLD_EXP_BARRIER do { } while (0)
+#else
+#define DFOLD_EXP_BARRIER __builtin_amdgcn_s_barrier()
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -601,8 +614,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   if (w < 4) {
     // ---- group A (one wave per SIMD): per K step [fragment reads][40 MFMAs], DMA pieces between the MFMAs ----
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      DFOLD_EXP_WAIT;
+      DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
       const char* base = lds3 + (s & 1) * STAGE_BYTES;
       ldfrag(0, base, 0);
@@ -647,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     mma(1);
     ldfrag(1, lds3, 3);
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      DFOLD_EXP_WAIT;
+      DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
       const char* base = lds3 + (s & 1) * STAGE_BYTES;
       stage((s + 1) & 1);
