@@ -246,8 +246,11 @@ def conv_splitk(M, CO, CI, device):
     return best
 
 
-# DFOLD_CONV_SKIP_PAD=0: walk the all-padding frame taps of the edge tiles too (A/B measurement of the skip)
-_SKIP_PAD_TAPS = os.environ.get("DFOLD_CONV_SKIP_PAD", "1") != "0"
+# DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).
+# Off by default: the skipped K steps (3.75 %) are exact zeros and the results are bit-identical, but the edge tiles then
+# fall out of step with the other workgroups of their XCD, which all stream the same weight K-slab at the same time -- the
+# launch gains 0.5 % and its HBM-side fetch goes from 1.27 GB to 3.4 GB (profiles/r2_pmc_conv.json, scripts/pmc_ab.sh).
+_SKIP_PAD_TAPS = os.environ.get("DFOLD_CONV_SKIP_PAD", "0") == "1"
 
 
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
