@@ -825,7 +825,10 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   // 256 x 256 form of the same kernel (wave tile 64 x 128): N a multiple of 256 -- the per-(window,frame,head) attention
   // products (M = N = 256: one workgroup per batch item reads each operand once) and the 256-wide projections.
   const long tilesq = (long)((d->M + BM3 - 1) / BM3) * (d->N / 256);
-  if (variant >= 256 && variant != 2560 && variant != 3201 && role == 0 && (d->N % 256) == 0 && (d->seglen % BK) == 0 && d->M >= 256 &&
+  // many small batch items whose 256 x 256 tiles would not even fill the chip once (the triangle contraction at
+  // N_res = 256: 128 channel planes = 128 tiles for 256 CUs): 256 x 128 tiles instead (19.5 -> 15.2 us there)
+  const bool half_tiles = tilesq * d->nbatch < 256 && d->M >= 256 && d->nbatch >= 64 && steps >= 4 && tiles256 * d->nbatch >= 192;
+  if (!half_tiles && variant >= 256 && variant != 2560 && variant != 3201 && role == 0 && (d->N % 256) == 0 && (d->seglen % BK) == 0 && d->M >= 256 &&
       steps >= 2 && tilesq * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
     static bool attrq_done = false;
     const size_t lds = 2 * (A3_BYTES + 256 * BK * 2);
@@ -836,7 +839,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<0, 4>), dim3((unsigned)tilesq, d->nbatch, 1), dim3(512), lds, (hipStream_t)stream, p);
     return dfold_check_launch();
   }
-  if (variant >= 256 && d->M >= 1024 && steps >= 4 && tiles256 * d->nbatch >= 192) {
+  if (variant >= 256 && (d->M >= 1024 || (d->M >= 256 && d->nbatch >= 64)) && steps >= 4 && tiles256 * d->nbatch >= 192) {
     static bool attr_done = false;
     if (!attr_done) {
       hipFuncSetAttribute((const void*)dfold_mfma_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2_BYTES);

@@ -79,6 +79,15 @@ struct PairProjParams {
 #define PP_LDS0 (2 * 16384 + 512 + 256 * PP_SPITCH + 64 * PP_GPITCH)
 #define PP_LDS1 (2 * 16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 2048)
 
+// sum over the 16 lanes of a DPP row (all 16 lanes receive it): quad butterflies + two row rotations, 4 VALU ops
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov_f<0xb1>(0.f, v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4e>(0.f, v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x124>(0.f, v);   // row_ror 4
+  v += dpp_mov_f<0x128>(0.f, v);   // row_ror 8
+  return v;
+}
+
 template <int MODE, bool XBF16>
 __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) {
   constexpr int NG = MODE == 0 ? 5 : 4;
@@ -109,41 +118,62 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wf[g][ks] = *(const bf16x8*)(p.W + (long)n * 128 + ks * 32 + l4 * 8);
   }
-  const float2 gam = ((const float2*)p.gamma)[lane], bet = ((const float2*)p.beta)[lane];
-  float2 wt[4];
+  // LayerNorm layout: 16 lanes per cell (lane l15 holds channels 8*l15 .. +8), four cells per pass (row l4 of the quad):
+  // the two reductions of a cell are 4 DPP steps each and serve four cells at once
+  float gam[8], bet[8], wt[4][8];
 #pragma unroll
-  for (int h = 0; h < 4; ++h) wt[h] = MODE == 1 ? ((const float2*)p.wtri)[h * 64 + lane] : make_float2(0.f, 0.f);
+  for (int i = 0; i < 8; ++i) {
+    gam[i] = p.gamma[l15 * 8 + i];
+    bet[i] = p.beta[l15 * 8 + i];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) wt[h][i] = MODE == 1 ? p.wtri[h * 128 + l15 * 8 + i] * 1.44269504088896341f : 0.f;   // bias consumed in the log2 domain
+  }
 
   const int tpl = NP / PP_TILE;
   const unsigned ntiles = (unsigned)p.B * (unsigned)N * (unsigned)tpl;   // < 2^31, checked by the launcher
+  const unsigned esz = XBF16 ? 2u : 4u;
+  const unsigned rstride_in = (p.swap ? (unsigned)N : 1u) * 128u * esz;   // bytes between consecutive cells of a tile
+  // per-thread byte offsets of the stream-out vectors relative to the tile's first element (tile-invariant)
+  unsigned voff_pl[4], voff_cl[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 512 * i;
+    voff_pl[i] = MODE == 0 ? ((unsigned)(id >> 3) * (unsigned)N * (unsigned)NP + (unsigned)(id & 7) * 8u) * 2u
+                           : ((unsigned)(id >> 3) * (unsigned)NP + (unsigned)(id & 7) * 8u) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 512 * i;
+    voff_cl[i] = (unsigned)(id >> 4) * ((MODE == 0 && p.swap) ? (unsigned)N : 1u) * 256u + (unsigned)(id & 15) * 16u;
+  }
 
-  float2 zr[8];
-  float mk = 0.f;
+  f32x4 zr[2][2];
+  float mk[2] = {0.f, 0.f};
   auto issue = [&](unsigned t) __attribute__((always_inline)) {
     const int pt = (int)(t % (unsigned)tpl);
     const unsigned bl = t / (unsigned)tpl;
     const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
+    const long cell0 = p.swap ? ((long)b * N + pt * PP_TILE) * N + line : ((long)b * N + line) * N + pt * PP_TILE;
+    const char* base = (const char*)p.x + cell0 * (128 * (long)esz);     // wave-uniform
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int pos = pt * PP_TILE + w * 8 + q;
-      float2 v = make_float2(0.f, 0.f);
-      if (pos < N) {
-        const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
-        if (XBF16) {
-          const uint32_t u = ((const uint32_t*)p.x)[cell * 64 + lane];
-          v = make_float2(bf_lo(u), bf_hi(u));
-        } else {
-          v = ((const float2*)p.x)[cell * 64 + lane];
-        }
+    for (int qd = 0; qd < 2; ++qd) {
+      // cells past the row end re-read the last valid cell: their mask is zero (a = b = 0) and their rows are not stored
+      int r = w * 8 + qd * 4 + l4;
+      const int over = pt * PP_TILE + r - (N - 1);
+      r -= over > 0 ? over : 0;
+      const char* src = base + (unsigned)r * rstride_in + (unsigned)l15 * (8u * esz);
+      if (XBF16) {
+        const uint4 u = *(const uint4*)src;
+        zr[qd][0] = (f32x4){bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+        zr[qd][1] = (f32x4){bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+      } else {
+        zr[qd][0] = *(const f32x4*)src;
+        zr[qd][1] = *(const f32x4*)(src + 16);
       }
-      zr[q] = v;
-    }
-    if (MODE == 0) {
-      mk = 0.f;
-      const int pos = pt * PP_TILE + w * 8 + (lane & 7);
-      if (lane < 8 && pos < N) {
-        const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
-        mk = p.mask[cell];
+      if (MODE == 0) {
+        const int pos = pt * PP_TILE + w * 8 + qd * 4 + l4;
+        mk[qd] = 0.f;
+        if (l15 == 0 && pos < N) mk[qd] = p.mask[cell0 + (long)(w * 8 + qd * 4 + l4) * (p.swap ? N : 1)];
       }
     }
   };
@@ -152,37 +182,35 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   auto stream_out = [&](int b, int line, int pt, int par) __attribute__((always_inline)) {
     const int pos0 = pt * PP_TILE;
     if (MODE == 0) {
+      char* const pbase = (char*)p.o0 + ((((long)b * 256) * N + line) * NP + pos0) * 2;          // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        const uint4 val = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
-        *(uint4*)(p.o0 + (((long)b * 256 + pl) * N + line) * NP + pos0 + v * 8) = val;
+        *(uint4*)(pbase + voff_pl[i]) = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
       }
+      const long cell0 = p.swap ? ((long)b * N + pos0) * N + line : ((long)b * N + line) * N + pos0;
+      char* const gbase = (char*)p.o1 + cell0 * 256;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        const int pos = pos0 + cr;
-        if (pos < N) {
-          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
-          *(uint4*)(p.o1 + cell * 128 + v * 8) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
-        }
+        if (pos0 + cr < N) *(uint4*)(gbase + voff_cl[i]) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
       }
     } else {
+      const long cell0 = ((long)b * N + line) * N + pos0;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        const int pos = pos0 + cr;
-        if (pos < N) {
-          const long cell = ((long)b * N + line) * N + pos;
-          *(uint4*)(p.o0 + cell * 128 + v * 8) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
-          *(uint4*)(p.o1 + cell * 128 + v * 8) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
-          *(uint4*)(p.o3 + cell * 128 + v * 8) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
+        if (pos0 + cr < N) {
+          *(uint4*)((char*)p.o0 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
+          *(uint4*)((char*)p.o1 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
+          *(uint4*)((char*)p.o3 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
         }
       }
+      char* const vbase = (char*)p.o2 + ((((long)b * N + line) * 128) * NP + pos0) * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(p.o2 + (((long)b * N + line) * 128 + pl) * NP + pos0 + v * 8) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
+        *(uint4*)(vbase + voff_pl[i]) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
       }
       if (tid < 64) {
         const int h = tid >> 4, v = tid & 15;
@@ -206,33 +234,50 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     char* const ldsA = ldsA2 + par * 16384;
     float* const ldsM = ldsM2 + par * 64;
 
-    // ---- S0: LayerNorm of this wave's 8 cells (one cell per pass, lane = channels 2l, 2l+1) -> bf16 A tile ----
+    // ---- S0: LayerNorm of this wave's 8 cells, four at a time -> bf16 A tile (one 16-byte chunk per lane) ----
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int row = w * 8 + q;
-      const float mean = wave_sum(zr[q].x + zr[q].y) * (1.f / 128.f);
-      const float d0 = zr[q].x - mean, d1 = zr[q].y - mean;
-      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-      const float rstd = rsqrtf(var + p.eps);
-      const float v0 = d0 * rstd * gam.x + bet.x, v1 = d1 * rstd * gam.y + bet.y;
-      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) = pack2bf_hw(v0, v1);
+    for (int qd = 0; qd < 2; ++qd) {
+      const int row = w * 8 + qd * 4 + l4;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] = zr[qd][0][i];
+        x[4 + i] = zr[qd][1][i];
+      }
+      const float mean = row16_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.f / 128.f);
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] -= mean;
+        q2 = __builtin_fmaf(x[i], x[i], q2);
+      }
+      const float rstd = rsqrtf(row16_sum(q2) * (1.f / 128.f) + p.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i] * rstd, gam[i], bet[i]);
+      *(uint4*)(ldsA + a_tile_off(row, l15)) =
+          make_uint4(pack2bf_hw(x[0], x[1]), pack2bf_hw(x[2], x[3]), pack2bf_hw(x[4], x[5]), pack2bf_hw(x[6], x[7]));
       if (MODE == 1) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const float th = wave_sum(v0 * wt[h].x + v1 * wt[h].y);
-          if (lane == 0) ldsT[par * 256 + h * 64 + row] = th * 1.44269504088896341f;   // consumed in the log2 domain
+          float th = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) th = __builtin_fmaf(x[i], wt[h][i], th);
+          th = row16_sum(th);
+          if (l15 == 0) ldsT[par * 256 + h * 64 + row] = th;
         }
       }
-      if (MODE == 0 && p.f0 != nullptr) {
-        const int pos = pt * PP_TILE + row;
-        if (lane == 0 && pos < N) {
-          const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
-          p.f0[2 * cell] = mean;
-          p.f0[2 * cell + 1] = rstd;
+      if (MODE == 0) {
+        if (l15 == 0) ldsM[row] = mk[qd];
+        if (p.f0 != nullptr) {
+          const int pos = pt * PP_TILE + row;
+          if (l15 == 0 && pos < N) {
+            const long cell = p.swap ? ((long)b * N + pos) * N + line : ((long)b * N + line) * N + pos;
+            p.f0[2 * cell] = mean;
+            p.f0[2 * cell + 1] = rstd;
+          }
         }
       }
     }
-    if (MODE == 0 && lane < 8) ldsM[w * 8 + lane] = mk;
     __syncthreads();
 
     // ---- S1: prefetch the next tile's rows, stream the previous tile out (both in flight during the MFMA phase) ----
@@ -310,7 +355,9 @@ static int pair_proj_launch(int mode, const PairProjParams& p, int x_is_bf16, hi
 }
 
 static bool pf_dims_ok(int B, int N, int NP) {
-  return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * (NP / PP_TILE) < (1L << 31) && (long)B * N * N < (1L << 40);
+  // 32-bit per-thread byte offsets inside one batch item's planes (256 N NP bf16) and inside a tile of transposed cells
+  return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * (NP / PP_TILE) < (1L << 31) && (long)B * N * N < (1L << 40) &&
+         512L * N * NP < (1L << 32) && 64L * N * 512 < (1L << 32);
 }
 
 extern "C" int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma,
@@ -375,7 +422,12 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wz[ks] = *(const bf16x8*)(p.Wz + (long)(16 * w + l15) * 128 + ks * 32 + l4 * 8);
   const float bz = p.bz[16 * w + l15];
-  const float2 gam = ((const float2*)p.gamma)[lane], bet = ((const float2*)p.beta)[lane];
+  float gam[8], bet[8];            // LayerNorm layout as in pair_proj_kernel: 16 lanes per cell, 8 channels per lane
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    gam[i] = p.gamma[l15 * 8 + i];
+    bet[i] = p.beta[l15 * 8 + i];
+  }
 
   const int tpl = NP / PP_TILE;
   const unsigned ntiles = (unsigned)p.B * (unsigned)N * (unsigned)tpl;
@@ -448,18 +500,29 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
       }
     }
     __syncthreads();
-    // ---- S0b: LayerNorm over channels -> bf16 A tile ----
+    // ---- S0b: LayerNorm over channels, four cells per pass -> bf16 A tile ----
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int row = w * 8 + q;
-      const uint32_t u = *(const uint32_t*)(ldsX + row * TO_XPITCH + lane * 4);
-      const float x0 = bf_lo(u), x1 = bf_hi(u);
-      const float mean = wave_sum(x0 + x1) * (1.f / 128.f);
-      const float d0 = x0 - mean, d1 = x1 - mean;
-      const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-      const float rstd = rsqrtf(var + p.eps);
-      *(uint32_t*)(ldsA + a_tile_off(row, lane >> 2) + ((lane & 3) << 2)) =
-          pack2bf_hw(d0 * rstd * gam.x + bet.x, d1 * rstd * gam.y + bet.y);
+    for (int qd = 0; qd < 2; ++qd) {
+      const int row = w * 8 + qd * 4 + l4;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t u = *(const uint32_t*)(ldsX + row * TO_XPITCH + l15 * 16 + i * 4);
+        x[2 * i] = bf_lo(u);
+        x[2 * i + 1] = bf_hi(u);
+      }
+      const float mean = row16_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.f / 128.f);
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] -= mean;
+        q2 = __builtin_fmaf(x[i], x[i], q2);
+      }
+      const float rstd = rsqrtf(row16_sum(q2) * (1.f / 128.f) + p.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i] * rstd, gam[i], bet[i]);
+      *(uint4*)(ldsA + a_tile_off(row, l15)) =
+          make_uint4(pack2bf_hw(x[0], x[1]), pack2bf_hw(x[2], x[3]), pack2bf_hw(x[4], x[5]), pack2bf_hw(x[6], x[7]));
     }
     if (t + gridDim.x < ntiles) issue(t + gridDim.x);
     if (have_prev) stream_out(pb, pi, pjt);

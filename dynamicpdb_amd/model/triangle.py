@@ -188,37 +188,52 @@ def _recompute_grads(fn, x, mask, dout, head_args, params, transpose=False):
         return torch.autograd.grad(y, [xs] + ps, dout.reshape(y.shape).float(), allow_unused=True)
 
 
+def _ws_get(ws, key, shape, dtype, dev):
+    """caller-owned workspace: scratch tensors reused across calls of one module (same stream -> ordered)"""
+    if ws is None:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    t = ws.get(key)
+    if t is None or t.shape != torch.Size(shape) or t.dtype != dtype or t.device != dev:
+        t = ws[key] = torch.empty(shape, dtype=dtype, device=dev)
+    return t
+
+
+def _trimul_fused(z, mask, outgoing, pack, ws=None):
+    """Fused forward (csrc/pair_fused.hip), three launches: LayerNorm + 640-wide projection + gates -> a|b planes and the
+    output gate; x_c = a_c b_c^T batched over (B, channel) on the MFMA engine; LayerNorm_out + linear_z + gate.
+    z [B,N,N,128] fp32|bf16, mask [B,N,N]; pack = TriangleMultiplicativeUpdate._packed().  Returns (out, z used, mask used)."""
+    L = _lib.lib()
+    wcat, bcat, wz, g_in, b_in, g_out, b_out, b_z = pack
+    B, N = z.shape[0], z.shape[1]
+    NP = _np64(N)
+    dev = z.device
+    zc = z if z.is_contiguous() else z.contiguous()
+    if zc.dtype not in (torch.float32, BF16):
+        zc = zc.float()
+    maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
+    planes = _ws_get(ws, "planes", (B, 256, N, NP), BF16, dev)
+    gate = _ws_get(ws, "gate", (B, N, N, 128), BF16, dev)
+    xpl = _ws_get(ws, "xpl", (B, 128, N, NP), BF16, dev)
+    st = stream()
+    check(L.dfold_trimul_proj_fwd(_p(zc), c_int32(1 if zc.dtype == BF16 else 0), _p(maskf), _p(g_in), _p(b_in), _p(wcat),
+                                  _p(bcat), _p(planes), _p(gate), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP),
+                                  c_int32(0 if outgoing else 1), ctypes_float(1e-5), st), "dfold_trimul_proj_fwd")
+    pl = N * NP
+    gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(NP), c_rows=rows_plain(NP), ldb=NP, nbatch=B * 128, nb1=128,
+         sa=(256 * pl, pl), sb=(256 * pl, pl), sc=(128 * pl, pl), b_off=128 * pl)               # x_c = a_c b_c^T  (:113-118)
+    out = torch.empty((B, N, N, 128), dtype=zc.dtype, device=dev)
+    check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(g_out), _p(b_out), _p(wz), _p(b_z), _p(out),
+                                 c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
+                                 ctypes_float(1e-5), st), "dfold_trimul_out_fwd")
+    return out, zc, maskf
+
+
 class TriMulFusedFn(Function):
-    """z [B,N,N,128] fp32|bf16, mask [B,N,N] -> same shape/dtype as z: three launches (csrc/pair_fused.hip):
-    LayerNorm + 640-wide projection + gates -> a|b planes and the output gate; x_c = a_c b_c^T batched over (B, channel)
-    on the MFMA engine; LayerNorm_out + linear_z + gate."""
+    """autograd node of the fused forward; the backward re-derives the unfused chain from the saved inputs"""
 
     @staticmethod
-    def forward(ctx, z, mask, outgoing, wcat, bcat, wz, *params):
-        L = _lib.lib()
-        (g_in, b_in, w_ap, b_ap, w_ag, b_ag, w_bp, b_bp, w_bg, b_bg, w_g, b_g, w_z, b_z, g_out, b_out) = params
-        B, N = z.shape[0], z.shape[1]
-        NP = _np64(N)
-        dev = z.device
-        zc = z.contiguous()
-        if zc.dtype not in (torch.float32, BF16):
-            zc = zc.float()
-        maskf = mask.contiguous().float()
-        planes = torch.empty((B, 256, N, NP), dtype=BF16, device=dev)
-        gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
-        f32 = lambda t: t.detach().float().contiguous()
-        check(L.dfold_trimul_proj_fwd(_p(zc), c_int32(1 if zc.dtype == BF16 else 0), _p(maskf), _p(f32(g_in)), _p(f32(b_in)),
-                                      _p(wcat), _p(bcat), _p(planes), _p(gate), c_void_p(0), c_int32(B), c_int32(N),
-                                      c_int32(NP), c_int32(0 if outgoing else 1), ctypes_float(1e-5), stream()),
-              "dfold_trimul_proj_fwd")
-        xpl = torch.empty((B, 128, N, NP), dtype=BF16, device=dev)
-        pl = N * NP
-        gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(NP), c_rows=rows_plain(NP), ldb=NP, nbatch=B * 128, nb1=128,
-             sa=(256 * pl, pl), sb=(256 * pl, pl), sc=(128 * pl, pl), b_off=128 * pl)           # x_c = a_c b_c^T  (:113-118)
-        out = torch.empty((B, N, N, 128), dtype=zc.dtype, device=dev)
-        check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(f32(g_out)), _p(f32(b_out)), _p(wz), _p(f32(b_z)), _p(out),
-                                     c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
-                                     ctypes_float(1e-5), stream()), "dfold_trimul_out_fwd")
+    def forward(ctx, z, mask, outgoing, pack, ws, *params):
+        out, zc, maskf = _trimul_fused(z, mask, outgoing, pack, ws)
         ctx.save_for_backward(zc, maskf, *params)
         ctx.outgoing = outgoing
         return out
@@ -227,7 +242,7 @@ class TriMulFusedFn(Function):
     def backward(ctx, dout):
         zc, maskf, *params = ctx.saved_tensors
         g = _recompute_grads(TriangleMultiplicationFn, zc, maskf, dout, (ctx.outgoing,), params)
-        return (g[0].to(zc.dtype), None, None, None, None, None, *g[1:])
+        return (g[0].to(zc.dtype), None, None, None, None, *g[1:])
 
 
 class TriangleMultiplicativeUpdate(nn.Module):
@@ -261,18 +276,23 @@ class TriangleMultiplicativeUpdate(nn.Module):
                 self.layer_norm_out.weight, self.layer_norm_out.bias)
 
     def _packed(self):
-        """bf16 [a_p|a_g|b_p|b_g|g] weight block, fp32 bias block, bf16 linear_z weight; rebuilt when a parameter changes"""
+        """bf16 [a_p|a_g|b_p|b_g|g] weight block, fp32 bias block, bf16 linear_z weight, fp32 LayerNorm / bias vectors;
+        rebuilt when a parameter changes"""
         ps = self._params()
         stamp = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_pack", None) is None or self._pack[0] != stamp:
+            f32 = lambda t: t.detach().float().contiguous()
             with torch.no_grad():
                 wcat = torch.cat([self.linear_a_p.weight, self.linear_a_g.weight, self.linear_b_p.weight,
                                   self.linear_b_g.weight, self.linear_g.weight], 0).to(BF16).contiguous()
                 bcat = torch.cat([self.linear_a_p.bias, self.linear_a_g.bias, self.linear_b_p.bias, self.linear_b_g.bias,
                                   self.linear_g.bias]).float().contiguous()
                 wz = self.linear_z.weight.to(BF16).contiguous()
-            self._pack = (stamp, wcat, bcat, wz)
-        return self._pack[1:]
+                pack = (wcat, bcat, wz, f32(self.layer_norm_in.weight), f32(self.layer_norm_in.bias),
+                        f32(self.layer_norm_out.weight), f32(self.layer_norm_out.bias), f32(self.linear_z.bias))
+            self._pack = (stamp, pack)
+            self._ws = {}
+        return self._pack[1]
 
     def forward(self, z, mask=None):
         if not z.is_cuda:
@@ -281,7 +301,11 @@ class TriangleMultiplicativeUpdate(nn.Module):
             mask = z.new_ones(z.shape[:-1])
         if self.c_z == 128 and self.c_hidden == 128 and _use_fused():
             zs, ms = z.reshape((-1,) + z.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
-            y = TriMulFusedFn.apply(zs, ms, self._outgoing, *self._packed(), *self._params())
+            pack = self._packed()
+            if torch.is_grad_enabled() and (zs.requires_grad or any(p.requires_grad for p in self._params())):
+                y = TriMulFusedFn.apply(zs, ms, self._outgoing, pack, None, *self._params())
+            else:       # inference: no autograd node, scratch tensors reused across calls
+                y = _trimul_fused(zs, ms, self._outgoing, pack, self._ws)[0]
             return y.reshape(z.shape)
         if z.shape[-2] % 8:
             raise ValueError("the unfused triangle path needs N_res % 8 == 0")
@@ -409,38 +433,43 @@ class TriangleAttentionFn(Function):
                 dwcat[3 * HC:], dbcat[3 * HC:], dw_o, db_o)
 
 
+def _triatt_fused(x, mask, starting, inf, pack, ws=None):
+    """Fused forward (csrc/pair_fused.hip), two launches: LayerNorm + q|k|v|g projections + triangle bias; flash-style gated
+    attention per row + linear_o (no [I,H,N,N] logits in HBM).  x [B,N,N,128] fp32|bf16, NOT transposed for the ending
+    node (the kernels index x^T); pack = TriangleAttention._packed().  Returns (out, x used, mask used)."""
+    L = _lib.lib()
+    wcat, bcat, wo, g_ln, b_ln, w_tri, b_o = pack
+    B, N = x.shape[0], x.shape[1]
+    NP = _np64(N)
+    dev = x.device
+    xc = x if x.is_contiguous() else x.contiguous()
+    if xc.dtype not in (torch.float32, BF16):
+        xc = xc.float()
+    maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
+    q = _ws_get(ws, "q", (B, N, N, 128), BF16, dev)
+    k = _ws_get(ws, "k", (B, N, N, 128), BF16, dev)
+    gate = _ws_get(ws, "gate", (B, N, N, 128), BF16, dev)
+    vT = _ws_get(ws, "vT", (B, N, 128, NP), BF16, dev)
+    tri = _ws_get(ws, "tri", (B, 4, N, NP), torch.float32, dev)
+    ending = 0 if starting else 1
+    st = stream()
+    check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(wcat), _p(bcat),
+                                  _p(w_tri), _p(q), _p(k), _p(vT), _p(gate), _p(tri), c_int32(B), c_int32(N), c_int32(NP),
+                                  c_int32(ending), ctypes_float(1e-5), st), "dfold_triatt_proj_fwd")
+    out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
+    check(L.dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(maskf), _p(wo), _p(b_o), _p(out),
+                                  c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
+                                  c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)), st),
+          "dfold_triatt_core_fwd")
+    return out, xc, maskf
+
+
 class TriAttFusedFn(Function):
-    """x [B,N,N,128] fp32|bf16 (NOT transposed for the ending node: the kernels index x^T), mask [B,N,N] -> like x.
-    Two launches (csrc/pair_fused.hip): LayerNorm + q|k|v|g projections + triangle bias; flash-style gated attention per
-    row + linear_o.  No [I,H,N,N] logits in HBM."""
+    """autograd node of the fused forward; the backward re-derives the unfused chain from the saved inputs"""
 
     @staticmethod
-    def forward(ctx, x, mask, starting, inf, wcat, bcat, wo, *params):
-        L = _lib.lib()
-        (g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o) = params
-        B, N = x.shape[0], x.shape[1]
-        NP = _np64(N)
-        dev = x.device
-        xc = x.contiguous()
-        if xc.dtype not in (torch.float32, BF16):
-            xc = xc.float()
-        maskf = mask.contiguous().float()
-        f32 = lambda t: t.detach().float().contiguous()
-        q = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
-        k = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
-        gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
-        vT = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
-        tri = torch.empty((B, 4, N, NP), dtype=torch.float32, device=dev)
-        ending = 0 if starting else 1
-        check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(f32(g_ln)), _p(f32(b_ln)), _p(wcat),
-                                      _p(bcat), _p(f32(w_tri)), _p(q), _p(k), _p(vT), _p(gate), _p(tri), c_int32(B),
-                                      c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), stream()),
-              "dfold_triatt_proj_fwd")
-        out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
-        check(L.dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(maskf), _p(wo), _p(f32(b_o)), _p(out),
-                                      c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
-                                      c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)), stream()),
-              "dfold_triatt_core_fwd")
+    def forward(ctx, x, mask, starting, inf, pack, ws, *params):
+        out, xc, maskf = _triatt_fused(x, mask, starting, inf, pack, ws)
         ctx.save_for_backward(xc, maskf, *params)
         ctx.starting, ctx.inf = starting, inf
         return out
@@ -449,7 +478,7 @@ class TriAttFusedFn(Function):
     def backward(ctx, dout):
         xc, maskf, *params = ctx.saved_tensors
         g = _recompute_grads(TriangleAttentionFn, xc, maskf, dout, (4, ctx.inf), params, transpose=not ctx.starting)
-        return (g[0].to(xc.dtype), None, None, None, None, None, None, *g[1:])
+        return (g[0].to(xc.dtype), None, None, None, None, None, *g[1:])
 
 
 class _Attention(nn.Module):
@@ -479,18 +508,27 @@ class TriangleAttention(nn.Module):
                                          self.linear.weight, m.linear_q.weight, m.linear_k.weight, m.linear_v.weight,
                                          m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
 
+    def _att_params(self):
+        m = self.mha
+        return (self.layer_norm.weight, self.layer_norm.bias, self.linear.weight, m.linear_q.weight, m.linear_k.weight,
+                m.linear_v.weight, m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
+
     def _packed(self):
         m = self.mha
-        ps = (m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_g.weight, m.linear_g.bias, m.linear_o.weight)
+        ps = self._att_params()
         stamp = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_pack", None) is None or self._pack[0] != stamp:
+            f32 = lambda t: t.detach().float().contiguous()
             with torch.no_grad():
                 wcat = torch.cat([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_g.weight], 0).to(BF16).contiguous()
                 hc = m.linear_q.weight.shape[0]
                 bcat = torch.cat([torch.zeros(3 * hc, device=wcat.device), m.linear_g.bias.float()]).contiguous()
                 wo = m.linear_o.weight.to(BF16).contiguous()
-            self._pack = (stamp, wcat, bcat, wo)
-        return self._pack[1:]
+                pack = (wcat, bcat, wo, f32(self.layer_norm.weight), f32(self.layer_norm.bias), f32(self.linear.weight),
+                        f32(m.linear_o.bias))
+            self._pack = (stamp, pack)
+            self._ws = {}
+        return self._pack[1]
 
     def forward(self, x, mask=None, chunk_size=None, use_memory_efficient_kernel=False, use_lma=False, inplace_safe=False):
         if not x.is_cuda:
@@ -498,11 +536,13 @@ class TriangleAttention(nn.Module):
         if mask is None:
             mask = x.new_ones(x.shape[:-1])
         if self.c_in == 128 and self.c_hidden == 32 and self.no_heads == 4 and _use_fused():
-            m = self.mha
             xs, ms = x.reshape((-1,) + x.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
-            y = TriAttFusedFn.apply(xs, ms, self.starting, self.inf, *self._packed(), self.layer_norm.weight,
-                                    self.layer_norm.bias, self.linear.weight, m.linear_q.weight, m.linear_k.weight,
-                                    m.linear_v.weight, m.linear_g.weight, m.linear_g.bias, m.linear_o.weight, m.linear_o.bias)
+            pack = self._packed()
+            ps = self._att_params()
+            if torch.is_grad_enabled() and (xs.requires_grad or any(p.requires_grad for p in ps)):
+                y = TriAttFusedFn.apply(xs, ms, self.starting, self.inf, pack, None, *ps)
+            else:
+                y = _triatt_fused(xs, ms, self.starting, self.inf, pack, self._ws)[0]
             return y.reshape(x.shape)
         if x.shape[-2] % 8:
             raise ValueError("the unfused triangle path needs N_res % 8 == 0")

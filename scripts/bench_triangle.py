@@ -58,7 +58,7 @@ def _stages_mul(m, z, mask, reps):
     NP = (N + 63) // 64 * 64
     dev = z.device
     es = z.element_size()
-    wcat, bcat, wz = m._packed()
+    wcat, bcat, wz = m._packed()[:3]
     f32 = lambda t: t.detach().float().contiguous()
     gi, bi, go, bo, bz = (f32(m.layer_norm_in.weight), f32(m.layer_norm_in.bias), f32(m.layer_norm_out.weight),
                           f32(m.layer_norm_out.bias), f32(m.linear_z.bias))
@@ -103,7 +103,7 @@ def _stages_att(m, x, mask, reps):
     NP = (N + 63) // 64 * 64
     dev = x.device
     es = x.element_size()
-    wcat, bcat, wo = m._packed()
+    wcat, bcat, wo = m._packed()[:3]
     f32 = lambda t: t.detach().float().contiguous()
     g, b, wt, bo = f32(m.layer_norm.weight), f32(m.layer_norm.bias), f32(m.linear.weight), f32(m.mha.linear_o.bias)
     q = torch.empty((B, N, N, 128), dtype=BF16, device=dev)

@@ -57,7 +57,7 @@ def test_trimul_proj_stage(N, incoming):
     m = _rand_module(T.TriangleMultiplicationOutgoing(128, 128), 5).to(dev)
     z, mask = _inputs(B, N, 3)
     z, mask = z.to(dev), mask.to(dev)
-    wcat, bcat, _ = m._packed()
+    wcat, bcat = m._packed()[:2]
     NP = (N + 63) // 64 * 64
     planes = torch.full((B, 256, N, NP), 7.0, dtype=BF16, device=dev)
     gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
@@ -96,7 +96,7 @@ def test_trimul_out_stage(N):
     NP = (N + 63) // 64 * 64
     x = torch.tensor(rng.standard_normal((B, 128, N, NP), dtype=np.float32) * 3.0 + 0.5).to(dev).to(BF16)
     gate = torch.tensor(rng.uniform(size=(B, N, N, 128)).astype(np.float32)).to(dev).to(BF16)
-    _, _, wz = m._packed()
+    wz = m._packed()[2]
     f32 = lambda t: t.detach().float().contiguous()
     with torch.no_grad():
         xc = x[..., :N].float().permute(0, 2, 3, 1)                 # [B, i, j, c]
@@ -131,7 +131,7 @@ def test_triatt_proj_stage(N, ending):
     m = _rand_module(T.TriangleAttentionStartingNode(128, 32, 4), 9).to(dev)
     x, _ = _inputs(B, N, 4)
     x = x.to(dev)
-    wcat, bcat, _ = m._packed()
+    wcat, bcat = m._packed()[:2]
     NP = (N + 63) // 64 * 64
     q = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
     k, gate = torch.empty_like(q), torch.empty_like(q)
@@ -169,7 +169,7 @@ def test_triatt_core_stage(N, ending):
     gate = torch.tensor(rng.uniform(size=(B, N, N, 128)).astype(np.float32)).to(dev).to(BF16)
     tri = mk(B, 4, N, NP)
     mask = torch.tensor((rng.uniform(size=(B, N, N)) > 0.2).astype(np.float32)).to(dev)      # coordinates of x
-    _, _, wo = m._packed()
+    wo = m._packed()[2]
     out = torch.empty((B, N, N, 128), dtype=torch.float32, device=dev)
     tri_l2 = (tri * math.log2(math.e)).contiguous()      # ABI: the bias arrives pre-multiplied by log2(e)
     check(_lib.lib().dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri_l2), _p(mask), _p(wo),
