@@ -7,7 +7,7 @@
 // happens in registers / LDS:
 //
 //   pair_proj_kernel<0>   LayerNorm_in -> 5 projections (a_p|a_g|b_p|b_g|g: one 640-wide MFMA product per 64-cell
-//                         tile) -> sigmoid gates * mask -> a|b written as bf16 K-contiguous PLANES [B][256][N][NP]
+//                         tile) -> sigmoid gates * mask -> a|b written as bf16 K-contiguous PLANES [B][N][256][NP]
 //                         (the layout the ik,jk->ij contraction consumes: no transposes), output gate sigmoid(g) bf16.
 //   (contraction)         x_c = a_c b_c^T per (batch, channel) on the bf16 MFMA engine (dfold_gemm_bf16, batched).
 //   trimul_out_kernel     x planes -> LDS transpose -> LayerNorm_out -> linear_z (MFMA) -> * gate -> out.
@@ -30,6 +30,23 @@
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+// Diagnostic builds only (scripts/build_variant.sh, timing experiments with wrong results): PF_EXP_NOSTORE drops the global
+// stores of pair_proj_kernel, PF_EXP_NOEPI its sigmoid / gate arithmetic, PF_EXP_NOMFMA its MFMAs.
+#if defined(PF_EXP_NOMFMA)
+#define MFMA16P(a, b, c) (c)
+#else
+#define MFMA16P(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#if defined(PF_EXP_NOEPI)
+#define SIGM_P(x) (x)
+#else
+#define SIGM_P(x) sigm_f(x)
+#endif
+#if defined(PF_EXP_NOSTORE)
+#define PF_STORE(ptr, val) do { if (p.eps < 0.f) *(uint4*)(ptr) = (val); } while (0)
+#else
+#define PF_STORE(ptr, val) *(uint4*)(ptr) = (val)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 __device__ __forceinline__ float sigm_f(float y) { return __builtin_amdgcn_rcpf(1.f + __expf(-y)); }
@@ -74,7 +91,7 @@ struct PairProjParams {
   float eps;
 };
 
-// MODE 0: triangle multiplication (o0 = planes [B][256][N][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
+// MODE 0: triangle multiplication (o0 = planes [B][N][256][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
 // MODE 1: triangle attention      (o0 = q, o1 = k, o3 = gate: [B][N][N][128]; o2 = vT [B][N][128][NP]; f0 = tri [B][4][N][NP])
 #define PP_LDS0 (2 * 16384 + 512 + 256 * PP_SPITCH + 64 * PP_GPITCH)
 #define PP_LDS1 (2 * 16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 2048)
@@ -138,8 +155,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = tid + 512 * i;
-    voff_pl[i] = MODE == 0 ? ((unsigned)(id >> 3) * (unsigned)N * (unsigned)NP + (unsigned)(id & 7) * 8u) * 2u
-                           : ((unsigned)(id >> 3) * (unsigned)NP + (unsigned)(id & 7) * 8u) * 2u;
+    voff_pl[i] = ((unsigned)(id >> 3) * (unsigned)NP + (unsigned)(id & 7) * 8u) * 2u;   // plane row `id >> 3` of this line
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -147,9 +163,11 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     voff_cl[i] = (unsigned)(id >> 4) * ((MODE == 0 && p.swap) ? (unsigned)N : 1u) * 256u + (unsigned)(id & 15) * 16u;
   }
 
-  f32x4 zr[2][2];
-  float mk[2] = {0.f, 0.f};
-  auto issue = [&](unsigned t) __attribute__((always_inline)) {
+  // one register set: the rows of tile t+1 are requested while tile t computes (a second set / prefetch distance 2 was
+  // measured: no gain, +16 VGPRs)
+  f32x4 zrA[2][2];
+  float mkA[2] = {0.f, 0.f};
+  auto issue = [&](unsigned t, f32x4 (&zr)[2][2], float (&mk)[2]) __attribute__((always_inline)) {
     const int pt = (int)(t % (unsigned)tpl);
     const unsigned bl = t / (unsigned)tpl;
     const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
@@ -182,18 +200,18 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   auto stream_out = [&](int b, int line, int pt, int par) __attribute__((always_inline)) {
     const int pos0 = pt * PP_TILE;
     if (MODE == 0) {
-      char* const pbase = (char*)p.o0 + ((((long)b * 256) * N + line) * NP + pos0) * 2;          // wave-uniform
+      char* const pbase = (char*)p.o0 + ((((long)b * N + line) * 256) * NP + pos0) * 2;          // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(pbase + voff_pl[i]) = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
+        PF_STORE(pbase + voff_pl[i], *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16));
       }
       const long cell0 = p.swap ? ((long)b * N + pos0) * N + line : ((long)b * N + line) * N + pos0;
       char* const gbase = (char*)p.o1 + cell0 * 256;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        if (pos0 + cr < N) *(uint4*)(gbase + voff_cl[i]) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
+        if (pos0 + cr < N) PF_STORE(gbase + voff_cl[i], *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16));
       }
     } else {
       const long cell0 = ((long)b * N + line) * N + pos0;
@@ -201,20 +219,20 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
         if (pos0 + cr < N) {
-          *(uint4*)((char*)p.o0 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
-          *(uint4*)((char*)p.o1 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
-          *(uint4*)((char*)p.o3 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
+          PF_STORE((char*)p.o0 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16));
+          PF_STORE((char*)p.o1 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16));
+          PF_STORE((char*)p.o3 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16));
         }
       }
       char* const vbase = (char*)p.o2 + ((((long)b * N + line) * 128) * NP + pos0) * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(vbase + voff_pl[i]) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
+        PF_STORE(vbase + voff_pl[i], *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16));
       }
       if (tid < 64) {
         const int h = tid >> 4, v = tid & 15;
-        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4);
+        PF_STORE(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4, *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4));
       }
     }
   };
@@ -223,11 +241,9 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   // area] | barrier | [MFMA + gates(t) -> staging].  Loads and stores are both issued right before the MFMA phase and
   // nothing waits on the memory counter until the next tile's LayerNorm, so neither latency sits on the critical path
   // (the compiler waits vmcnt(0) wherever loads and stores are mixed).  A / mask / bias tiles alternate by tile parity.
-  unsigned t = blockIdx.x;
-  if (t < ntiles) issue(t);
   int pb = 0, pline = 0, ppt = 0, par = 0;
   bool have_prev = false;
-  for (; t < ntiles; t += gridDim.x) {
+  auto tile = [&](unsigned t, f32x4 (&zr)[2][2], float (&mk)[2]) __attribute__((always_inline)) {
     const int pt = (int)(t % (unsigned)tpl);
     const unsigned bl = t / (unsigned)tpl;
     const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     __syncthreads();
 
     // ---- S1: prefetch the next tile's rows, stream the previous tile out (both in flight during the MFMA phase) ----
-    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+    if (t + gridDim.x < ntiles) issue(t + gridDim.x, zr, mk);     // this tile's rows have been consumed above
     if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
     __syncthreads();
 
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
+        for (int g = 0; g < NG; ++g) acc[g] = MFMA16P(af, wf[g][ks], acc[g]);
       }
       // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
       const int cell0 = rt * 16 + l4 * 4;
@@ -305,9 +321,9 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         float a[4], bb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
-          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
-          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[4][r] + bv[4]));
+          a[r] = (acc[0][r] + bv[0]) * SIGM_P(acc[1][r] + bv[1]) * m[r];
+          bb[r] = (acc[2][r] + bv[2]) * SIGM_P(acc[3][r] + bv[3]) * m[r];
+          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(SIGM_P(acc[4][r] + bv[4]));
         }
         *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]));
         *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(bb[0], bb[1]), pack2bf_hw(bb[2], bb[3]));
@@ -317,14 +333,17 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         for (int r = 0; r < 4; ++r) {
           *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[0][r] + bv[0]);
           *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[1][r] + bv[1]);
-          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[3][r] + bv[3]));
+          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(SIGM_P(acc[3][r] + bv[3]));
           vv[r] = acc[2][r] + bv[2];
         }
         *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(vv[0], vv[1]), pack2bf_hw(vv[2], vv[3]));
       }
     }
     pb = b; pline = line; ppt = pt; par ^= 1; have_prev = true;
-  }
+  };
+  unsigned t = blockIdx.x;
+  if (t < ntiles) issue(t, zrA, mkA);
+  for (; t < ntiles; t += gridDim.x) tile(t, zrA, mkA);
   __syncthreads();
   if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
 }
@@ -357,7 +376,7 @@ static int pair_proj_launch(int mode, const PairProjParams& p, int x_is_bf16, hi
 static bool pf_dims_ok(int B, int N, int NP) {
   // 32-bit per-thread byte offsets inside one batch item's planes (256 N NP bf16) and inside a tile of transposed cells
   return B > 0 && N > 0 && NP >= N && (NP % PP_TILE) == 0 && (long)B * N * (NP / PP_TILE) < (1L << 31) && (long)B * N * N < (1L << 40) &&
-         512L * N * NP < (1L << 32) && 64L * N * 512 < (1L << 32);
+         512L * NP < (1L << 32) && 64L * N * 512 < (1L << 32);
 }
 
 extern "C" int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma,
@@ -388,7 +407,7 @@ extern "C" int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const flo
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Triangle multiplication, output stage: x planes [B][128][N][NP] (bf16, from the contraction) -> LayerNorm_out over
+// Triangle multiplication, output stage: x planes [B][N][128][NP] (bf16, from the contraction) -> LayerNorm_out over
 // the 128 channels of every cell -> linear_z -> * gate -> out [B][N][N][128] (fp32 or bf16)
 // (triangular_multiplicative_update.py:119-124).
 // ------------------------------------------------------------------------------------------------------------------
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
     const int i = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
-      xv[c2] = *(const uint4*)(p.xpl + (((long)b * 128 + 2 * pr + c2) * N + i) * NP + jt * PP_TILE + xv8 * 8);
+      xv[c2] = *(const uint4*)(p.xpl + (((long)b * N + i) * 128 + 2 * pr + c2) * NP + jt * PP_TILE + xv8 * 8);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int id = tid + 512 * k, cr = id >> 4, v = id & 15;

@@ -211,16 +211,16 @@ def _trimul_fused(z, mask, outgoing, pack, ws=None):
     if zc.dtype not in (torch.float32, BF16):
         zc = zc.float()
     maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
-    planes = _ws_get(ws, "planes", (B, 256, N, NP), BF16, dev)
+    planes = _ws_get(ws, "planes", (B, N, 256, NP), BF16, dev)      # [line][channel][pos]: line-major planes
     gate = _ws_get(ws, "gate", (B, N, N, 128), BF16, dev)
-    xpl = _ws_get(ws, "xpl", (B, 128, N, NP), BF16, dev)
+    xpl = _ws_get(ws, "xpl", (B, N, 128, NP), BF16, dev)
     st = stream()
     check(L.dfold_trimul_proj_fwd(_p(zc), c_int32(1 if zc.dtype == BF16 else 0), _p(maskf), _p(g_in), _p(b_in), _p(wcat),
                                   _p(bcat), _p(planes), _p(gate), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP),
                                   c_int32(0 if outgoing else 1), ctypes_float(1e-5), st), "dfold_trimul_proj_fwd")
-    pl = N * NP
-    gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(NP), c_rows=rows_plain(NP), ldb=NP, nbatch=B * 128, nb1=128,
-         sa=(256 * pl, pl), sb=(256 * pl, pl), sc=(128 * pl, pl), b_off=128 * pl)               # x_c = a_c b_c^T  (:113-118)
+    # x_c = a_c b_c^T  (:113-118): batch (b, c); rows i / j of channel c are 256 NP (a, b) resp. 128 NP (x) elements apart
+    gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(256 * NP), c_rows=rows_plain(128 * NP), ldb=256 * NP,
+         nbatch=B * 128, nb1=128, sa=(N * 256 * NP, NP), sb=(N * 256 * NP, NP), sc=(N * 128 * NP, NP), b_off=128 * NP)
     out = torch.empty((B, N, N, 128), dtype=zc.dtype, device=dev)
     check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(g_out), _p(b_out), _p(wz), _p(b_z), _p(out),
                                  c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),

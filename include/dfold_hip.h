@@ -202,12 +202,14 @@ int dfold_sum_leading(const float* x, float* out, int32_t I, int64_t n, int64_t 
  * ---------------------------------------------------------------------------------------------- */
 /* Triangle multiplication, stage 1 (triangular_multiplicative_update.py:92-104,122): LayerNorm_in, the five projections
  * (w_cat rows a_p|a_g|b_p|b_g|g, [640][128] bf16; bias_cat [640]), gates and mask ->
- *   planes bf16 [B][256][N][NP]: plane[ch][i][k] = a[i,k,ch] (outgoing) or a[k,i,ch] (incoming), ch < 128; b in 128..255
- *   (pad columns k >= N zero-filled); gate bf16 [B][N][N][128] = sigmoid(linear_g(LN(z))); stats [B*N*N][2] or NULL */
+ *   planes bf16 [B][N][256][NP]: plane[i][ch][k] = a[i,k,ch] (outgoing) or a[k,i,ch] (incoming), ch < 128; b in 128..255
+ *   (line-major: the 256 channel rows of one line i share a 256*NP*2-byte region, so a tile's 128-byte segments stay in
+ *   one DRAM neighbourhood; pad columns k >= N zero-filled); gate bf16 [B][N][N][128] = sigmoid(linear_g(LN(z)));
+ *   stats [B*N*N][2] or NULL */
 int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
                           const void* w_cat_bf16, const float* bias_cat, void* planes_bf16, void* gate_bf16, float* stats,
                           int32_t B, int32_t N, int32_t NP, int32_t incoming, float eps, void* stream);
-/* stage 3 (:119-124): x planes bf16 [B][128][N][NP] (x_c = a_c b_c^T from dfold_gemm_bf16) -> LayerNorm_out -> linear_z
+/* stage 3 (:119-124): x planes bf16 [B][N][128][NP] (x[i][c][j] = sum_k a_c[i,k] b_c[j,k] from dfold_gemm_bf16) -> LayerNorm_out -> linear_z
  * -> * gate -> out [B][N][N][128] fp32 | bf16 */
 int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const float* ln_gamma, const float* ln_beta,
                          const void* w_z_bf16, const float* b_z, void* out, int32_t out_is_bf16, int32_t B, int32_t N,

@@ -62,9 +62,9 @@ def _stages_mul(m, z, mask, reps):
     f32 = lambda t: t.detach().float().contiguous()
     gi, bi, go, bo, bz = (f32(m.layer_norm_in.weight), f32(m.layer_norm_in.bias), f32(m.layer_norm_out.weight),
                           f32(m.layer_norm_out.bias), f32(m.linear_z.bias))
-    planes = torch.empty((B, 256, N, NP), dtype=BF16, device=dev)
+    planes = torch.empty((B, N, 256, NP), dtype=BF16, device=dev)
     gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
-    xpl = torch.empty((B, 128, N, NP), dtype=BF16, device=dev)
+    xpl = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
     out = torch.empty_like(z)
     zb = 1 if z.dtype == BF16 else 0
     pl = N * NP
@@ -75,8 +75,8 @@ def _stages_mul(m, z, mask, reps):
                                       ctypes_float(1e-5), stream()), "proj")
 
     def s2():
-        gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(NP), c_rows=rows_plain(NP), ldb=NP, nbatch=B * 128, nb1=128,
-             sa=(256 * pl, pl), sb=(256 * pl, pl), sc=(128 * pl, pl), b_off=128 * pl)
+        gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(256 * NP), c_rows=rows_plain(128 * NP), ldb=256 * NP,
+             nbatch=B * 128, nb1=128, sa=(N * 256 * NP, NP), sb=(N * 256 * NP, NP), sc=(N * 128 * NP, NP), b_off=128 * NP)
 
     def s3():
         check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(go), _p(bo), _p(wz), _p(bz), _p(out), c_int32(zb), c_int32(B),

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Build a diagnostic variant of the library: scripts/build_variant.sh <name> [-DFLAG ...]  -> gpurun_out/libdfold_<name>.so
-# (gpurun_out/ does not travel to the GPU box: variants are written to dynamicpdb_amd/csrc/variants/, git-ignored *.so)
+# Build a diagnostic variant of the library: [SRC=pair_fused] scripts/build_variant.sh <name> [-DFLAG ...]
+#   -> dynamicpdb_amd/csrc/variants/libdfold_<name>.so (git-ignored; load it with DFOLD_LIB=...).  Only $SRC.hip (default
+#   gemm_bf16) is recompiled with the extra flags; the other objects come from the regular build.
 set -e
 name=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -10,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-
 objs=""
 for f in $R/dynamicpdb_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  if [ "$b" = "gemm_bf16" ]; then
+  if [ "$b" = "${SRC:-gemm_bf16}" ]; then
     /opt/rocm/bin/hipcc $FLAGS "$@" -I $R/include -c $f -o $out/obj_$name/$b.o
     objs="$objs $out/obj_$name/$b.o"
   else

@@ -59,7 +59,7 @@ def test_trimul_proj_stage(N, incoming):
     z, mask = z.to(dev), mask.to(dev)
     wcat, bcat = m._packed()[:2]
     NP = (N + 63) // 64 * 64
-    planes = torch.full((B, 256, N, NP), 7.0, dtype=BF16, device=dev)
+    planes = torch.full((B, N, 256, NP), 7.0, dtype=BF16, device=dev)
     gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
     stats = torch.empty((B * N * N, 2), dtype=torch.float32, device=dev)
     f32 = lambda t: t.detach().float().contiguous()
@@ -73,7 +73,7 @@ def test_trimul_proj_stage(N, incoming):
         b = m.linear_b_p(zn) * torch.sigmoid(m.linear_b_g(zn)) * mask[..., None]
         g = torch.sigmoid(m.linear_g(zn))
         ab = torch.cat([a, b], -1)                                  # [B, r, s, 256]
-        ref = ab.permute(0, 3, 2, 1) if incoming else ab.permute(0, 3, 1, 2)   # plane[ch][line][pos]
+        ref = ab.permute(0, 2, 3, 1) if incoming else ab.permute(0, 1, 3, 2)   # plane[line][ch][pos]
     assert rel_l2(planes[..., :N].float(), ref) < 8e-3, rel_l2(planes[..., :N].float(), ref)
     assert float(planes[..., N:].float().abs().max()) == 0.0 if NP > N else True
     assert rel_l2(gate.float(), g) < 6e-3
@@ -94,12 +94,12 @@ def test_trimul_out_stage(N):
     m = _rand_module(T.TriangleMultiplicationOutgoing(128, 128), 6).to(dev)
     rng = np.random.default_rng(8)
     NP = (N + 63) // 64 * 64
-    x = torch.tensor(rng.standard_normal((B, 128, N, NP), dtype=np.float32) * 3.0 + 0.5).to(dev).to(BF16)
+    x = torch.tensor(rng.standard_normal((B, N, 128, NP), dtype=np.float32) * 3.0 + 0.5).to(dev).to(BF16)   # [i][c][j]
     gate = torch.tensor(rng.uniform(size=(B, N, N, 128)).astype(np.float32)).to(dev).to(BF16)
     wz = m._packed()[2]
     f32 = lambda t: t.detach().float().contiguous()
     with torch.no_grad():
-        xc = x[..., :N].float().permute(0, 2, 3, 1)                 # [B, i, j, c]
+        xc = x[..., :N].float().permute(0, 1, 3, 2)                 # [B, i, j, c]
         ref = m.linear_z(_ln(xc, m.layer_norm_out.weight, m.layer_norm_out.bias)) * gate.float()
     for out_bf16 in (0, 1):
         out = torch.empty((B, N, N, 128), dtype=BF16 if out_bf16 else torch.float32, device=dev)
