@@ -453,8 +453,19 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 #define A3_BYTES (BM3 * BK * 2)
 #define B3_BYTES (BN3 * BK * 2)
 #define STAGE3_BYTES (A3_BYTES + B3_BYTES)
+// "halo" form of the 5x5 conv launch: one A tile of 256 + 4 consecutive residues (8-row DMA pieces: 264 rows) serves the five
+// residue taps of a (channel chunk, frame tap) group
+#define HALO_PIECES 33
+#define HALO_BYTES (HALO_PIECES * 1024)
+#define HALO_LDS (2 * HALO_BYTES + 2 * B3_BYTES)
 
-template <int ROLE, int NJ>
+// HALO (5x5 conv launches whose 256-row tiles are runs of consecutive residues of one frame row, N_res % 256 == 0): the five
+// residue taps dn of a (channel chunk, frame tap) group read the SAME 260 activation rows shifted by one row each, so the
+// A operand is staged once per group as a 264-row halo tile and the fragment reads of tap dn start dn rows further down;
+// only the weight tile is staged per K step.  LDS-DMA pieces per wave and K step: 6 instead of 9 (their issue cost inside
+// the MFMA stream is the largest loss of the K loop: scripts/exp_conv_variants.py, NODMA +45 %).  Same K order, same
+// accumulation order: results are bit-identical to the per-tap form.
+template <int ROLE, int NJ, bool HALO = false>
 __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmParams p) {
   constexpr int BNW = 64 * NJ;                 // N tile: 320 (NJ = 5) or 256 (NJ = 4)
   constexpr int BW_BYTES = BNW * BK * 2;
@@ -506,6 +517,16 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     if (m >= p.M) m = p.M - 1;
     aoff[t] = (unsigned)((row_off(p.am, m) + kofs) * 2);
   }
+  // HALO: byte offset of the tile's first halo row (tap (0,0) corner of row m0; the 264 rows follow at the row pitch)
+  const unsigned h_row0 = HALO ? (unsigned)(row_off(p.am, m0) * 2) : 0u;
+  const unsigned h_ld2 = (unsigned)(p.am.ld * 2);
+  // piece j holds LDS rows 8j + rsub; swizzle key of that row = ((8j + rsub) >> 1) & 7 = (4 (j & 1) + (rsub >> 1)) & 7
+  const unsigned h_ce = (unsigned)((cphys ^ ((rsub >> 1) & 7)) * 16), h_co = (unsigned)((cphys ^ ((4 + (rsub >> 1)) & 7)) * 16);
+  auto halo_off = [&](int j) {   // lane's source byte offset of halo piece j (rows past the 260th re-read the last one)
+    unsigned r = (unsigned)(j * 8 + rsub);
+    r = r < 259u ? r : 259u;
+    return h_row0 + r * h_ld2 + ((j & 1) ? h_co : h_ce);
+  };
 #pragma unroll
   for (int t = 0; t < NJ; ++t) {
     long n = (long)n0 + (t * 8 + w) * 8 + rsub;
@@ -545,6 +566,18 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const char* pa = A + (p.a_seg0 + (long)df_lo * p.a_seg_s1) * 2;
   const char* pb = B + (p.b_seg0 + (long)df_lo * p.b_seg_s1) * 2;
   int st_mid = 0, st_lo = 0, st_kk = 0, st_left = nsteps;
+  // HALO prefetch cursor: h_next = base of the group being prefetched (the one after the group of the step in flight),
+  // h_mid its frame tap, h_gleft = groups from it to the end (it stays on the last group when there is none left: the
+  // surplus loads go to the idle buffer), h_dn = position inside the current group, h_buf = halo buffer of the current group
+  const int h_groups = nsteps / 5;
+  const char* h_next = A + (p.a_seg0 + (long)df_lo * p.a_seg_s1) * 2;
+  int h_mid = 0, h_gleft = h_groups, h_dn = 0, h_buf = 0;
+  if (HALO && h_groups > 1) {       // the prefetched group starts as group 1
+    h_gleft = h_groups - 1;
+    const bool wrap = ndf == 1;
+    h_mid = wrap ? 0 : 1;
+    h_next += wrap ? p.a_seg_s0 * 2 : p.a_seg_s1 * 2;
+  }
   auto stage = [&](int buf) {
     const char* sa = pa;
     const char* sb = pb;
@@ -567,12 +600,39 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     pb += (BK2 + (eb1 & k0) + (eb2 & k1) + (eb3 & k2)) & ka;
     char* la = lds3 + buf * STAGE_BYTES;
     char* lb = la + A3_BYTES;
+    if (HALO) {
+      // one piece of the NEXT group's halo per wave and step (5 steps x 8 waves = 40 slots for 33 pieces: the surplus
+      // slots re-load piece 32, so every wave issues the same instruction count and the loop stays branch-free)
+      int j = h_dn * 8 + w;
+      j = j < HALO_PIECES - 1 ? j : HALO_PIECES - 1;
+      la = lds3 + (h_buf ^ 1) * HALO_BYTES;
+      lb = lds3 + 2 * HALO_BYTES + buf * BW_BYTES;
+      __builtin_amdgcn_global_load_lds((const void*)(h_next + halo_off(j)), (lds_ptr_t)(la + j * 1024), 16, 0, 0);
+      // advance (dn, group) -- scalar, branch-free: at the end of a group the prefetched group becomes current
+      const int dn1 = h_dn + 1;
+      const unsigned gw = (unsigned)(4 - dn1) >> 31;                 // dn1 == 5
+      h_dn = dn1 & (int)(gw - 1u);
+      h_buf ^= (int)gw;
+      const unsigned more = ((unsigned)(1 - h_gleft) >> 31) & gw;    // a group after the prefetched one exists
+      h_gleft -= (int)more;
+      int mid = h_mid + (int)more;
+      const unsigned mw = ((unsigned)(ndf - 1 - mid) >> 31) & more;  // frame tap wraps: next channel chunk
+      mid &= (int)(mw - 1u);
+      h_mid = mid;
+      h_next += ((p.a_seg_s1 * 2) & -(long)more) + (ea3 & -(long)mw);
+    }
+#if !defined(DFOLD_EXP_NODMA)
+    if (!HALO) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+      for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_global_load_lds((const void*)(sa + aoff[t]), (lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < NJ; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+#else
+    asm volatile("" ::"s"(sa), "s"(sb), "v"(aoff[0]), "v"(boff[0]), "r"(la), "r"(lb));
+#endif
   };
 
   f32x16 acc[2][NJ];
@@ -587,15 +647,40 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   const int fsw = (lane >> 1) & 7;
   const int fhalf = lane >> 5;
   const int fa = (wm * 64 + frow) * 128;
-  const int fb = A3_BYTES + (wn * (32 * NJ) + frow) * 128;
+  const int fb = (HALO ? 0 : A3_BYTES) + (wn * (32 * NJ) + frow) * 128;
 
   bf16x8 af[2][2], bfr[2][NJ];
+  // HALO: the A fragments of residue tap dn sit dn rows further down the halo tile; their swizzle key follows the row
+  int c_dn = 0, c_hb = 0;          // residue tap / halo buffer of the tile being read (advanced once per K step)
+  const char* c_ha = lds3;         // halo tile + dn rows
+  int c_sw = fsw;
+  auto halo_step = [&]() {          // called when a wave moves on to the next tile
+    const int d1 = c_dn + 1;
+    const unsigned gw = (unsigned)(4 - d1) >> 31;
+    c_dn = d1 & (int)(gw - 1u);
+    c_hb ^= (int)gw;
+    c_ha = lds3 + c_hb * HALO_BYTES + c_dn * 128;
+    c_sw = ((frow + c_dn) >> 1) & 7;
+  };
   auto ldfrag = [&](int set, const char* base, int k4) {
     const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
+#if !defined(DFOLD_EXP_NOLDS)
+    if (HALO) {
+      const int cha = ((k4 * 2 + fhalf) ^ c_sw) << 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) af[set][i] = *(const bf16x8*)(base + fa + i * 32 * 128 + ch);
+      for (int i = 0; i < 2; ++i) af[set][i] = *(const bf16x8*)(c_ha + fa + i * 32 * 128 + cha);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[set][i] = *(const bf16x8*)(base + fa + i * 32 * 128 + ch);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bfr[set][j] = *(const bf16x8*)(base + fb + j * 32 * 128 + ch);
+#else
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(af[set][i]) : "r"(base), "r"(ch));     // fragments stay whatever they were
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bfr[set][j]));
+#endif
   };
   auto mma = [&](int set) {
 #pragma unroll
@@ -605,7 +690,26 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
   };
 
-  stage(0);
+  if (HALO) {
+    // prologue: the whole halo tile of group 0 (33 pieces over 8 waves, surplus slots re-load piece 32), then weight tile 0
+    const char* h0 = A + (p.a_seg0 + (long)df_lo * p.a_seg_s1) * 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int j = w + 8 * i;
+      j = j < HALO_PIECES - 1 ? j : HALO_PIECES - 1;
+      __builtin_amdgcn_global_load_lds((const void*)(h0 + halo_off(j)), (lds_ptr_t)(lds3 + j * 1024), 16, 0, 0);
+    }
+    {
+      const int keep_dn = h_dn, keep_buf = h_buf, keep_mid = h_mid, keep_left = h_gleft;
+      const char* keep_next = h_next;
+      stage(0);                    // issues weight tile 0 (and one harmless piece of group 1); undo the halo cursor advance
+      h_dn = keep_dn; h_buf = keep_buf; h_mid = keep_mid; h_gleft = keep_left; h_next = keep_next;
+    }
+  } else {
+    stage(0);
+  }
+  const int bbase = HALO ? 2 * HALO_BYTES : 0, bstride = HALO ? BW_BYTES : STAGE_BYTES;
+  constexpr int BLK2 = HALO ? 1 : 4;   // LDS-DMA pieces beyond the NJ weight pieces per wave and step
   // Static wave priority (s_setprio is scalar and ignores EXEC: the guard is wave-uniform).  1 (default): the late group
   // B outranks group A for the whole K loop (+2.3 % on the conv launches, scripts/exp_conv_prio.py); 2: the reverse
   // (-0.3 %); 0: none.  Per-cluster flips inside the loop need scalar branches there, which break the pinned
@@ -617,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       DFOLD_EXP_WAIT;
       DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
-      const char* base = lds3 + (s & 1) * STAGE_BYTES;
+      const char* base = lds3 + bbase + (s & 1) * bstride;
       ldfrag(0, base, 0);
       ldfrag(1, base, 1);
       stage((s + 1) & 1);
@@ -627,7 +731,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       ldfrag(1, base, 3);
       mma(0);
       mma(1);
-      // issue order: [2(2+NJ) reads] [NJ x (2 MFMA, 1 DMA)] [2+NJ reads] [4 x (2 MFMA, 1 DMA)] [rest of mma(1)] [2+NJ reads] [4NJ MFMA]
+      if (HALO) halo_step();
+      // issue order: [2(2+NJ) reads] [NJ x (2 MFMA, 1 DMA)] [2+NJ reads] [BLK2 x (2 MFMA, 1 DMA)] [rest of mma(1)] [2+NJ reads] [4NJ MFMA]
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
 #pragma unroll
       for (int g = 0; g < NJ; ++g) {
@@ -636,11 +741,11 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < BLK2; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-      if (NJ > 4) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
     }
@@ -652,18 +757,19 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ldfrag(0, lds3, 0);
-    ldfrag(1, lds3, 1);
+    ldfrag(0, lds3 + bbase, 0);
+    ldfrag(1, lds3 + bbase, 1);
     stage(1);
     mma(0);
-    ldfrag(0, lds3, 2);
+    ldfrag(0, lds3 + bbase, 2);
     mma(1);
-    ldfrag(1, lds3, 3);
+    ldfrag(1, lds3 + bbase, 3);
+    if (HALO) halo_step();
     for (int s = 1; s < nsteps; ++s) {
       DFOLD_EXP_WAIT;
       DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
-      const char* base = lds3 + (s & 1) * STAGE_BYTES;
+      const char* base = lds3 + bbase + (s & 1) * bstride;
       stage((s + 1) & 1);
       mma(0);                 // previous tile, K16 blocks 2 and 3
       mma(1);
@@ -673,12 +779,13 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       ldfrag(0, base, 2);
       mma(1);
       ldfrag(1, base, 3);
+      if (HALO) halo_step();
 #pragma unroll
-      for (int g = 0; g < 4 + NJ; ++g) {
+      for (int g = 0; g < BLK2 + NJ; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
-      if (NJ > 4) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
@@ -810,11 +917,23 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
       hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
       hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE3_BYTES);
+      hipFuncSetAttribute((const void*)dfold_mfma_gemm320_kernel<1, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
       attr3_done = true;
     }
     dim3 grid3((unsigned)tiles320, S > 1 ? S : d->nbatch, 1);
     const size_t lds = 2 * STAGE3_BYTES;
-    if (role == 1)
+    // halo form (DFOLD_CONV_HALO=0 turns it off): every 256-row tile is a run of consecutive residues of one frame row, one
+    // K step per (chunk, tap) segment, the residue tap moves the operand by exactly one row
+    static int halo_mode = -1;
+    if (halo_mode < 0) {
+      const char* e = getenv("DFOLD_CONV_HALO");
+      halo_mode = e ? atoi(e) : 1;
+    }
+    const bool halo = halo_mode && role == 1 && d->a_rows.mode == 1 && (d->a_rows.n % BM3) == 0 && (d->M % BM3) == 0 && d->seglen == BK &&
+                      d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && (d->nseg % (25 * S)) == 0 && p.conv_F == 0;
+    if (halo)
+      DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5, true>), grid3, dim3(512), (size_t)HALO_LDS, (hipStream_t)stream, p);
+    else if (role == 1)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);
     else if (role == 2)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<2, 5>), dim3((unsigned)(tiles320 * 25), 1, 1), dim3(512), lds, (hipStream_t)stream, p);

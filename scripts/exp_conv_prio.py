@@ -12,11 +12,12 @@ T = lambda L: 5 * L - 6
 flop = 2 * C * (C // 2) * T(F) * T(N) * Wn
 res = {}
 for CI, CO in ((1280, 640), (640, 1280)):
-    x = g.alloc(CI); g.interior(x).copy_(torch.randn(Wn, F, N, CI, device=dev).to(torch.bfloat16))
-    wf = (torch.randn(CO, 25, CI, device=dev) / np.sqrt(25 * CI)).to(torch.bfloat16)
+    x = g.alloc(CI); g.interior(x).copy_(torch.randn(Wn, F, N, CI, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(torch.bfloat16))
+    wf = (torch.randn(CO, 25, CI, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) / np.sqrt(25 * CI)).to(torch.bfloat16)
     out = g.alloc(CO)
     t = timeit(lambda: ops.conv5x5_fwd(g, x, wf, torch.zeros(CO, device=dev), out, relu=True), iters=10, warm=3)
     res[f"{CI}->{CO}"] = round(flop / t / 1e12, 1)
+    res[f"sum{CI}"] = int(out.view(torch.int16).to(torch.int64).sum())       # bit-level checksum of the output grid
 print(json.dumps(res))
 '''
 for prio in sys.argv[1:] or ["0", "1", "2"]:
