@@ -94,7 +94,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel": "dfold_mfma_gemm320_kernel<1, 5> (5x5 conv implicit GEMM, forward + dgrad launches)", "launches": len(ms),
+            "kernel": "dfold_mfma_gemm320_kernel<1, 5, true> (5x5 conv implicit GEMM, halo form, forward + dgrad launches)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
 
 
