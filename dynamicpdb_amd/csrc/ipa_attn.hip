@@ -31,6 +31,10 @@ struct IpaDims {
 };
 
 // q_pts [B,F,N,H,PQ,3], k_pts [B,F,N,H,PQ,3], v_pts [B,F,N,H,PV,3] fp32; S/P [B,F,H,N,N]; bias [B,H,N,N]; mask [B,F,N]
+// One workgroup per (window, frame, head): the key point table is staged once (16-byte vectors) for all N rows; a wave
+// owns every 4th row, its q point vector arrives through the scalar cache, and the logits / pair bias of the NEXT row are
+// requested before the current row is reduced (the row-serial load -> max -> exp -> sum -> store chain was latency bound).
+template <int MT>
 __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, const float* __restrict__ bias,
                                                               const float* __restrict__ q_pts,
                                                               const float* __restrict__ k_pts,
@@ -41,29 +45,45 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
   float* kp = sm;  // [N][KPS]
   const int N = d.N, H = d.H;
   const int bf = blockIdx.z, h = blockIdx.y, b = bf / d.F;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
-  for (int e = threadIdx.x; e < N * KP; e += 256) {
-    const int j = e / KP, c = e - j * KP;
-    kp[j * KPS + c] = kbase[(long)j * H * KP + c];
+  for (int e = threadIdx.x; e < N * (KP / 4); e += 256) {
+    const int j = e / (KP / 4), q = e - j * (KP / 4);
+    *(float4*)(kp + j * KPS + 4 * q) = *(const float4*)(kbase + (long)j * H * KP + 4 * q);
   }
   __syncthreads();
   const float hwh = hw[h];
-  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
-  for (int r = w; r < ROWS_PER_BLOCK; r += 4) {
-    const int i = i0 + r;
-    if (i >= N) break;
+  float mj[MT];                                   // key mask of this lane's columns (row independent)
+#pragma unroll
+  for (int t = 0; t < MT; ++t) mj[t] = (lane + 64 * t < N) ? mask[(long)bf * N + lane + 64 * t] : 0.f;
+  const long baseS = ((long)bf * H + h) * N * N, baseB = ((long)b * H + h) * N * N;
+  float sc[MT], bc[MT];                           // logits / pair bias of the row in flight
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int j = lane + 64 * t;
+    const bool ok = j < N && w < N;
+    sc[t] = ok ? S[baseS + (long)w * N + j] : 0.f;
+    bc[t] = ok ? bias[baseB + (long)w * N + j] : 0.f;
+  }
+  for (int i = w; i < N; i += 4) {
     float qv[KP];
-    const float* qb = q_pts + (((long)bf * N + i) * H + h) * KP;
+    const float* qb = q_pts + (((long)bf * N + i) * H + h) * KP;      // wave-uniform row: scalar loads
 #pragma unroll
     for (int c = 0; c < KP; ++c) qv[c] = qb[c];
     const float mi = mask[(long)bf * N + i];
-    const long rowS = (((long)bf * H + h) * N + i) * N;
-    const long rowB = (((long)b * H + h) * N + i) * N;
-    float lg[MAXT];
+    const long rowS = baseS + (long)i * N;
+    float sn[MT], bn[MT];                         // next row of this wave
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int j = lane + 64 * t;
+      const bool ok = j < N && i + 4 < N;
+      sn[t] = ok ? S[rowS + 4L * N + j] : 0.f;
+      bn[t] = ok ? bias[baseB + (long)(i + 4) * N + j] : 0.f;
+    }
+    float lg[MT];
     float mx = -3.0e38f;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       lg[t] = -3.0e38f;
       if (j < N) {
@@ -74,8 +94,8 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
           const float d0 = qv[4 * c4] - kv.x, d1 = qv[4 * c4 + 1] - kv.y, d2_ = qv[4 * c4 + 2] - kv.z, d3 = qv[4 * c4 + 3] - kv.w;
           d2 += d0 * d0 + d1 * d1 + d2_ * d2_ + d3 * d3;
         }
-        float v = S[rowS + j] + bias_scale * bias[rowB + j] - 0.5f * hwh * d2;
-        v += inf * (mi * mask[(long)bf * N + j] - 1.f);
+        float v = sc[t] + bias_scale * bc[t] - 0.5f * hwh * d2;
+        v += inf * (mi * mj[t] - 1.f);
         lg[t] = v;
         mx = fmaxf(mx, v);
       }
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       if (j < N) {
         lg[t] = expf(lg[t] - mx);
@@ -93,13 +113,15 @@ __global__ __launch_bounds__(256) void ipa_softmax_fwd_kernel(const float* S, co
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       if (j < N) {
         const float p = lg[t] * inv;
         P[rowS + j] = p;
         Pb[rowS + j] = f2bf(p);
       }
+      sc[t] = sn[t];
+      bc[t] = bn[t];
     }
   }
 }
@@ -110,10 +132,17 @@ extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const fl
   if (!S || !bias || !q_pts || !k_pts || !mask || !hw || !P || !P_bf16) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  dim3 grid(1, H, B * F);
   const size_t lds = (size_t)N * KPS * sizeof(float);
-  DFOLD_LAUNCH(ipa_softmax_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, S, bias, q_pts, k_pts, mask, hw,
-                     P, (bf16_t*)P_bf16, d, bias_scale, inf);
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 256)
+    DFOLD_LAUNCH(ipa_softmax_fwd_kernel<4>, grid, dim3(256), lds, st, S, bias, q_pts, k_pts, mask, hw, P, (bf16_t*)P_bf16, d, bias_scale, inf);
+  else if (N <= 512)
+    DFOLD_LAUNCH(ipa_softmax_fwd_kernel<8>, grid, dim3(256), lds, st, S, bias, q_pts, k_pts, mask, hw, P, (bf16_t*)P_bf16, d, bias_scale, inf);
+  else {
+    hipFuncSetAttribute((const void*)ipa_softmax_fwd_kernel<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_fwd_kernel<MAXT>, grid, dim3(256), lds, st, S, bias, q_pts, k_pts, mask, hw, P, (bf16_t*)P_bf16, d, bias_scale, inf);
+  }
   return dfold_check_launch();
 }
 
@@ -230,6 +259,10 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
 //   dq_pts[i,c] = -hw sum_j dS_ij (q_ic - k_jc);   dhw[h] += sum_j dS_ij * (-0.5 |q_i - k_j|^2)
 // writes dS (fp32, and bf16 for the MFMA products dQ/dK).
 // ---------------------------------------------------------------------------------------------
+// One workgroup per (window, frame, head): the key / value point tables are staged ONCE (16-byte vectors) and serve all N
+// attention rows (8 waves x N/8 rows); the row's own q / do_pt vectors are wave-uniform and come through the scalar cache.
+// 64 KB of LDS -> two workgroups (16 waves) per CU.  (With 64-row workgroups re-staging the tables for every row block,
+// 81 KB of LDS and one workgroup per CU, the row-serial load -> reduce -> store chain ran at 1.4 TB/s.)
 template <int MT>
 __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __restrict__ P, const float* dP,
                                                               const float* __restrict__ q_pts,
@@ -239,44 +272,42 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
                                                               float* dS, bf16_t* __restrict__ dSb,
                                                               float* __restrict__ dq_pts, float* __restrict__ dhw,
                                                               IpaDims d) {
-  // 8 waves share the per-(window,frame,head) key/value point tables AND the block's 64 query rows' point vectors in
-  // LDS (no per-row uniform global loads, ~100 VGPRs -> 4 waves per SIMD hide the row-serial latency chain).
+  // The rows of dS sum to zero (sum_j P_ij (g_ij - sum_j' P_ij' g_ij') = 0), so the q-dependent parts of the point
+  // gradients drop out of the per-pair work:
+  //   dq_pts[i,c] = -hw sum_j dS_ij (q_ic - k_jc)                      = +hw A_ic,           A_ic = sum_j dS_ij k_jc
+  //   dhw[h]     += sum_j dS_ij (-0.5 |q_i - k_j|^2) = -0.5 (sum_j dS_ij |k_j|^2 - 2 q_i . A_i)
+  // i.e. 25 FMAs per (i, j) pair instead of 24 differences + 48 FMAs, and 7 instead of 12 LDS vector reads; the q_i . A_i
+  // product is once per row.  (fp32: the dropped terms are eps * |q|^2 * sum_j |dS_ij|, five orders below the kept ones.)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = d.N, H = d.H;
-  float* kp = sm;                          // [N][KPS]
+  float* kp = sm;                          // [N][KPS]  (column 24 of a row: |k_j|^2)
   float* vp = kp + N * KPS;                // [N][VPS]
-  float* qr = vp + N * VPS;                // [ROWS][KP]
-  float* dr = qr + ROWS_PER_BLOCK * KP;    // [ROWS][VP]
   const int bf = blockIdx.z, h = blockIdx.y;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * ROWS_PER_BLOCK;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
   const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
-  for (int e = threadIdx.x; e < N * KP; e += 512) {
-    const int j = e / KP, c = e - j * KP;
-    kp[j * KPS + c] = kbase[(long)j * H * KP + c];
+  for (int e = threadIdx.x; e < N * (KP / 4); e += 512) {
+    const int j = e / (KP / 4), q = e - j * (KP / 4);
+    *(float4*)(kp + j * KPS + 4 * q) = *(const float4*)(kbase + (long)j * H * KP + 4 * q);
   }
-  for (int e = threadIdx.x; e < N * VP; e += 512) {
-    const int j = e / VP, c = e - j * VP;
-    vp[j * VPS + c] = vbase[(long)j * H * VP + c];
+  for (int e = threadIdx.x; e < N * (VP / 4); e += 512) {
+    const int j = e / (VP / 4), q = e - j * (VP / 4);
+    *(float4*)(vp + j * VPS + 4 * q) = *(const float4*)(vbase + (long)j * H * VP + 4 * q);
   }
-  for (int e = threadIdx.x; e < ROWS_PER_BLOCK * KP; e += 512) {
-    const int r = e / KP, c = e - r * KP;
-    qr[e] = (i0 + r < N) ? q_pts[(((long)bf * N + i0 + r) * H + h) * KP + c] : 0.f;
-  }
-  for (int e = threadIdx.x; e < ROWS_PER_BLOCK * VP; e += 512) {
-    const int r = e / VP, c = e - r * VP;
-    dr[e] = (i0 + r < N) ? do_pt[(((long)bf * N + i0 + r) * H + h) * VP + c] : 0.f;
+  __syncthreads();
+  for (int j = threadIdx.x; j < N; j += 512) {      // |k_j|^2 into the pad column of the key table
+    float kn = 0.f;
+#pragma unroll
+    for (int c = 0; c < KP; ++c) kn += kp[j * KPS + c] * kp[j * KPS + c];
+    kp[j * KPS + KP] = kn;
   }
   __syncthreads();
   const float hwh = hw[h];
   float dhw_acc = 0.f;
-  for (int r = w; r < ROWS_PER_BLOCK; r += 8) {
-    const int i = i0 + r;
-    if (i >= N) break;
+  for (int i = w; i < N; i += 8) {
     const long pix = ((long)bf * N + i) * H + h;
-    const float* qv = qr + r * KP;
-    const float* dov = dr + r * VP;
+    const float* qv = q_pts + pix * KP;        // wave-uniform rows: scalar loads
+    const float* dov = do_pt + pix * VP;
     const long row = (((long)bf * H + h) * N + i) * N;
     float pv[MT], gv[MT];
     float dot = 0.f;
@@ -290,8 +321,7 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
 #pragma unroll
         for (int c4 = 0; c4 < VP / 4; ++c4) {
           const float4 vv = *(const float4*)(vp + j * VPS + 4 * c4);
-          const float4 dd = *(const float4*)(dov + 4 * c4);
-          g += dd.x * vv.x + dd.y * vv.y + dd.z * vv.z + dd.w * vv.w;
+          g += dov[4 * c4] * vv.x + dov[4 * c4 + 1] * vv.y + dov[4 * c4 + 2] * vv.z + dov[4 * c4 + 3] * vv.w;
         }
         pv[t] = P[row + j];
         gv[t] = g;
@@ -299,9 +329,10 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
       }
     }
     dot = wave_sum(dot);
-    float dq[KP];
+    float ak[KP];            // A_ic partial sums of this lane
+    float akn = 0.f;         // sum_j dS_ij |k_j|^2
 #pragma unroll
-    for (int c = 0; c < KP; ++c) dq[c] = 0.f;
+    for (int c = 0; c < KP; ++c) ak[c] = 0.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
@@ -309,28 +340,27 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
         const float ds = pv[t] * (gv[t] - dot);
         dS[row + j] = ds;
         dSb[row + j] = f2bf(ds);
-        float d2 = 0.f;
 #pragma unroll
         for (int c4 = 0; c4 < KP / 4; ++c4) {
           const float4 kv = *(const float4*)(kp + j * KPS + 4 * c4);
-          const float4 qq = *(const float4*)(qv + 4 * c4);
-          const float df[4] = {qq.x - kv.x, qq.y - kv.y, qq.z - kv.z, qq.w - kv.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            dq[4 * c4 + u] += ds * df[u];
-            d2 += df[u] * df[u];
-          }
+          ak[4 * c4] += ds * kv.x;
+          ak[4 * c4 + 1] += ds * kv.y;
+          ak[4 * c4 + 2] += ds * kv.z;
+          ak[4 * c4 + 3] += ds * kv.w;
         }
-        dhw_acc += -0.5f * ds * d2;
+        akn += ds * kp[j * KPS + KP];
       }
     }
+    float qa = 0.f;          // q_i . A_i, accumulated per component after the wave reduction
 #pragma unroll
     for (int c = 0; c < KP; ++c) {
-      const float sres = wave_sum(dq[c]);
-      if (lane == 0) dq_pts[pix * KP + c] = -hwh * sres;
+      const float sres = wave_sum(ak[c]);
+      qa += qv[c] * sres;
+      if (lane == 0) dq_pts[pix * KP + c] = hwh * sres;
     }
+    akn = wave_sum(akn);
+    if (lane == 0) dhw_acc += -0.5f * (akn - 2.f * qa);
   }
-  dhw_acc = wave_sum(dhw_acc);
   if (lane == 0 && dhw_acc != 0.f) atomicAdd(dhw + h, dhw_acc);
 }
 
@@ -340,9 +370,9 @@ extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const floa
   if (!P || !dP || !q_pts || !k_pts || !v_pts || !do_pt || !hw || !dS || !dS_bf16 || !dq_pts || !dhw) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
-  const size_t lds = ((size_t)N * (KPS + VPS) + (size_t)ROWS_PER_BLOCK * (KP + VP)) * sizeof(float);
+  const size_t lds = (size_t)N * (KPS + VPS) * sizeof(float);
   if (lds > 160 * 1024) return DFOLD_EINVAL;
-  dim3 grid((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, H, B * F);
+  dim3 grid(1, H, B * F);
   hipStream_t st = (hipStream_t)stream;
   bf16_t* dsb = (bf16_t*)dS_bf16;
   if (N <= 256) {
@@ -381,6 +411,7 @@ __global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < VP; ++c) av[c] = 0.f;
   const long base = ((long)bf * H + h) * N * N + (ok ? j : 0);
+#pragma unroll 4
   for (int i = 0; i < N; ++i) {
     const float ds = dS[base + (long)i * N];
     const float p = P[base + (long)i * N];
