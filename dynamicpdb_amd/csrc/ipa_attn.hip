@@ -304,11 +304,28 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
   __syncthreads();
   const float hwh = hw[h];
   float dhw_acc = 0.f;
+  const long base = ((long)bf * H + h) * N * N;
+  float pc[MT], dc[MT];                       // P / dP of the row in flight (the next row is requested one row ahead)
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int j = lane + 64 * t;
+    const bool ok = j < N && w < N;
+    pc[t] = ok ? P[base + (long)w * N + j] : 0.f;
+    dc[t] = ok ? dP[base + (long)w * N + j] : 0.f;
+  }
   for (int i = w; i < N; i += 8) {
     const long pix = ((long)bf * N + i) * H + h;
     const float* qv = q_pts + pix * KP;        // wave-uniform rows: scalar loads
     const float* dov = do_pt + pix * VP;
-    const long row = (((long)bf * H + h) * N + i) * N;
+    const long row = base + (long)i * N;
+    float pn[MT], dn[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int j = lane + 64 * t;
+      const bool ok = j < N && i + 8 < N;
+      pn[t] = ok ? P[row + 8L * N + j] : 0.f;
+      dn[t] = ok ? dP[row + 8L * N + j] : 0.f;
+    }
     float pv[MT], gv[MT];
     float dot = 0.f;
 #pragma unroll
@@ -317,16 +334,18 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
       pv[t] = 0.f;
       gv[t] = 0.f;
       if (j < N) {
-        float g = dP[row + j];
+        float g = dc[t];
 #pragma unroll
         for (int c4 = 0; c4 < VP / 4; ++c4) {
           const float4 vv = *(const float4*)(vp + j * VPS + 4 * c4);
           g += dov[4 * c4] * vv.x + dov[4 * c4 + 1] * vv.y + dov[4 * c4 + 2] * vv.z + dov[4 * c4 + 3] * vv.w;
         }
-        pv[t] = P[row + j];
+        pv[t] = pc[t];
         gv[t] = g;
         dot += pv[t] * g;
       }
+      pc[t] = pn[t];
+      dc[t] = dn[t];
     }
     dot = wave_sum(dot);
     float ak[KP];            // A_ic partial sums of this lane

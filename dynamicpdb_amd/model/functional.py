@@ -211,20 +211,32 @@ class ConvTowerFn(Function):
     fp32) and added to the parameters' .grad layer by layer during the backward of the application that runs last."""
 
     @staticmethod
-    def forward(ctx, x, tower, last_frame_only, track, *params):
-        """last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
+    def forward(ctx, tower, last_frame_only, track, n_parts, *args):
+        """args = the n_parts channel slices of the input (bf16 [W,F,N,C_k], concatenated along the channel axis in the
+        padded grid itself -- the producers' outputs are copied once, straight into the grid interior; no torch.cat and no
+        second copy), then the conv parameters (only there so that autograd sees the dependency).
+        last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
         dependency cone of that frame (ops.ConvTower.cone); the other output frames are returned as zeros and the
         incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller).
         track: a backward will follow (grad mode on and something requires grad, decided by the caller -- inside
         Function.forward grad mode is always off).  Only then are the activations kept and the application counted in
         `tower.pending`; a no_grad pass (sampling, self-conditioning, evaluation) leaves no trace in the tower."""
-        Wn, F, N, C = x.shape
-        g = ops.Grid(Wn, F, N, x.device)
+        xs = args[:n_parts]
+        Wn, F, N, _ = xs[0].shape
+        widths = [x.shape[-1] for x in xs]
+        C = sum(widths)
+        g = ops.Grid(Wn, F, N, xs[0].device)
         tower.refresh()
-        h0 = g.alloc(C)
-        g.interior(h0).copy_(x)
-        h4, saved = tower.forward(g, h0, save=track, last_frame_only=last_frame_only)
-        ctx.tower, ctx.g, ctx.saved, ctx.last, ctx.track = tower, g, saved, last_frame_only, track
+        slot = tower.slot(track)
+        h0 = tower.grid(g, C, slot, "in")
+        inner, off = g.interior(h0), 0
+        for x, c in zip(xs, widths):
+            inner[..., off:off + c].copy_(x)
+            off += c
+        h4, saved = tower.forward(g, h0, save=track, last_frame_only=last_frame_only, slot=slot)
+        ctx.tower, ctx.g, ctx.saved, ctx.last, ctx.track, ctx.widths = tower, g, saved, last_frame_only, track, widths
+        ctx.n_params = len(args) - n_parts
+        ctx.slot, ctx.gen = slot, tower.slot_gen.get(slot)
         if track:
             tower.pending += 1
         return g.interior(h4).contiguous()
@@ -234,6 +246,7 @@ class ConvTowerFn(Function):
         tower, g = ctx.tower, ctx.g
         if not ctx.track or ctx.saved is None:
             raise RuntimeError("ConvTowerFn.backward: forward ran without activation tracking (no_grad) or twice")
+        tower.check_slot(ctx.slot, ctx.gen)
         gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]), zero=ctx.last)
         if ctx.last:
             g.interior(gt)[:, -1:].copy_(gy[:, -1:])
@@ -246,7 +259,13 @@ class ConvTowerFn(Function):
         g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=last)
         ctx.saved = None
         tower.pending = max(0, tower.pending - 1)
-        return (g.interior(g0).contiguous(), None, None, None, *([None] * (2 * len(tower.weights))))
+        # one compact copy per input slice (g0 is scratch of the tower, overwritten by the next application's backward;
+        # the slices are what the producers' backward nodes read -- no full-width copy in between)
+        inner, off, grads = g.interior(g0), 0, []
+        for k, c in enumerate(ctx.widths):
+            grads.append(inner[..., off:off + c].contiguous() if ctx.needs_input_grad[4 + k] else None)
+            off += c
+        return (None, None, None, None, *grads, *([None] * ctx.n_params))
 
 
 # ------------------------------------------------------------------------------------------------

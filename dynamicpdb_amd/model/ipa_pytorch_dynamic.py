@@ -70,11 +70,13 @@ class ConvNet(nn.Module):
         return self._tower
 
     def run(self, x, last_frame_only=False):
-        """x bf16 [W,F,N,C] -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode)."""
+        """x bf16 [W,F,N,C], or a list of channel slices [W,F,N,C_k] that are concatenated inside the padded conv grid
+        (no torch.cat) -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode)."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
         ws, bs = self._params()
         inter = [p for pair in zip(ws, bs) for p in pair]
-        track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in inter))
-        return F_.ConvTowerFn.apply(x, self.tower(), bool(last_frame_only), bool(track), *inter)
+        track = torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(p.requires_grad for p in inter))
+        return F_.ConvTowerFn.apply(self.tower(), bool(last_frame_only), bool(track), len(xs), *xs, *inter)
 
     def forward(self, x):
         _require_cuda(x)
@@ -279,8 +281,8 @@ class DFOLDIpaScore(nn.Module):
             ipa = self.trunk[f'ipa_{b}']
             feats = ipa.features(node_embed, edge, curr_rigids, node_mask)
             ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
-            node_feat = torch.cat([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], dim=-1)
-            node_feat = conv.run(node_feat, last_frame_only)
+            # cat([rigids, ipa, force, vel, angle], -1) (:846) happens inside the padded conv grid
+            node_feat = conv.run([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], last_frame_only)
             if last_frame_only:
                 # only frame F-1 of the tower output is defined (and consumed): per-position heads run on it alone
                 upd_last = self.trunk[f'bb_update_{b}'](node_feat[:, -1:])

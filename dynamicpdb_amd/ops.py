@@ -363,6 +363,8 @@ class ConvTower:
         self.dwg = [torch.zeros((max(w.shape[:2]), 25, min(w.shape[:2])), dtype=torch.float32, device=dev) for w in weights]
         self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
         self.ws = Workspace(dev)
+        self.pool = Workspace(dev)   # persistent activation grids of the applications of a step (grid())
+        self.slot_gen = {}
         self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
         self.fresh = [True] * len(weights)   # accumulator j holds nothing yet this step: its first wgrad overwrites
         self.on_final = None      # callback(param) after a layer's gradient has been handed to .grad (dp.GradReducer)
@@ -429,18 +431,47 @@ class ConvTower:
         nf1, nf2 = min(F, r + 3), min(F, r + 1)
         return (F - nf1, nf1), (F - nf2, nf2)
 
-    def forward(self, g, h0, save=True, last_frame_only=False):
+    POOL_SLOTS = 8       # tracked applications per step served from the pool (the reference model has 4)
+
+    def grid(self, g, C, slot, name, last_frame_only=False):
+        """A zero-bordered activation grid [Wn,Fp,Wp,C].  slot None: a fresh zero-filled tensor.  Otherwise a persistent
+        buffer of the pool, keyed by (slot, name, mode, shape): the conv launches only ever write interior cells (all of
+        them in the all-frames mode, the same dependency cone every time in the last-frame mode), so the border -- and,
+        in the last-frame mode, everything below the cone -- stays the zero it was allocated as, and the 191 MB fill per
+        grid and application disappears from the step.  A slot is one application of the tower inside a step (its
+        activations live until that application's backward); passes without a backward share the slot "nograd"."""
+        if slot is None:
+            return g.alloc(C)
+        return self.pool.get("%s/%s/%d" % (slot, name, 1 if last_frame_only else 0), (g.Wn, g.Fp, g.Wp, C))
+
+    def slot(self, track):
+        """pool slot of the application about to run (None: beyond the pool, fresh tensors).  Taking a slot starts a new
+        generation of it: a backward that still holds activations of an earlier generation (a graph kept across
+        reset_step) must not run on the overwritten buffers -- check_slot() raises."""
+        if not track:
+            return "nograd"
+        if self.pending >= self.POOL_SLOTS:
+            return None
+        self.slot_gen[self.pending] = self.slot_gen.get(self.pending, 0) + 1
+        return self.pending
+
+    def check_slot(self, slot, gen):
+        if slot is not None and slot != "nograd" and self.slot_gen.get(slot) != gen:
+            raise RuntimeError("ConvTower: the activations of this application were overwritten by a later forward pass "
+                               "(backward of a graph from before reset_step / a previous step)")
+
+    def forward(self, g, h0, save=True, last_frame_only=False, slot=None):
         """h0: padded grid [Wn,Fp,Wp,C] bf16.  Returns (h4, saved).  last_frame_only: compute the dependency cone of
-        the last output frame only (h4 is then valid on frame F-1 alone, zero elsewhere)."""
+        the last output frame only (h4 is then valid on frame F-1 alone, zero elsewhere).  slot: see grid()."""
         C = h0.shape[-1]
         saved = [h0] if save else None
         h = h0
         for i in range(4):
             (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else ((0, g.F), (0, g.F))
-            u = g.alloc(C // 2)
+            u = self.grid(g, C // 2, slot, "u%d" % i, last_frame_only)
             ws = self.ws if last_frame_only else None
             conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True, f_lo=l1, nf=n1, ws=ws)
-            hn, v = g.alloc(C), g.alloc(C)
+            hn, v = self.grid(g, C, slot, "h%d" % i, last_frame_only), self.grid(g, C, slot, "v%d" % i, last_frame_only)
             conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v,
                         f_lo=l2, nf=n2, ws=ws)
             if save:
