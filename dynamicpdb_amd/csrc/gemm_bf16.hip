@@ -448,6 +448,12 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 // K step moves 72 KiB HBM/L2 -> LDS for 10.5 MFLOP (vs 48 KiB for 4.2): the LDS port stops being the limiter.
 // Two LDS stages (2 x 72 KiB): wait tile s, barrier, launch the LDS-DMA of tile s+1, run 40 MFMAs per wave on tile s.
 // ------------------------------------------------------------------------------------------------
+#ifndef DFOLD_SCHED_A
+#define DFOLD_SCHED_A 0     // placement of the LDS-DMA pieces inside a K step (scripts/exp_conv_variants.py)
+#endif
+#ifndef DFOLD_SCHED_B
+#define DFOLD_SCHED_B 0
+#endif
 #define BM3 256
 #define BN3 320
 #define A3_BYTES (BM3 * BK * 2)
@@ -732,6 +738,50 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       mma(0);
       mma(1);
       if (HALO) halo_step();
+#if DFOLD_SCHED_A == 1
+      // [reads] [all DMA pieces] [2NJ MFMA] [reads] [2NJ MFMA] [reads] [4NJ MFMA]: pieces issued under the read latency
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#elif DFOLD_SCHED_A == 2
+      // pieces inside the last 4NJ MFMAs (no fragment reads around them)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+#pragma unroll
+      for (int g = 0; g < NJ + BLK2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 2 * (NJ + BLK2), 0);
+#elif DFOLD_SCHED_A == 3
+      // pieces spread over the whole step: one per 4 MFMAs while there are any
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+#pragma unroll
+      for (int g = 0; g < NJ + BLK2 - 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 4 * (NJ + BLK2 - 4), 0);
+#else
       // issue order: [2(2+NJ) reads] [NJ x (2 MFMA, 1 DMA)] [2+NJ reads] [BLK2 x (2 MFMA, 1 DMA)] [rest of mma(1)] [2+NJ reads] [4NJ MFMA]
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
 #pragma unroll
@@ -748,6 +798,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#endif
     }
   } else {
     // ---- group B (the second wave of every SIMD) runs HALF A K STEP BEHIND: it enters each step with the fragments of
@@ -780,12 +831,25 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       mma(1);
       ldfrag(1, base, 3);
       if (HALO) halo_step();
+#if DFOLD_SCHED_B == 1
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2, 0);      // all pieces first, then the 4NJ MFMAs of the previous tile
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#elif DFOLD_SCHED_B == 3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                                     // one piece per 4 MFMAs, the rest later
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2 - 4, 0);
+#else
 #pragma unroll
       for (int g = 0; g < BLK2 + NJ; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
       if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);

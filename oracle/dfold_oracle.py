@@ -715,6 +715,63 @@ def evoformer_block_core(P, m, z, msa_mask, pair_mask):
     return m, z
 
 
+def _unit_norm(x):
+    """utils.normalize (omegafold/utils/torch_utils.py:53-83): LayerNorm over the last axis, no gain / shift, eps 1e-5"""
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), None, None, 1e-5)
+
+
+def omegafold_node2edge(P, node_repr, mask):
+    """Node2Edge.forward (src/toolbox/OmegaFold/omegafold/modules.py:336-351): node_repr [S,N,in], mask [S,N] ->
+    [N,N,out].  l, r = halves of the masked input projection; out_ijf = sum_s sum_de l_sid W_def r_sje + bias, divided
+    by (number of rows where both residues are present + 1e-3)."""
+    x = _unit_norm(node_repr)
+    act = (x @ P["input_proj.weight"].t() + P["input_proj.bias"]) * mask[..., None]
+    d = P["out_weights"].shape[0]
+    left, right = act[..., :d], act[..., d:]
+    pair = torch.einsum("sid,sje->ijde", left, right)
+    out = torch.einsum("ijde,def->ijf", pair, P["out_weights"]) + P["out_bias"]
+    both = torch.einsum("si,sj->ij", mask, mask)
+    return out / (both + 1e-3)[..., None]
+
+
+def omegafold_geometric_attention(P, edge_repr, mask):
+    """GeometricAttention.forward (modules.py:716-723) on one [N,N,d] edge tensor with residue mask [N]; no sub-batching.
+    Axis r = 0 works on the edge tensor, r = 1 on its transpose (`_get_sharded_stacked`, :550-565).
+      attended (:616-652): per row s of X_r a gated multi-head attention over the row (`Attention`, :400-481) whose logits
+        get the per-pair bias X_r[q,k] . linear_b_weights[:,r,h] + linear_b_bias[r,h]; the axis-1 result is transposed back
+        and added.  NOTE: the vendored code builds `b` from the mask bias (:627) and then ASSIGNS the pair bias into every
+        row block of it (:645-647), so the mask bias is overwritten and no key is masked in this term; restated as is.
+      gated (:654-689): GLU projections of X_r (even / odd quarter blocks of act_w for the first / second factor,
+        :691-715), masked by the residue of their FIRST index, contracted over the second index, normalised, projected
+        and gated by sigmoid of the last act_w block; summed over the axes WITHOUT transposing the axis-1 term back."""
+    e = _unit_norm(edge_repr)
+    d = e.shape[-1]
+    H, c = P["attention.qg_weights"].shape[2], P["attention.kv_weights"].shape[-1] // 2
+    out = torch.zeros_like(e)
+    for r in range(2):
+        X = e if r == 0 else e.transpose(0, 1)
+        # ---- attention along the rows of X
+        qg = torch.einsum("sqa,ahc->shqc", X, P["attention.qg_weights"][:, r]) + P["attention.qg_bias"][r]
+        kv = torch.einsum("ska,ahc->shkc", X, P["attention.kv_weights"][:, r]) + P["attention.kv_bias"][r]
+        q, g = qg[..., :c], qg[..., c:]
+        k, v = kv[..., :c], kv[..., c:]
+        pair_bias = torch.einsum("qka,ah->hqk", X, P["linear_b_weights"][:, r]) + P["linear_b_bias"][r]
+        logits = torch.einsum("shqc,shkc->shqk", q, k) * c ** -0.5 + pair_bias[None]
+        att = torch.einsum("shqk,shkc->shqc", torch.softmax(logits, -1), v) * torch.sigmoid(g)
+        o = torch.einsum("shqc,hco->sqo", att, P["attention.o_weights"][r]) + P["attention.o_bias"][:, r]
+        out = out + (o if r == 0 else o.transpose(0, 1))
+        # ---- gated product
+        w, b = P["act_w"][:, r], P["act_b"][r]
+        blk = lambda t, i: t[..., i * d:(i + 1) * d]
+        glu = lambda i_p, i_g: (X @ blk(w, i_p) + blk(b, i_p)) * torch.sigmoid(X @ blk(w, i_g) + blk(b, i_g))
+        first = glu(0, 2) * mask[:, None, None]                             # [i, k, d]
+        second = glu(1, 3) * mask[:, None, None]                            # [j, k, d]
+        ab = _unit_norm(torch.einsum("ikd,jkd->ijd", first, second))
+        gate = torch.sigmoid(X @ blk(w, 4) + blk(b, 4))
+        out = out + (ab @ P["out_proj_w"][r] + P["out_proj_b"][r]) * gate
+    return out
+
+
 def make_atom14(aatype, pos37, mask37):
     """make_atom14_masks + make_atom14_positions (data_transforms.py:572-643, :653-752), restated with the reference's
     permutation-matrix formulation (einsum with the 14x14 renaming matrices)."""

@@ -81,7 +81,31 @@ def bench_epilogue(Wn=8, F=32, N=256):
                               tflops_issued=2 * g.M * CO * 25 * CI / t0 / 1e12)), flush=True)
 
 
+def bench_conv_vs_library(Wn=8, F=32, N=256, C=1280):
+    """The production conv launches (BASELINE config 3 grid) next to the vendor library (hipBLASLt through torch.matmul)
+    on the GEMM of the SAME size with its operand already materialised (65536 x 32000 im2col matrix the implicit kernel
+    never builds): the practical MFMA ceiling of this box for this much work."""
+    g = ops.Grid(Wn, F, N, dev)
+    for CI, CO in ((C, C // 2), (C // 2, C)):
+        x = g.alloc(CI)
+        g.interior(x).copy_(torch.randn(Wn, F, N, CI, device=dev).to(torch.bfloat16))
+        wf = (torch.randn(CO, 25, CI, device=dev) / np.sqrt(25 * CI)).to(torch.bfloat16)
+        bias = torch.zeros(CO, device=dev)
+        out = g.alloc(CO)
+        t = timeit(lambda: ops.conv5x5_fwd(g, x, wf, bias, out, relu=True), iters=5, warm=2)
+        fl = 2.0 * g.M * CO * 25 * CI
+        a = torch.randn(g.M, 25 * CI, device=dev).to(torch.bfloat16)
+        b = wf.view(CO, 25 * CI)
+        t2 = timeit(lambda: torch.matmul(a, b.t()), iters=5, warm=2)
+        print(json.dumps(dict(op="conv launch vs library GEMM of the same size", CI=CI, CO=CO, M=g.M, K=25 * CI, ms=t * 1e3,
+                              tflops_issued=fl / t / 1e12, library_ms=t2 * 1e3, library_tflops=fl / t2 / 1e12)), flush=True)
+        del a
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "library":
+        bench_conv_vs_library()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epilogue":
         bench_epilogue()
         sys.exit(0)

@@ -276,6 +276,51 @@ def golden_pair_stack(S=6, N=24, seed=17):
     print("pair stack golden written", len(fix), "arrays")
 
 
+def golden_geoformer(S=5, N=24, seed=23):
+    """OmegaFold pair-track operators as the reference vendors them (src/toolbox/OmegaFold/omegafold/modules.py):
+    Node2Edge (:320-351) and GeometricAttention (:568-723) with OmegaFold's sizes (node 256, edge 128, 32-channel outer
+    product, 4 heads x 32, 2 axes), forward only (the reference runs them under no_grad).  The package imports Biopython
+    for PDB output at import time; it is not installed here and not needed by these modules, so it is stubbed."""
+    import argparse
+    import types
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = _Stub(self.__name__ + "." + k)
+            setattr(self, k, m)
+            return m
+    for name in ("Bio", "Bio.Data", "Bio.Data.SCOPData", "Bio.PDB"):
+        sys.modules.setdefault(name, _Stub(name))
+    sys.modules["Bio.Data.SCOPData"].protein_letters_3to1 = {}
+    sys.path.insert(0, os.path.join(os.environ.get("DFOLD_REFERENCE", "/root/reference"), "src", "toolbox", "OmegaFold"))
+    from omegafold import modules
+    rng = np.random.default_rng(seed)
+    fix = {}
+    node = torch.tensor(rng.standard_normal((S, N, 256), dtype=np.float32))
+    edge = torch.tensor((rng.standard_normal((N, N, 128)) * 1.5 + 0.2).astype(np.float32))
+    res_mask = np.ones(N, np.float32)
+    res_mask[[3, N - 2]] = 0
+    seq_mask = np.tile(res_mask, (S, 1))
+    seq_mask[2, 7] = 0
+    fix.update(node=np_(node), edge=np_(edge), res_mask=res_mask, seq_mask=seq_mask)
+    n2e = modules.Node2Edge(in_dim=256, proj_dim=32, out_dim=128)
+    ga = modules.GeometricAttention(d_edge=128, c=32, n_head=4, n_axis=2)
+    for mod, pre, std in ((n2e, "n2e.", 0.08), (ga, "ga.", 0.09)):
+        with torch.no_grad():
+            for k, p_ in mod.named_parameters():
+                p_.copy_(torch.tensor((rng.standard_normal(tuple(p_.shape)) * std).astype(np.float32)))
+                fix[pre + "P." + k] = np_(p_)
+    with torch.no_grad():
+        fix["n2e.out"] = np_(n2e(node, torch.tensor(seq_mask)))
+        fix["ga.out"] = np_(ga(edge, torch.tensor(res_mask), argparse.Namespace(subbatch_size=None)))
+        sub7 = np_(ga(edge, torch.tensor(res_mask), argparse.Namespace(subbatch_size=7)))   # sub-batching changes nothing
+    np.savez_compressed(os.path.join(HERE, f"geoformer_S{S}_N{N}.npz"), **fix)
+    print("geoformer golden written", len(fix), "arrays; sub-batched vs whole:",
+          float(np.abs(fix["ga.out"] - sub7).max()))
+
+
 def golden_diffuser(exp, F=3, N=16):
     d = exp.diffuser
     so3, r3 = d._so3_diffuser, d._r3_diffuser
@@ -383,9 +428,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pair_stack":
         golden_pair_stack()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "geoformer":
+        golden_geoformer()
+        sys.exit(0)
     exp = golden_network()
     golden_diffuser(exp)
     golden_triangle()
     golden_dataset_geom()
     golden_pair_transition()
     golden_pair_stack()
+    golden_geoformer()

@@ -260,3 +260,16 @@ def test_pair_stack_vs_reference_golden():
     assert rel_l2(m.grad, g["core.gm"]) < 1e-4 and rel_l2(z.grad, g["core.gz"]) < 1e-4
     gn = np.array([float(P[k].grad.norm()) for k in names])
     assert np.allclose(gn, g["core.gnorm"], rtol=2e-4, atol=1e-7)
+
+
+def test_geoformer_ops_vs_reference_golden():
+    """oracle Node2Edge / GeometricAttention vs OmegaFold's own modules (tests/golden/geoformer_S5_N24.npz, minted by
+    tests/golden/make_golden.py::golden_geoformer from src/toolbox/OmegaFold/omegafold/modules.py:320-351,568-723)."""
+    g = load_golden("geoformer_S5_N24.npz")
+    P = {k[6:]: torch.tensor(v) for k, v in g.items() if k.startswith("n2e.P.")}
+    y = O.omegafold_node2edge(P, torch.tensor(g["node"]), torch.tensor(g["seq_mask"]))
+    assert rel_l2(y, g["n2e.out"]) < 1e-5
+    P = {k[5:]: torch.tensor(v) for k, v in g.items() if k.startswith("ga.P.")}
+    y = O.omegafold_geometric_attention(P, torch.tensor(g["edge"]), torch.tensor(g["res_mask"]))
+    assert rel_l2(y, g["ga.out"]) < 1e-5
+    assert float((y - torch.tensor(g["ga.out"])).abs().max()) < 1e-4
