@@ -172,7 +172,10 @@ def test_gradient_reducer_path_on_one_gpu():
         for forced in (False, True):
             model, diffuser = _build(F, 3, dev)
             batch = _batch(diffuser, B, F, N, dev, seed=70)
-            tr = experiment.Trainer(model, lr=1e-3, last_frame_only=True, force_reduce=forced, bucket_bytes=8 << 20)
+            # lr = 0: the parameters never move, so every step of both runs sees the same weights and the hook-driven steps can
+            # be compared tightly (with a real step Adam turns rounding-level noise in near-dead gradients into +-lr moves and
+            # two separately trained models drift apart by several per cent within three steps)
+            tr = experiment.Trainer(model, lr=0.0, last_frame_only=True, force_reduce=forced, bucket_bytes=8 << 20)
             launched_before_finish = None
             if forced:
                 fin = tr.reducer.finish
@@ -183,9 +186,11 @@ def test_gradient_reducer_path_on_one_gpu():
                         launched_before_finish = list(tr.reducer._launched)
                     fin()
                 tr.reducer.finish = spy
-            losses = [float(tr.update_fn(batch)[0]) for _ in range(3)]
+            losses = [float(tr.update_fn(batch)[0])]
+            first = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            losses += [float(tr.update_fn(batch)[0]) for _ in range(2)]
             res[forced] = (losses, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
-                           {n: p.detach().clone() for n, p in model.named_parameters()})
+                           first)
             if forced:
                 red = tr.reducer
                 assert red.flat is not None and len(red.buckets) >= 8
@@ -204,12 +209,16 @@ def test_gradient_reducer_path_on_one_gpu():
         for a, b in zip(res[False][0], res[True][0]):
             assert abs(a - b) < 2e-3 * abs(a), (res[False][0], res[True][0])
         assert set(res[False][1]) == set(res[True][1])
-        # two separately trained models (3 steps, fp32 atomics in the weight-gradient reductions): tensors whose gradient is
-        # three orders of magnitude below the largest (the first IPA block: 1e-5 against 1e+0) are compared on that floor
-        gmax = max(float(g.norm()) for g in res[False][1].values())
+        # step 1 (same parameters, same activations: only the order of the fp32 atomics of the weight-gradient reductions
+        # differs between two runs): the reduced flat-buffer gradients equal the plain ones tightly
+        gmax = max(float(g.norm()) for g in res[False][2].values())
+        for n in res[False][2]:
+            a, b = res[True][2][n].double(), res[False][2][n].double()
+            assert float((a - b).norm()) < 1e-3 * max(float(b.norm()), 1e-3 * gmax), n
+        # step 3 (buckets launched from the hooks during backward): same gradients again
         for n in res[False][1]:
             a, b = res[True][1][n].double(), res[False][1][n].double()
-            assert float((a - b).norm()) < 2e-2 * max(float(b.norm()), 1e-3 * gmax), n
+            assert float((a - b).norm()) < 1e-3 * max(float(b.norm()), 1e-3 * gmax), n
     finally:
         dist.destroy_process_group()
 
