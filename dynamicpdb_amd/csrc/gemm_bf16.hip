@@ -454,6 +454,9 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 #ifndef DFOLD_SCHED_B
 #define DFOLD_SCHED_B 0
 #endif
+#ifndef DFOLD_MMA_ORDER
+#define DFOLD_MMA_ORDER 0   // order of the 2 x NJ MFMAs of a K16 block
+#endif
 #define BM3 256
 #define BN3 320
 #define A3_BYTES (BM3 * BK * 2)
@@ -689,11 +692,29 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
 #endif
   };
   auto mma = [&](int set) {
+#if DFOLD_MMA_ORDER == 1
+    // A-stationary: one A fragment against the NJ weight fragments, then the other (operand-bus toggling experiment)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+#elif DFOLD_MMA_ORDER == 2
+    // serpentine: every MFMA shares one operand with its predecessor
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = (j & 1) ? 1 - ii : ii;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+      }
+#else
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+#endif
   };
 
   if (HALO) {
