@@ -95,7 +95,11 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": "dfold_mfma_gemm320_kernel<1, 5, true> (5x5 conv implicit GEMM, halo form, forward + dgrad launches)", "launches": len(ms),
-            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops}
+            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops,
+            "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "
+                    "binary on all-zero operands runs 1.85 PFLOP/s = 0.74 of the peak (scripts/exp_conv_dvfs.py), hipBLASLt "
+                    "on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s (scripts/bench_conv.py library); "
+                    "DESIGN.md section 5"}
 
 
 def triangle_roofline(dev, reps=10):

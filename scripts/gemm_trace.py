@@ -1,0 +1,68 @@
+"""Per-shape time of every contraction launched by one update_fn (HIP events around ops.gemm; diagnostic).
+    python scripts/gemm_trace.py [--mode all_frames|last_frame]"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="all_frames")
+    a = ap.parse_args()
+    import bench
+    from dynamicpdb_amd import experiment, ops, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    dev = torch.device("cuda:0")
+    conf = synthetic.default_conf(32, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    model.load_state_dict(synthetic.seeded_state_dict(0), strict=True)
+    model.to(dev)
+    trainer = experiment.Trainer(model, lr=1e-4, last_frame_only=(a.mode == "last_frame"))
+    batch = bench.make_batch(synthetic, diffuser, 8, 32, 256, 0, dev)
+    for _ in range(2):
+        trainer.update_fn(batch)
+    torch.cuda.synchronize()
+    ev = []
+    orig = ops.gemm
+
+    def timed(A, B, C, M, N, K, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(A, B, C, M, N, K, **kw)
+        e1.record()
+        nseg = kw.get("nseg", 1)
+        key = (M, N, K * nseg, kw.get("nbatch", 1), str(C.dtype).replace("torch.", ""), "conv" if kw.get("seg_div_mid", 0) == 5 else
+               ("wgrad" if kw.get("nb1", 1) == 5 and kw.get("nbatch", 1) == 25 else ""), kw.get("flags", 0))
+        ev.append((key, e0, e1))
+        return r
+    ops.gemm = timed
+    import dynamicpdb_amd.model.functional as F_
+    import dynamicpdb_amd.model.triangle as T_
+    for mod in (F_, T_):
+        if getattr(mod, "gemm", None) is orig:
+            mod.gemm = timed
+    trainer.update_fn(batch)
+    torch.cuda.synchronize()
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for key, e0, e1 in ev:
+        agg[key][0] += e0.elapsed_time(e1)
+        agg[key][1] += 1
+    tot = sum(v[0] for v in agg.values())
+    print(f"contractions in one step: {tot:.2f} ms over {len(ev)} launches")
+    print("    ms  calls   us/call  TFLOP/s   M      N      K     batch dtype kind flags")
+    for key, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+        M, N, K, nb, dt, kind, fl = key
+        tf = 2.0 * M * N * K * nb * n / (t * 1e-3) / 1e12
+        print(f"{t:7.2f} {n:5d} {t / n * 1e3:9.1f} {tf:8.1f}  {M:6d} {N:6d} {K:6d} {nb:5d} {dt:9s} {kind:5s} {fl}")
+
+
+if __name__ == "__main__":
+    main()
