@@ -329,3 +329,21 @@ def test_checkpoint_format_warm_start_and_true_resume(tmp_path):
         assert not checkpoint.load_pretrained_model(m3, str(tmp_path / "missing.pth"))
     finally:
         experiment.loss_fn = experiment_loss
+
+
+def test_geoformer_dropins_keep_the_reference_parameter_layout():
+    """Node2Edge / GeometricAttention expose exactly the parameter names and shapes of OmegaFold's modules (the names in
+    the reference-minted golden file are the reference's own named_parameters()), load such a state_dict strictly, and
+    refuse CPU tensors (no fallback)."""
+    from dynamicpdb_amd.model.geoformer import GeometricAttention, Node2Edge
+    g = np.load(os.path.join(ROOT, "tests", "golden", "geoformer_S5_N24.npz"))
+    for mod, pre in ((Node2Edge(in_dim=256, proj_dim=32, out_dim=128), "n2e.P."), (GeometricAttention(128, 32, 4, 2), "ga.P.")):
+        want = {k[len(pre):]: tuple(g[k].shape) for k in g.files if k.startswith(pre)}
+        have = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        assert have == want, (sorted(set(have) ^ set(want)))
+        mod.load_state_dict({k: torch.tensor(g[pre + k]) for k in want}, strict=True)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod(torch.zeros(8, 8, 128), torch.ones(8), None)
+    with pytest.raises(ValueError):
+        GeometricAttention(64, 32, 4, 2)

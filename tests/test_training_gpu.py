@@ -105,6 +105,16 @@ def test_no_grad_pass_does_not_disturb_next_training_step():
     for n, p in model.named_parameters():
         if "conv_0" in n:
             assert rel_l2(p.grad, ref[n]) < 1e-3, n
+    # the activation grids of a tower application live in a persistent pool: a graph kept across a later step must not be
+    # differentiated on the overwritten buffers -- it raises instead of returning wrong gradients
+    stale = model(batch, last_frame_only=True)["rigid_update"].float().sum()
+    tr.update_fn(batch, step_optimizer=False)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        stale.backward()
+    tr.update_fn(batch, step_optimizer=False)
+    for n, p in model.named_parameters():
+        if "conv_0" in n:
+            assert rel_l2(p.grad, ref[n]) < 1e-3, n
 
 
 def test_inference_fn_vs_reference_golden():
