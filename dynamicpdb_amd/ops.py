@@ -364,6 +364,7 @@ class ConvTower:
         self.db = [torch.zeros_like(b, dtype=torch.float32) for b in biases]
         self.ws = Workspace(dev)
         self.pool = Workspace(dev)   # persistent activation grids of the applications of a step (grid())
+        self.pool_bytes = 0
         self.slot_gen = {}
         self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
         self.fresh = [True] * len(weights)   # accumulator j holds nothing yet this step: its first wgrad overwrites
@@ -432,6 +433,7 @@ class ConvTower:
         return (F - nf1, nf1), (F - nf2, nf2)
 
     POOL_SLOTS = 8       # tracked applications per step served from the pool (the reference model has 4)
+    POOL_CAP_BYTES = int(float(os.environ.get("DFOLD_POOL_GB", "64")) * (1 << 30))   # of 288 GB; cfg3 uses 8.4 GB per mode
 
     def grid(self, g, C, slot, name, last_frame_only=False):
         """A zero-bordered activation grid [Wn,Fp,Wp,C].  slot None: a fresh zero-filled tensor.  Otherwise a persistent
@@ -442,7 +444,18 @@ class ConvTower:
         activations live until that application's backward); passes without a backward share the slot "nograd"."""
         if slot is None:
             return g.alloc(C)
-        return self.pool.get("%s/%s/%d" % (slot, name, 1 if last_frame_only else 0), (g.Wn, g.Fp, g.Wp, C))
+        shape = (g.Wn, g.Fp, g.Wp, C)
+        key = "%s/%s/%d" % (slot, name, 1 if last_frame_only else 0)
+        if (key, shape, BF16) not in self.pool.bufs:
+            # a caller that keeps changing shapes (sampling proteins of many lengths) must not grow the pool without bound:
+            # past the cap the pool is dropped (tensors already handed out stay alive through their references; nothing of
+            # a pending application is in the dict's sole custody because `saved` holds them)
+            need = 2 * g.Wn * g.Fp * g.Wp * C
+            if self.pool_bytes + need > self.POOL_CAP_BYTES:
+                self.pool.bufs.clear()
+                self.pool_bytes = 0
+            self.pool_bytes += need
+        return self.pool.get(key, shape)
 
     def slot(self, track):
         """pool slot of the application about to run (None: beyond the pool, fresh tensors).  Taking a slot starts a new

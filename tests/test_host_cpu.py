@@ -347,3 +347,31 @@ def test_geoformer_dropins_keep_the_reference_parameter_layout():
             mod(torch.zeros(8, 8, 128), torch.ones(8), None)
     with pytest.raises(ValueError):
         GeometricAttention(64, 32, 4, 2)
+
+
+def test_conv_tower_grid_pool_is_bounded():
+    """the persistent activation grids of ops.ConvTower are keyed by (slot, name, mode, shape); past the byte cap the pool
+    is dropped instead of growing with every new shape, and tensors already handed out stay valid"""
+    from dynamicpdb_amd import ops
+
+    class G:
+        Wn, Fp, Wp = 1, 6, 6
+
+        @staticmethod
+        def alloc(C):
+            return torch.zeros(1, 6, 6, C, dtype=torch.bfloat16)
+    t = ops.ConvTower.__new__(ops.ConvTower)
+    t.pool, t.pool_bytes = ops.Workspace(torch.device("cpu")), 0
+    cap, ops.ConvTower.POOL_CAP_BYTES = ops.ConvTower.POOL_CAP_BYTES, 10_000
+    try:
+        a = t.grid(G, 32, 0, "u0")                      # 2 * 36 * 32 = 2304 bytes
+        t.grid(G, 32, 0, "h0")
+        assert t.grid(G, 32, 0, "u0").data_ptr() == a.data_ptr() and t.pool_bytes == 4608
+        assert t.grid(G, 32, 0, "u0", last_frame_only=True).data_ptr() != a.data_ptr()      # the step modes never share
+        t.grid(G, 32, None, "u0")                       # slot None: a fresh tensor, not pooled
+        assert t.pool_bytes == 6912
+        t.grid(G, 64, 1, "v0")                          # 6912 + 4608 > cap: the pool is dropped first
+        assert t.pool_bytes == 4608 and len(t.pool.bufs) == 1
+        assert float(a.float().abs().sum()) == 0.0
+    finally:
+        ops.ConvTower.POOL_CAP_BYTES = cap
