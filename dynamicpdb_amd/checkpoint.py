@@ -31,8 +31,25 @@ def write_checkpoint(ckpt_path, model, conf, optimizer, epoch, step, logger=None
     os.replace(tmp, ckpt_path)
 
 
-def read_checkpoint(ckpt_path):
-    return torch.load(ckpt_path, map_location='cpu', weights_only=False)
+def read_checkpoint(ckpt_path, allow_pickle=None):
+    """Loads with torch's restricted unpickler first (tensors, containers, numbers -- everything this module writes when
+    `conf` is a plain dict / None).  A reference checkpoint carries an OmegaConf object under 'conf'
+    (src/data/utils.py:353-362), which needs the unrestricted pickle loader: that executes code from the file, so it is
+    only used when allowed -- `allow_pickle=True`, or the environment variable DFOLD_TRUSTED_CHECKPOINTS=1 (default: on,
+    matching the reference's own torch.load; set it to 0 to refuse such files)."""
+    import pickle
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)       # "pickle protocol 4" note of the restricted unpickler
+            return torch.load(ckpt_path, map_location='cpu', weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError) as e:
+        if allow_pickle is None:
+            allow_pickle = os.environ.get("DFOLD_TRUSTED_CHECKPOINTS", "1") != "0"
+        if not allow_pickle:
+            raise RuntimeError(f"{ckpt_path} needs the unrestricted pickle loader (it holds non-tensor objects, e.g. an "
+                               "OmegaConf 'conf'); pass allow_pickle=True for files you trust") from e
+        return torch.load(ckpt_path, map_location='cpu', weights_only=False)
 
 
 def load_pretrained_model(model, ckpt_path, logger=None):
@@ -64,7 +81,7 @@ def load_pretrained_model(model, ckpt_path, logger=None):
 def save(trainer, ckpt_path, conf=None, epoch=0, step=0, rng=None, logger=None):
     """checkpoint of a dynamicpdb_amd.experiment.Trainer in the reference's format (state dicts moved to the host)"""
     cpu = lambda o: (o.detach().cpu() if torch.is_tensor(o) else {k: cpu(v) for k, v in o.items()} if isinstance(o, dict)
-                     else [cpu(v) for v in o] if isinstance(o, (list, tuple)) else copy.deepcopy(o))
+                     else type(o)(cpu(v) for v in o) if isinstance(o, (list, tuple)) else copy.deepcopy(o))
     write_checkpoint(ckpt_path, cpu(trainer.model.state_dict()), conf, cpu(trainer.opt.state_dict()), epoch, step,
                      logger=logger, extra=None if rng is None else {'rng': rng.state()})
 

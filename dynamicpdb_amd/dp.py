@@ -12,9 +12,61 @@ remaining layers of its last backward application are still computing (89 % of t
 The first step is a discovery step (plain backward, then one blocking reduction): it observes which parameters receive
 a gradient at all (the reference's 91,540 dead ones never do -- no find_unused_parameters graph walk afterwards), how
 many accumulation events each sees per step (one for an autograd leaf however often it is used; whatever a custom node
-such as the conv tower reports) and in what order they complete; rank 0's observation is broadcast so that every rank cuts identical buckets."""
+such as the conv tower reports) and in what order they complete; rank 0's observation is broadcast so that every rank
+cuts identical buckets.
+
+A step whose graph differs from the discovered one (a parameter used more often, or one that had no gradient in the
+discovery step) is still reduced exactly -- `finish()` agrees on it across ranks with one small flag collective, reduces
+the affected buckets again / the stray gradients separately -- and the next step re-discovers.
+
+`broadcast_parameters` is DDP's start-up broadcast (train_DFOLD_dynamics.py:615: rank 0's 737.7 MB of parameters, and the
+optimizer state on a resume) -- the reference seeds every rank differently (:419), so without it N ranks would train N
+different models."""
 import torch
 import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+def broadcast_parameters(tensors, src=0, group=None):
+    """In-place broadcast of rank `src`'s values into every rank's tensors (parameters, buffers, optimizer state), a few
+    large collectives: the tensors are packed into flat fp32/any-dtype staging chunks of <= 256 MB (xGMI rings are
+    per-link bound -- few, large transfers), broadcast, and copied back.  Returns the number of bytes broadcast."""
+    if not _dist_on() or dist.get_world_size(group) == 1:
+        return 0
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    by_kind = {}
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            continue
+        by_kind.setdefault((t.dtype, t.device), []).append(t)
+    total = 0
+    cap = 256 << 20
+    for (dtype, dev), ts in by_kind.items():
+        chunk, size = [], 0
+        def flush():
+            nonlocal chunk, size
+            if not chunk:
+                return
+            flat = torch.cat([t.detach().reshape(-1) for t in chunk])
+            dist.broadcast(flat, src=gsrc, group=group)
+            off = 0
+            with torch.no_grad():
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+            chunk, size = [], 0
+        for t in ts:
+            nb = t.numel() * t.element_size()
+            if chunk and size + nb > cap:
+                flush()
+            chunk.append(t)
+            size += nb
+            total += nb
+        flush()
+    return total
 
 
 class GradReducer:
@@ -22,22 +74,30 @@ class GradReducer:
         """params: the trainable parameters in a fixed order (identical on all ranks).  force: run the collectives even
         in a single-rank world (test / single-GPU coverage of the multi-GPU code path)."""
         self.params = list(params)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if _dist_on() else 1
         self.active = self.world > 1 or force
-        if self.active and not (dist.is_available() and dist.is_initialized()):
+        if self.active and not _dist_on():
             raise RuntimeError("GradReducer(force=True) needs an initialised process group")
         self.bucket_bytes = bucket_bytes
         self.flat = None
         self.buckets = []            # [(start, end)] element ranges of self.flat
         self._bucket_of = {}         # id(param) -> bucket index
         self._expected = {}          # id(param) -> accumulations per step
+        self._views = {}             # id(param) -> its view into self.flat
         self._fired, self._order = {}, {}
         self._remaining, self._works, self._launched = [], [], []
+        self._redo, self._stray = set(), set()
         self._hooks = []
         self._towers = []
+        self.rediscoveries = 0
+        self._pending_rebuild = False
         backend = dist.get_backend(group) if self.active else None
-        self._avg = backend == "nccl"     # RCCL averages in the collective; gloo sums and we scale once afterwards
+        self._avg = backend == "nccl"     # RCCL averages in the collective; gloo sums and each bucket is scaled once
+        self._stage_host = None           # gloo without device-tensor support: buckets go through host memory (tests)
+        self.timing = False               # record how long the stream waits for the collectives in finish()
+        self._ev, self.wait_ms = None, []
 
     # ---------------------------------------------------------------- wiring
     def attach(self, model=None):
@@ -67,17 +127,34 @@ class GradReducer:
     # ---------------------------------------------------------------- per-step protocol
     def begin_step(self):
         """call before forward: zero the gradients (flat buffer once built) and re-arm the buckets."""
+        if self._ev is not None:             # last step's wait time (events of the previous step have long completed)
+            a, b = self._ev
+            b.synchronize()
+            self.wait_ms.append(a.elapsed_time(b))
+            self._ev = None
         if not self.active:
             for p in self.params:
                 p.grad = None
             return
         self._bind_towers()
+        self._redo, self._stray = set(), set()
+        if self._pending_rebuild:            # last step's graph differed from the discovered one: discover again
+            self._pending_rebuild = False
+            self.rebuild()
         if self.flat is None:
             for p in self.params:
                 p.grad = None
             self._fired, self._order = {}, {}
             return
         self.flat.zero_()
+        # every bucketed gradient must still BE its view of the flat buffer: optimizer.zero_grad(set_to_none=True) or a
+        # caller's `p.grad = None` would make autograd allocate a fresh tensor and the bucket would reduce zeros
+        for p in self.params:
+            v = self._views.get(id(p))
+            if v is None:
+                p.grad = None
+            elif p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
         self._remaining = [sum(self._expected[id(p)] for p in ps) for ps in self._bucket_params]
         self._works = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
@@ -97,25 +174,57 @@ class GradReducer:
             return
         b = self._bucket_of.get(k)
         if b is None:
-            raise RuntimeError("a parameter without a gradient in the discovery step received one now; rebuild the reducer")
+            # no gradient in the discovery step, one now: its (separate) .grad is reduced on its own in finish(), and the
+            # next step discovers again
+            self._stray.add(self._index[k])
+            return
         if self._launched[b]:
-            raise RuntimeError("a gradient arrived after its bucket had been reduced (the step's graph differs from the "
-                               "discovery step's); call GradReducer.rebuild()")
+            # more accumulations than discovered: the bucket already holds avg(earlier) + this rank's late part; reducing
+            # it once more in finish() gives avg(earlier) + avg(late) exactly (the first term is equal on all ranks)
+            self._redo.add(b)
+            return
         self._remaining[b] -= 1
         if self._remaining[b] == 0:
             self._launch(b)
 
+    def _reduce_async(self, t):
+        """all-reduce (average for RCCL, sum for gloo) of a flat tensor; returns a closure that completes it"""
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if self._stage_host is None and not self._avg and t.is_cuda:
+            try:                                  # gloo builds without device-tensor support: stage through the host
+                dist.all_reduce(torch.zeros(1, device=t.device), group=self.group)
+                self._stage_host = False
+            except RuntimeError:
+                self._stage_host = True
+        if self._stage_host and t.is_cuda:
+            h = t.detach().cpu()
+            w = dist.all_reduce(h, op=op, group=self.group, async_op=True)
+
+            def done():
+                w.wait()
+                t.copy_(h)
+                if not self._avg and self.world > 1:
+                    t.div_(self.world)
+            return done
+        w = dist.all_reduce(t, op=op, group=self.group, async_op=True)
+
+        def done():
+            w.wait()                              # stream-ordered for RCCL: the current stream waits, the host does not
+            if not self._avg and self.world > 1:
+                t.div_(self.world)
+        return done
+
     def _launch(self, b):
         s, e = self.buckets[b]
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._works[b] = dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True)
+        self._works[b] = self._reduce_async(self.flat[s:e])
         self._launched[b] = True
 
     def finish(self):
-        """call after backward: reduce whatever has not been launched yet, wait for every bucket (stream-ordered for
-        RCCL: the current stream waits, the host does not), average."""
+        """call after backward: reduce whatever has not been launched yet, wait for every bucket, average; then agree
+        across ranks on whether this step's graph matched the discovered one and repair / re-discover if not."""
         if not self.active:
             return
+        dev = None
         if self.flat is None:
             self._build()
             for b in range(len(self.buckets)):
@@ -123,21 +232,56 @@ class GradReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        dev = self.flat.device
+        if self.timing and dev.type == "cuda":
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for w in self._works:
-            w.wait()
-        if not self._avg and self.world > 1:
-            self.flat.div_(self.world)
+            w()
+        if self.timing and dev.type == "cuda":
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._ev = (ev0, ev1)
+        self._reconcile(dev)
+
+    def _reconcile(self, dev):
+        """one small collective per step: flags [redo bucket b ...| stray parameter i ...], MAX over ranks"""
+        nb = len(self.buckets)
+        flags = torch.zeros(nb + len(self.params), dtype=torch.int32)
+        for b in self._redo:
+            flags[b] = 1
+        for i in self._stray:
+            flags[nb + i] = 1
+        if self.world > 1:
+            stage = self._stage_host or dev.type != "cuda"
+            f = flags if stage else flags.to(dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+            flags = f.cpu()
+        if not bool(flags.any()):
+            return
+        for b in torch.nonzero(flags[:nb]).flatten().tolist():
+            s, e = self.buckets[b]
+            self._reduce_async(self.flat[s:e])()
+        for i in torch.nonzero(flags[nb:]).flatten().tolist():
+            p = self.params[i]
+            if p.grad is None:                    # another rank's stray: this rank contributes zeros
+                p.grad = torch.zeros_like(p)
+            self._reduce_async(p.grad.view(-1))()
+        self.rediscoveries += 1
+        # this step's (now exact) gradients stay where they are for the optimizer; the next begin_step forgets the
+        # structure and discovers again
+        self._pending_rebuild = True
 
     def rebuild(self):
         """forget the discovered structure (the next step is a discovery step again)"""
         for p in self.params:
             p.grad = None
-        self.flat, self.buckets, self._bucket_of, self._expected = None, [], {}, {}
+        self.flat, self.buckets, self._bucket_of, self._expected, self._views = None, [], {}, {}, {}
 
     # ---------------------------------------------------------------- discovery -> buckets
     def _build(self):
         live = [p for p in self.params if p.grad is not None]
-        index = {id(p): i for i, p in enumerate(self.params)}
+        index = self._index
         # order of completion and accumulation counts as seen by rank 0, identical buckets everywhere
         seen = [(index[k], self._fired[k]) for k in self._order if k in index]
         missing = [index[id(p)] for p in live if id(p) not in self._fired]       # gradient assigned without any hook
@@ -148,11 +292,16 @@ class GradReducer:
         plan = obj[0]
         self._plan = plan
         mine = sorted(index[id(p)] for p in live)
-        if sorted(i for i, _ in plan) != mine:
-            raise RuntimeError("ranks disagree on which parameters receive gradients")
+        ok = sorted(i for i, _ in plan) == mine
+        if self.world > 1:                        # the verdict is collective: a lone raise would leave the others hanging
+            oks = [None] * self.world
+            dist.all_gather_object(oks, ok, group=self.group)
+            ok = all(oks)
+        if not ok:
+            raise RuntimeError("ranks disagree on which parameters receive gradients in the discovery step")
         dev, total = live[0].device, sum(p.numel() for p in live)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.buckets, self._bucket_params, self._bucket_of, self._expected = [], [], {}, {}
+        self.buckets, self._bucket_params, self._bucket_of, self._expected, self._views = [], [], {}, {}, {}
         off, start, cur = 0, 0, []
         for i, cnt in plan:
             p = self.params[i]
@@ -166,6 +315,7 @@ class GradReducer:
             view = self.flat[off:off + n].view_as(p)
             view.copy_(p.grad)
             p.grad = view
+            self._views[id(p)] = view
             self._bucket_of[id(p)] = len(self.buckets)
             self._expected[id(p)] = cnt
             cur.append(p)

@@ -52,14 +52,19 @@ class Trainer:
     rank's shard of windows, with gradient averaging across ranks overlapped with backward (dp.GradReducer; the reference
     uses DistributedDataParallel, :615).  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
 
-    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=32 << 20, last_frame_only=True, force_reduce=False):
+    def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=32 << 20, last_frame_only=True, force_reduce=False,
+                 sync_params=True):
         """last_frame_only: run the model in its training-step mode (the live loss terms of loss_fn and the frame
         updates read the last frame of each window only, so the conv tower evaluates just that frame's dependency
         cone; identical loss and gradients, see DFOLDIpaScore.forward).  False = every frame, as the reference.
         force_reduce: run the gradient collectives even in a single-rank world (coverage of the multi-GPU path on one
-        GPU)."""
-        from .dp import GradReducer
+        GPU).  sync_params: in a multi-rank world, start from rank 0's parameters and buffers like the reference's
+        DistributedDataParallel wrap does (train_DFOLD_dynamics.py:615; every rank is seeded differently, :419)."""
+        from .dp import GradReducer, broadcast_parameters
         self.model = model
+        self.bytes_broadcast = 0
+        if sync_params:
+            self.bytes_broadcast = broadcast_parameters(list(model.parameters()) + list(model.buffers()))
         self.last_frame_only = last_frame_only
         self.params = [p for p in model.parameters() if p.requires_grad]
         if self.params and self.params[0].is_cuda:
@@ -88,6 +93,34 @@ class Trainer:
         if step_optimizer:
             self.opt.step()
         return loss.detach(), aux
+
+    def sync_from_rank0(self):
+        """Every rank takes rank 0's parameters, buffers AND optimizer state (exp_avg / exp_avg_sq / max_exp_avg_sq /
+        step): call after checkpoint.resume() on rank 0 only, or whenever ranks may have diverged.  The optimizer state
+        must exist on every rank first (a resumed rank has it; a fresh one gets zero state of the right shapes)."""
+        from .dp import broadcast_parameters
+        ts = list(self.model.parameters()) + list(self.model.buffers())
+        steps = []
+        for p in self.params:
+            st = self.opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                    st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.append(float(st["step"]))
+            ts += [st["exp_avg"], st["exp_avg_sq"], st["max_exp_avg_sq"]]
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        step_t = torch.tensor(steps, dtype=torch.float64, device=dev)     # the step counters live on the host: one vector
+        n = broadcast_parameters(ts + [step_t])
+        for p, v in zip(self.params, step_t.cpu().tolist()):
+            st = self.opt.state[p]
+            if torch.is_tensor(st["step"]):
+                st["step"].fill_(v)
+            else:
+                st["step"] = v
+        if self.params and self.params[0].is_cuda:
+            torch.autograd.graph.increment_version(self.params)    # the bf16 weight caches key on the version counter
+        return n
 
 
 def set_t_feats(diffuser, feats, t, like):

@@ -207,8 +207,11 @@ def linear_gln(x, weight, bias, silu):
 
 class ConvTowerFn(Function):
     """ConvNet (src/model/ipa_pytorch_dynamic.py:664-706) on bf16 [W,F,N,C].  `tower` is the shared
-    ops.ConvTower; weight gradients of all applications in a step are accumulated inside it (GEMM layout,
-    fp32) and added to the parameters' .grad layer by layer during the backward of the application that runs last."""
+    ops.ConvTower; weight gradients of all applications of a graph are accumulated inside it (GEMM layout, fp32) and
+    leave it in the backward of the application that runs last: as ordinary autograd outputs (AccumulateGrad nodes and
+    their hooks run, torch.autograd.grad() and a DistributedDataParallel wrapper see them), or -- only when a
+    dp.GradReducer has registered itself on the tower (`on_final`) -- layer by layer straight into .grad while the
+    remaining layers still compute, so that the reducer can start the all-reduce of the top layers early."""
 
     @staticmethod
     def forward(ctx, tower, last_frame_only, track, n_parts, *args):
@@ -218,9 +221,11 @@ class ConvTowerFn(Function):
         last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
         dependency cone of that frame (ops.ConvTower.cone); the other output frames are returned as zeros and the
         incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller).
-        track: a backward will follow (grad mode on and something requires grad, decided by the caller -- inside
+        track (bit 0): a backward will follow (grad mode on and something requires grad, decided by the caller -- inside
         Function.forward grad mode is always off).  Only then are the activations kept and the application counted in
-        `tower.pending`; a no_grad pass (sampling, self-conditioning, evaluation) leaves no trace in the tower."""
+        `tower.pending`; a no_grad pass (sampling, self-conditioning, evaluation) leaves no trace in the tower.
+        track bit 1: this application is the first one of a forward pass of the model (ops.ConvTower.register_application)."""
+        new_group, track = bool(int(track) & 2), bool(int(track) & 1)
         xs = args[:n_parts]
         Wn, F, N, _ = xs[0].shape
         widths = [x.shape[-1] for x in xs]
@@ -237,8 +242,10 @@ class ConvTowerFn(Function):
         ctx.tower, ctx.g, ctx.saved, ctx.last, ctx.track, ctx.widths = tower, g, saved, last_frame_only, track, widths
         ctx.n_params = len(args) - n_parts
         ctx.slot, ctx.gen = slot, tower.slot_gen.get(slot)
-        if track:
-            tower.pending += 1
+        # a tracked application is alive as long as its graph is: the tower counts live tokens, so a forward whose loss was
+        # dropped / a validation pass without no_grad / an exception between forward and backward cannot leave a stale
+        # count behind (the token dies with the graph)
+        ctx.token = tower.register_application(new_group) if track else None
         return g.interior(h4).contiguous()
 
     @staticmethod
@@ -252,20 +259,27 @@ class ConvTowerFn(Function):
             g.interior(gt)[:, -1:].copy_(gy[:, -1:])
         else:
             g.interior(gt).copy_(gy)
-        # the application whose backward runs last hands each layer's summed gradient to the parameters' .grad as soon as
-        # that layer's last weight-gradient product is done (ops.ConvTower.finalize_layer) -- not through autograd's
-        # return values, so that a data-parallel reducer can start on the top layers while the bottom ones still compute
-        last = tower.pending <= 1
-        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=last)
+        # The application whose backward runs last delivers the summed gradients.  With a data-parallel reducer registered
+        # (tower.on_final) each layer's gradient goes to .grad as soon as that layer's last weight-gradient product is
+        # done (ops.ConvTower.finalize_layer), so that the reducer can start on the top layers while the bottom ones still
+        # compute; otherwise the gradients are returned through autograd like any other node's.
+        last = tower.pending_in_group(ctx.token) <= 1
+        early = last and tower.on_final is not None
+        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=early)
         ctx.saved = None
-        tower.pending = max(0, tower.pending - 1)
+        tower.complete_application(ctx.token)
+        ctx.token = None
+        pgrads = [None] * ctx.n_params
+        if last and not early:
+            pgrads = [t if ctx.needs_input_grad[4 + len(ctx.widths) + k] else None
+                      for k, t in enumerate(tower.collect_grads())][:ctx.n_params]
         # one compact copy per input slice (g0 is scratch of the tower, overwritten by the next application's backward;
         # the slices are what the producers' backward nodes read -- no full-width copy in between)
         inner, off, grads = g.interior(g0), 0, []
         for k, c in enumerate(ctx.widths):
             grads.append(inner[..., off:off + c].contiguous() if ctx.needs_input_grad[4 + k] else None)
             off += c
-        return (None, None, None, None, *grads, *([None] * ctx.n_params))
+        return (None, None, None, None, *grads, *pgrads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -69,14 +69,17 @@ class ConvNet(nn.Module):
             self._tower = ops.ConvTower(ws, bs)
         return self._tower
 
-    def run(self, x, last_frame_only=False):
+    def run(self, x, last_frame_only=False, first_of_pass=True):
         """x bf16 [W,F,N,C], or a list of channel slices [W,F,N,C_k] that are concatenated inside the padded conv grid
-        (no torch.cat) -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode)."""
+        (no torch.cat) -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode).
+        first_of_pass: this is the first application of the shared tower in a forward pass of the enclosing model (the
+        weight gradients of the applications of one pass are summed inside the tower and delivered together)."""
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
         ws, bs = self._params()
         inter = [p for pair in zip(ws, bs) for p in pair]
         track = torch.is_grad_enabled() and (any(t.requires_grad for t in xs) or any(p.requires_grad for p in inter))
-        return F_.ConvTowerFn.apply(self.tower(), bool(last_frame_only), bool(track), len(xs), *xs, *inter)
+        flags = (1 if track else 0) | (2 if first_of_pass else 0)
+        return F_.ConvTowerFn.apply(self.tower(), bool(last_frame_only), flags, len(xs), *xs, *inter)
 
     def forward(self, x):
         _require_cuda(x)
@@ -282,7 +285,8 @@ class DFOLDIpaScore(nn.Module):
             feats = ipa.features(node_embed, edge, curr_rigids, node_mask)
             ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
             # cat([rigids, ipa, force, vel, angle], -1) (:846) happens inside the padded conv grid
-            node_feat = conv.run([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], last_frame_only)
+            node_feat = conv.run([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], last_frame_only,
+                                 first_of_pass=(b == 0))
             if last_frame_only:
                 # only frame F-1 of the tower output is defined (and consumed): per-position heads run on it alone
                 upd_last = self.trunk[f'bb_update_{b}'](node_feat[:, -1:])

@@ -366,7 +366,7 @@ class ConvTower:
         self.pool = Workspace(dev)   # persistent activation grids of the applications of a step (grid())
         self.pool_bytes = 0
         self.slot_gen = {}
-        self.pending = 0          # applications whose backward has not run yet (see model.functional.ConvTowerFn)
+        self._apps = []           # weak references to the tokens of tracked applications whose backward has not run yet
         self.fresh = [True] * len(weights)   # accumulator j holds nothing yet this step: its first wgrad overwrites
         self.on_final = None      # callback(param) after a layer's gradient has been handed to .grad (dp.GradReducer)
         self._stamp = None
@@ -403,6 +403,60 @@ class ConvTower:
             self.on_final(w)
             self.on_final(b)
 
+    def collect_grads(self):
+        """The accumulated gradients as fresh tensors in the reference layout, interleaved [w0, b0, w1, b1, ...] (None for
+        a layer that accumulated nothing), accumulators re-armed: what ConvTowerFn.backward returns through autograd."""
+        out = []
+        for j, (w, b, dwg, db) in enumerate(zip(self.weights, self.biases, self.dwg, self.db)):
+            if self.fresh[j]:
+                out += [None, None]
+                continue
+            gw = torch.empty_like(w)
+            check(_lib.lib().dfold_conv_wgrad_unpack(_p(dwg), _p(gw), c_int32(w.shape[0]), c_int32(w.shape[1]), c_int32(0),
+                                                     c_int32(1 if w.shape[1] > w.shape[0] else 0), stream()),
+                  "dfold_conv_wgrad_unpack")
+            out += [gw, db.clone()]
+            db.zero_()
+            self.fresh[j] = True
+        return out
+
+    # ---- live tracked applications (functional.ConvTowerFn) ----
+    class _App:
+        __slots__ = ("group", "__weakref__")
+
+    def _live(self, group=None):
+        self._apps = [r for r in self._apps if r() is not None]
+        if group is None:
+            return len(self._apps)
+        return sum(1 for r in self._apps if (lambda t: t is not None and t.group == group)(r()))
+
+    @property
+    def pending(self):
+        """tracked applications whose backward has not run yet and whose graph is still alive"""
+        return self._live()
+
+    def register_application(self, new_group):
+        """A tracked application joins the group of applications of ONE forward pass of the model (new_group: it is the
+        first one of such a pass).  The gradients of a group are delivered by whichever of its applications runs its
+        backward last.  Tokens die with their graph, so a forward whose loss was dropped, a validation pass without
+        no_grad or an exception between forward and backward leaves no stale count behind; a graph that is merely kept
+        alive (outputs stored somewhere) is its own group and does not block the delivery of later ones."""
+        if self._live() == 0 and not all(self.fresh):
+            self.zero_grad()          # partial sums of a graph that died between two of its backward applications
+        if new_group or not self._apps:
+            self._group = getattr(self, "_group", 0) + 1
+        import weakref
+        tok = ConvTower._App()
+        tok.group = self._group
+        self._apps.append(weakref.ref(tok))
+        return tok
+
+    def pending_in_group(self, tok):
+        return self._live(tok.group)
+
+    def complete_application(self, tok):
+        self._apps = [r for r in self._apps if r() is not None and r() is not tok]
+
     def pack(self):
         L = _lib.lib()
         for w, wf, wd in zip(self.weights, self.wf, self.wd):
@@ -417,8 +471,8 @@ class ConvTower:
     def reset_step(self):
         """Start of a training step: forget applications whose backward never ran (an exception between forward and
         backward, a forward whose loss was dropped) so that their count and partial sums cannot leak into this step."""
-        if self.pending or not all(self.fresh):
-            self.pending = 0
+        if self._apps or not all(self.fresh):
+            self._apps = []
             self.zero_grad()
 
     @staticmethod

@@ -91,13 +91,17 @@ def _quat_mul_np(p, q):
                      a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2], -1)
 
 
-def synthetic_window(seed, F, N, t=0.5, diffuser=None):
+def synthetic_window(seed, F, N, t=0.5, diffuser=None, rigid_cls=None, holes=0.0):
     """One window of F frames x N residues as float32/int64 torch CPU tensors with the
     reference dataset's keys.  Smooth trajectory: frame f+1 = frame f composed with a small
     rigid perturbation (rotvec sigma 0.05 rad, translation sigma 0.3 A) so the reference's
     trans_loss<100 gate stays open.  If `diffuser` (an SE3Diffuser) is given, rigids_t and the
     target scores come from its forward_marginal under numpy seed `seed`; otherwise only the
-    model inputs that do not need a diffuser are filled."""
+    model inputs that do not need a diffuser are filled.  `rigid_cls`: the Rigid class handed to the diffuser (the
+    golden-minting script passes the REFERENCE's openfold Rigid so that no product code sits between the seed and the
+    reference's forward_marginal).  `holes` > 0: res_mask with that fraction of dead residues plus one dead residue at
+    each end of the chain (the loader's res_mask is the CA mask, src/data/Dfold_data_loader_dynamic.py:248, and can
+    have holes); drawn from a separate stream so that the other tensors do not depend on it."""
     rng = np.random.default_rng(seed)
     q0 = rng.standard_normal((N, 4))
     q0 /= np.linalg.norm(q0, axis=-1, keepdims=True)
@@ -132,8 +136,15 @@ def synthetic_window(seed, F, N, t=0.5, diffuser=None):
         t=torch.tensor([t], dtype=torch.float32),
     )
     w["sc_ca_t"] = torch.zeros(F, N, 3)
+    if holes > 0:
+        dead = np.random.default_rng(seed + 7919).uniform(size=N) < holes
+        dead[0] = dead[-1] = True
+        w["res_mask"] = torch.tensor(np.repeat((~dead)[None], F, 0).astype(np.float32))
     if diffuser is not None:
-        from .rigid import Rigid
+        if rigid_cls is None:
+            from .rigid import Rigid
+        else:
+            Rigid = rigid_cls
         state = np.random.get_state()
         np.random.seed(seed)
         fm = diffuser.forward_marginal(Rigid.from_tensor_7(w["rigids_0"]), t, diffuse_mask=None, as_tensor_7=True)

@@ -22,8 +22,9 @@ import ref_import  # noqa: E402
 ref_import.install()
 os.chdir(os.environ.get("DFOLD_GOLDEN_WORKDIR", "/tmp/work"))
 
-from dynamicpdb_amd import synthetic  # noqa: E402
-from dynamicpdb_amd.rigid import Rigid  # noqa: E402
+from dynamicpdb_amd import synthetic  # noqa: E402  (seeded inputs / weights only: plain numpy, no device code)
+# the REFERENCE's Rigid: nothing of the product sits between the seeded inputs and the reference's diffuser
+from openfold.utils.rigid_utils import Rigid  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -40,7 +41,8 @@ def subsample(g, stride=9973):
 DIFFUSER_KEYS = ("rigids_t", "rot_score", "trans_score", "rot_score_scaling", "trans_score_scaling")
 
 
-def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973, compact=False):
+def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973, compact=False, holes=0.0,
+                   tag=""):
     """compact=True (BASELINE-sized captures): only the diffuser-dependent inputs are stored; every other input is
     regenerated bit-identically on the test side from dynamicpdb_amd.synthetic.synthetic_window(seed_x, F, N, t) and
     pinned by a float64 checksum."""
@@ -53,7 +55,7 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_str
     model.load_state_dict(sd, strict=True)
     model.eval()
     diffuser = exp.diffuser
-    win = synthetic.synthetic_window(seed_x, F, N, t=t, diffuser=diffuser)
+    win = synthetic.synthetic_window(seed_x, F, N, t=t, diffuser=diffuser, rigid_cls=Rigid, holes=holes)
     batch = {k: v.clone() for k, v in win.items()}
     # per-op captures through forward hooks on the reference modules
     cap = {}
@@ -108,7 +110,8 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_str
         fix[f"gsub_{name}"] = np_(subsample(g, grad_stride) if g.numel() > 70000 else g)
     fix["meta"] = np.array([F, N, seed_w, seed_x, grad_stride], np.int64)
     fix["t"] = np.array([t])
-    np.savez_compressed(os.path.join(HERE, f"network_F{F}_N{N}.npz"), **fix)
+    fix["holes"] = np.array([holes])
+    np.savez_compressed(os.path.join(HERE, f"network_F{F}_N{N}{tag}.npz"), **fix)
     print("network golden: loss", float(loss), {k: float(v) for k, v in aux.items() if "batch" not in k})
     return exp
 
@@ -122,7 +125,7 @@ def golden_sampler(F=3, N=16, seed_w=4, seed_x=8, num_t=3, noise_scale=0.5, seed
     conf.data.num_t = num_t
     exp = T.Experiment(conf=conf)
     exp.model.load_state_dict(synthetic.seeded_state_dict(seed_w), strict=True)
-    win = synthetic.synthetic_window(seed_x, F, N, t=1.0, diffuser=exp.diffuser)
+    win = synthetic.synthetic_window(seed_x, F, N, t=1.0, diffuser=exp.diffuser, rigid_cls=Rigid)
     np.random.seed(seed_z - 1)
     prior = exp.diffuser.sample_ref(n_samples=F * N, as_tensor_7=True)["rigids_t"].reshape(F, N, 7).to(torch.float32)
     init = {k: v.clone() for k, v in win.items()}
@@ -418,6 +421,24 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "network_n256":
         # run_train.sh window (frame_time = 2) at the headline N_res = 256
         golden_network(F=2, N=256, seed_w=13, seed_x=14, t=0.6, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_cfg3":
+        # BASELINE config 3 / 4: one 32-frame window at N_res 256 (the shape bench.py times, B = 8 independent windows)
+        golden_network(F=32, N=256, seed_w=21, seed_x=22, t=0.45, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_cfg2":
+        # BASELINE config 2: one 32-frame window at N_res 128
+        golden_network(F=32, N=128, seed_w=23, seed_x=24, t=0.35, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_cfg5":
+        # BASELINE config 5 is 64 frames x N_res 512: the reference cannot hold its IPA intermediates;
+        # 8 frames at N_res 512 is what it can run
+        golden_network(F=8, N=512, seed_w=25, seed_x=26, t=0.55, captures=False, grad_stride=39989, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "network_holes":
+        # res_mask with holes (10 % dead residues + both chain ends dead): masks of IPA, frame update, score heads,
+        # loss normalisers and the whole-tensor MyLayerNorm with dead residues, end to end
+        golden_network(F=6, N=40, seed_w=27, seed_x=28, t=0.5, captures=False, grad_stride=39989, holes=0.1, tag="_holes")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sampler":
         golden_sampler()

@@ -166,7 +166,10 @@ class _Toy(torch.nn.Module):
         h = torch.tanh(self.inp(batch["x"]))
         for _ in range(3):
             h = torch.tanh(self.shared(h))
-        return self.out(torch.tanh(self.big(h)))
+        y = self.out(torch.tanh(self.big(h)))
+        if batch.get("use_dead"):          # a step whose graph differs from the discovered one (on ONE rank only)
+            y = y + self.dead(batch["x"][:, :4]).sum(-1, keepdim=True)
+        return y
 
 
 def _dp_worker(rank, world, port, q):
@@ -179,19 +182,26 @@ def _dp_worker(rank, world, port, q):
     experiment.loss_fn = lambda out, batch, **kw: (out.pow(2).mean(), {})      # toy read-out instead of the SE(3) loss
     try:
         torch.manual_seed(0)
+        ref = _Toy()                                # the single-process reference starts from rank 0's initialisation
+        torch.manual_seed(rank)                     # every rank seeds differently (train_DFOLD_dynamics.py:419) ...
         model = _Toy()
-        ref = _Toy()
-        ref.load_state_dict(model.state_dict())
+        started_equal = all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))
         tr = experiment.Trainer(model, lr=1e-2, bucket_bytes=1024, last_frame_only=False)   # tiny buckets: several collectives
+        # ... and the Trainer starts every rank from rank 0's parameters (DDP's start-up broadcast, :615)
+        synced = all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))
         ref_opt = torch.optim.Adam([p for p in ref.parameters()], lr=1e-2, amsgrad=True)
         rows = []
-        for step in range(3):                       # step 0 = discovery, then bucketed / hook-driven steps
+        for step in range(6):                       # step 0 = discovery, then bucketed / hook-driven steps
             xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + 10 * step + r)) for r in range(world)]
-            loss, _ = tr.update_fn({"x": xs[rank]}, step_optimizer=True)
+            # step 3: rank 1 alone uses a parameter that had no gradient in the discovery step -> exact repair + re-discovery
+            flag = [step == 3 and r == 1 for r in range(world)]
+            if step == 2:                           # a caller that drops the gradients between steps
+                tr.opt.zero_grad(set_to_none=True)
+            loss, _ = tr.update_fn({"x": xs[rank], "use_dead": flag[rank]}, step_optimizer=True)
             # reference: the mean over ranks of the per-rank gradients, computed locally from every rank's shard
             ref_opt.zero_grad(set_to_none=True)
             for r in range(world):
-                (ref(dict(x=xs[r])).pow(2).mean() / world).backward()
+                (ref(dict(x=xs[r], use_dead=flag[r])).pow(2).mean() / world).backward()
             want = [None if p.grad is None else p.grad.clone() for p in ref.parameters()]
             got = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
             ref_opt.step()
@@ -199,7 +209,8 @@ def _dp_worker(rank, world, port, q):
         red = tr.reducer
         info = dict(n_buckets=len(red.buckets), views=all(p.grad is None or p.grad.untyped_storage().data_ptr() ==
                                                           red.flat.untyped_storage().data_ptr() for p in model.parameters()),
-                    expected_shared=red._expected[id(model.shared.weight)],
+                    expected_shared=red._expected[id(model.shared.weight)], rediscoveries=red.rediscoveries,
+                    started_equal=started_equal, synced=synced, bytes_broadcast=tr.bytes_broadcast,
                     params_equal=all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(model.parameters(), ref.parameters())))
         q.put((rank, rows, info))
     finally:
@@ -209,9 +220,12 @@ def _dp_worker(rank, world, port, q):
 
 
 def test_data_parallel_gradient_average_gloo_world2():
-    """2 gloo ranks, 3 steps: after every step each rank holds the mean over ranks of the per-rank gradients (discovery
-    step and hook-driven bucketed steps alike), gradients are views of the one flat buffer, the layer applied 3x per step
-    completes once (autograd sums its uses before the single accumulation), the dead parameter keeps grad None, and the optimizer trajectories match a single-process reference."""
+    """2 gloo ranks seeded differently, 6 steps: the Trainer starts both from rank 0's parameters; after every step each
+    rank holds the mean over ranks of the per-rank gradients (discovery step and hook-driven bucketed steps alike, also
+    after a caller's zero_grad(set_to_none=True)), gradients are views of the one flat buffer, the layer applied 3x per
+    step completes once (autograd sums its uses before the single accumulation), the dead parameter keeps grad None; a
+    step in which ONE rank's graph uses a parameter that had no gradient in the discovery step is still averaged exactly
+    and followed by a re-discovery; the optimizer trajectories match a single-process reference."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -230,6 +244,8 @@ def test_data_parallel_gradient_average_gloo_world2():
                 if g is not None:
                     assert np.allclose(g, w, rtol=1e-5, atol=1e-7), (rank, step)
         assert info["n_buckets"] >= 3 and info["views"] and info["expected_shared"] == 1 and info["params_equal"], info
+        assert info["rediscoveries"] == 1 and info["synced"] and info["bytes_broadcast"] > 0, info
+        assert info["started_equal"] == (rank == 0), info
 
 
 def test_bench_spawns_one_rank_per_gpu():

@@ -269,3 +269,54 @@ def test_fused_long_chain_properties(name):
         keep = ~dead
         # the perturbed cells only change their own output rows (their q / gate), not the other queries of the column
         assert rel_l2(y2[0, keep, 7], y[0, keep, 7]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
+@pytest.mark.parametrize("N", [256, 512])
+def test_fused_bench_sizes_vs_oracle(name, N):
+    """The sizes on the bench line -- N_res 256 and 512 (4 / 8 tiles per line, 1 / 2 key chunks of the attention core,
+    8192 / 65536 output tiles of the contraction) -- against the CPU oracle (the fp32 restatement of
+    openfold/model/triangular_multiplicative_update.py:61-126 and triangular_attention.py:78-139, pinned to the
+    reference-minted triangle_N24.npz): fp32 and bf16 pair tensors, two batch items at N_res 256 (the second item only
+    through the batch == single-call bit equality at 512, to bound the oracle's CPU time)."""
+    dev = torch.device(DEV)
+    m = _rand_module(_names()[name](), 60 + N // 256)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(dev)
+    B = 2
+    z, mask = _inputs(B, N, 61 + N, holes=0.07)
+    nref = B if N == 256 else 1
+    with torch.no_grad():
+        ref = torch.stack([_oracle(name, P, z[b], mask[b]) for b in range(nref)])
+        y = m(z.to(dev), mask=mask.to(dev))
+        yb = m(z.to(dev).to(BF16), mask=mask.to(dev))
+        y1 = m(z[1].to(dev), mask=mask[1].to(dev))
+    assert torch.isfinite(y).all() and torch.equal(y[1], y1)
+    e32, e16 = rel_l2(y[:nref], ref), rel_l2(yb[:nref].float(), ref)
+    print(f"[{name} N={N}] rel-L2 vs oracle: fp32 I/O {e32:.2e}, bf16 I/O {e16:.2e}")
+    assert e32 < 1.5e-2 and e16 < 2.5e-2, (e32, e16)
+    # per-cell: no single output row may be off by more than the bf16 class allows (catches a wrong tile / chunk seam
+    # that a global norm would average away)
+    d = (y[:nref].cpu() - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-3)
+    assert float(d.max()) < 0.15, float(d.max())
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
+def test_fused_nres256_gradients_vs_oracle(name):
+    """Backward at N_res 256 (one batch item) against the oracle's autograd: input gradient and every parameter
+    gradient, bf16 class."""
+    dev = torch.device(DEV)
+    N = 256
+    m = _rand_module(_names()[name](), 71)
+    P = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m.to(dev)
+    z, mask = _inputs(1, N, 72, holes=0.07)
+    gy = torch.tensor(np.random.default_rng(73).standard_normal((N, N, 128), dtype=np.float32))
+    zr = z[0].clone().requires_grad_(True)
+    _oracle(name, P, zr, mask[0]).backward(gy)
+    zz = z[0].to(dev).requires_grad_(True)
+    y = m(zz, mask=mask[0].to(dev))
+    y.backward(gy.to(dev))
+    assert rel_l2(zz.grad, zr.grad) < 3e-2, rel_l2(zz.grad, zr.grad)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, P[k].grad) < 3e-2, (k, rel_l2(p.grad, P[k].grad))

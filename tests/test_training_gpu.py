@@ -343,3 +343,145 @@ def test_loss_fn_on_device_vs_oracle_values_and_gradients():
         want = torch.stack([g[k] for g in ref_g]) / B          # the batched loss is the mean over windows
         assert rel_l2(ob[k].grad, want) < 1e-5, k
     assert set(aux) >= {"rot_loss", "trans_loss", "torsion_loss"}
+
+
+def test_conv_gradients_flow_through_autograd_and_ddp_wrapper():
+    """Without a dp.GradReducer the shared conv tower's weight gradients leave ConvTowerFn.backward as ordinary autograd
+    outputs: torch.autograd.grad() returns them, post-accumulate hooks fire, and the reference's own wrapper
+    -- DistributedDataParallel(find_unused_parameters=True), train_DFOLD_dynamics.py:615 -- reduces them (world of one
+    RCCL rank here: the wrapper's reducer must see every conv parameter as used and ready)."""
+    import os
+    import torch.distributed as dist
+    from dynamicpdb_amd import experiment
+    dev = torch.device(DEV)
+    F, N, B = 5, 16, 1
+    model, diffuser = _build(F, 8, dev)
+    batch = _batch(diffuser, B, F, N, dev, seed=90)
+    conv_names = [n for n, _ in model.named_parameters() if "conv_0" in n]
+    P = dict(model.named_parameters())
+    # (a) reference gradients: plain backward
+    out = model({k: v.clone() for k, v in batch.items()})
+    loss, _ = experiment.loss_fn(out, batch)
+    fired = []
+    hooks = [P[n].register_post_accumulate_grad_hook(lambda p, n=n: fired.append(n)) for n in conv_names]
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    assert sorted(fired) == sorted(conv_names)
+    ref = {n: P[n].grad.detach().clone() for n in conv_names}
+    assert all(float(g.abs().max()) > 0 for g in ref.values())
+    # (b) torch.autograd.grad sees them and leaves .grad alone
+    model.zero_grad(set_to_none=True)
+    out = model({k: v.clone() for k, v in batch.items()})
+    loss, _ = experiment.loss_fn(out, batch)
+    gs = torch.autograd.grad(loss, [P[n] for n in conv_names])
+    assert all(P[n].grad is None for n in conv_names)
+    for n, g in zip(conv_names, gs):
+        assert rel_l2(g, ref[n]) < 1e-3, n
+    # (c) a forward whose graph is dropped, then a kept-alive stale graph: neither blocks the next step's delivery
+    _ = model({k: v.clone() for k, v in batch.items()})
+    del _
+    stale = model({k: v.clone() for k, v in batch.items()})
+    out = model({k: v.clone() for k, v in batch.items()})
+    experiment.loss_fn(out, batch)[0].backward()
+    for n in conv_names:
+        assert P[n].grad is not None and rel_l2(P[n].grad, ref[n]) < 1e-3, n
+    del stale, out
+    # (d) the reference's wrapper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        model.zero_grad(set_to_none=True)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+        for _ in range(2):          # second step: DDP's bucket rebuild has happened
+            ddp.zero_grad(set_to_none=True)
+            out = ddp({k: v.clone() for k, v in batch.items()})
+            experiment.loss_fn(out, batch)[0].backward()
+            for n in conv_names:
+                assert P[n].grad is not None and rel_l2(P[n].grad, ref[n]) < 1e-3, n
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_real_model_worker(rank, world, port, q):
+    """one of two ranks sharing cuda:0 (gloo backend: RCCL refuses two ranks on one device)"""
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dynamicpdb_amd import experiment
+        dev = torch.device(DEV)
+        F, N = 3, 16
+        model, diffuser = _build(F, 100 + rank, dev)          # every rank starts from DIFFERENT weights (train:419)
+        shards = [_batch(diffuser, 1, F, N, dev, seed=200 + 10 * r) for r in range(world)]
+        tr = experiment.Trainer(model, lr=0.0, last_frame_only=True, bucket_bytes=64 << 20)
+        tr.reducer.timing = True
+        ck = float(sum(p.detach().double().sum() for p in model.parameters()))
+        launched = []
+        fin = tr.reducer.finish
+
+        def spy():
+            if tr.reducer.flat is not None:
+                launched.append(list(tr.reducer._launched))
+            fin()
+        tr.reducer.finish = spy
+        for _ in range(3):
+            loss, _ = tr.update_fn(shards[rank])
+        got = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        # the mean of the per-rank gradients, computed locally on the (now common) weights without any reducer
+        tr.reducer.detach()
+        tr.reducer.active = False
+        want = None
+        for r in range(world):
+            model.zero_grad(set_to_none=True)
+            for m in model.modules():
+                if getattr(m, "_tower", None) is not None:
+                    m._tower.on_final = None
+            out = model(shards[r], last_frame_only=True)
+            experiment.loss_fn(out, shards[r])[0].backward()
+            g = {n: p.grad.detach().double() / world for n, p in model.named_parameters() if p.grad is not None}
+            want = g if want is None else {n: want[n] + g[n] for n in g}
+        gmax = max(float(v.norm()) for v in want.values())
+        worst = max(float((got[n].double() - want[n]).norm()) / max(float(want[n].norm()), 1e-3 * gmax) for n in want)
+        q.put((rank, dict(checksum=ck, worst=worst, same_keys=set(got) == set(want), launched=launched,
+                          n_buckets=len(tr.reducer.buckets), wait_ms=list(tr.reducer.wait_ms),
+                          bytes_broadcast=tr.bytes_broadcast, staged=bool(tr.reducer._stage_host))))
+    except Exception as e:   # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, dict(error=traceback.format_exc())))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_real_model_two_ranks_on_one_gpu():
+    """The REAL model under dp.GradReducer with a peer: two processes share cuda:0 at F3 x N16, gloo
+    backend, each seeded differently.  The Trainer's start-up broadcast makes the parameters equal (same checksum); after
+    the discovery step and two hook-driven steps each rank's gradients equal the mean of the per-rank gradients; every
+    bucket -- the eight conv-layer buckets handed over by ConvTower.finalize_layer -> mark_ready included -- was launched
+    before finish() (i.e. during backward, overlapping the peer's collective)."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_real_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for r in (0, 1):
+        assert "error" not in res[r], res[r].get("error")
+    assert abs(res[0]["checksum"] - res[1]["checksum"]) < 1e-9 * max(1.0, abs(res[0]["checksum"])), "parameters not broadcast"
+    for r in (0, 1):
+        info = res[r]
+        assert info["bytes_broadcast"] > 700e6 and info["same_keys"], info
+        assert info["worst"] < 2e-3, info["worst"]
+        assert info["n_buckets"] >= 8 and len(info["launched"]) == 2 and all(all(l) for l in info["launched"]), info["launched"]
+        assert len(info["wait_ms"]) >= 1
+    print("2-rank real model on one GPU: worst gradient deviation from the mean of per-rank gradients",
+          max(res[0]["worst"], res[1]["worst"]), "host-staged gloo:", res[0]["staged"], "wait_ms", res[0]["wait_ms"])

@@ -48,10 +48,22 @@ def compact_window(g):
     Returns (window dict of CPU tensors, (F, N, seed_w, grad_stride))."""
     from dynamicpdb_amd import synthetic
     F, N, seed_w, seed_x, stride = [int(v) for v in g["meta"]]
-    w = synthetic.synthetic_window(seed_x, F, N, t=float(g["t"][0]), diffuser=None)
+    holes = float(g["holes"][0]) if "holes" in g else 0.0
+    w = synthetic.synthetic_window(seed_x, F, N, t=float(g["t"][0]), diffuser=None, holes=holes)
     sums = np.array([float(np.asarray(w[k].numpy(), dtype=np.float64).sum()) for k in sorted(w)])
     assert np.array_equal(sums, g["in_checksum"]), "synthetic_window no longer reproduces the minted inputs"
     for k in DIFFUSER_KEYS:
         w[k] = torch.tensor(g["in_" + k])
     w["rigids_t"] = w["rigids_t"].float()
     return w, (F, N, seed_w, stride)
+
+
+def golden_window(g):
+    """(window of CPU tensors, (F, N, seed_w, grad_stride)) of a network golden of either form: compact (inputs
+    regenerated from the seed) or with every input stored."""
+    if "in_checksum" in g:
+        return compact_window(g)
+    meta = [int(v) for v in g["meta"]]
+    F, N, seed_w = meta[:3]
+    stride = meta[4] if len(meta) > 4 else 9973
+    return window_from_golden(g), (F, N, seed_w, stride)
