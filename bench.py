@@ -45,16 +45,36 @@ def parse():
                     help="only rendezvous (nccl with GPUs, gloo without), all-reduce one number, report n_gpus")
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
     ap.add_argument("--no-triangle", action="store_true", help="skip the triangle-operator extra object")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 5 extra objects")
+    ap.add_argument("--same-batch", action="store_true", help="feed one batch to every step (profiling aid; default: a "
+                    "fresh synthetic batch per step, generated on the device and staged in HBM before the timed region)")
     ap.add_argument("--mode", choices=("all_frames", "last_frame"), default="all_frames",
                     help="what the MAIN timed region runs (profiling aid; the contract's headline is all_frames)")
     return ap.parse_args()
 
 
 def make_batch(synthetic, diffuser, B, F, N, rank, dev):
+    """host-generated batch (numpy stream; the generator the golden vectors use)"""
     ws = [synthetic.synthetic_window(1000 * rank + i, F, N, t=0.5, diffuser=diffuser) for i in range(B)]
     batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0] if k != "t"}
     batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
     return batch
+
+
+def make_batches(synthetic, diffuser, B, F, N, rank, dev, count, same):
+    """`count` batches resident in HBM before any timed region starts: a FRESH synthetic batch per step (device Philox
+    stream seeded by (rank, step): the operand sparsity the conv kernels see does not drift towards a memorised batch),
+    or -- `same` -- one host-generated batch repeated."""
+    if same:
+        b = make_batch(synthetic, diffuser, B, F, N, rank, dev)
+        return [b] * count
+    from dynamicpdb_amd.rng import DeviceRNG
+    out = []
+    for i in range(count):
+        rng = DeviceRNG(seed=0x5EED0000 + 1000003 * rank + i, device=dev)
+        out.append(synthetic.device_batch(rng, diffuser, B, F, N, t=0.5))
+    torch.cuda.synchronize()
+    return out
 
 
 def conv_kernel_roofline(model, trainer, batch, B, F, N):
@@ -110,11 +130,11 @@ def triangle_roofline(dev, reps=10):
     out = {}
     for name, ctor in (("tri_mul_out", lambda: T_.TriangleMultiplicationOutgoing(128, 128)),
                        ("tri_att_start", lambda: T_.TriangleAttentionStartingNode(128, 32, 4))):
-        for n in (256, 512):
+        for n, nb in ((256, 1), (512, 1), (256, 8), (512, 8)):
             torch.manual_seed(0)
             m = ctor().to(dev)
-            z = torch.randn(1, n, n, 128, device=dev) * 1.5
-            mask = (torch.rand(1, n, n, device=dev) > 0.05).float()
+            z = torch.randn(nb, n, n, 128, device=dev) * 1.5
+            mask = (torch.rand(nb, n, n, device=dev) > 0.05).float()
             with torch.no_grad():
                 for _ in range(3):
                     m(z, mask=mask)
@@ -126,19 +146,23 @@ def triangle_roofline(dev, reps=10):
                 e1.record()
                 torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / reps * 1e-3
-            alg = n * n * (2 * 128 * 4 + 4)
-            out[f"{name}_n{n}"] = {"ms": round(t * 1e3, 4), "algorithmic_bytes": alg, "GBps": round(alg / t / 1e9, 1),
-                                   "hbm_frac": round(alg / t / 8.0e12, 4)}
-    out["note"] = ("forward, fp32 pair tensor, batch 1, fused kernels of csrc/pair_fused.hip; bound = hbm (8 TB/s); the calls are "
-                   "VALU / issue bound, not HBM bound: counters in profiles/r2_triangle_pmc_*.txt, DESIGN.md section 4")
+            alg = nb * n * n * (2 * 128 * 4 + 4)
+            key = f"{name}_n{n}" + ("" if nb == 1 else f"_b{nb}")
+            out[key] = {"ms": round(t * 1e3, 4), "batch": nb, "algorithmic_bytes": alg, "GBps": round(alg / t / 1e9, 1),
+                        "hbm_frac": round(alg / t / 8.0e12, 4)}
+            del m, z, mask
+    out["note"] = ("forward, fp32 pair tensor, batch 1 and batch 8, fused kernels of csrc/pair_fused.hip; bound = hbm (8 TB/s): "
+                   "algorithmic bytes = read z + write out + mask (SURVEY 8d); counters in profiles/, DESIGN.md section 4")
     return out
 
 
 def cpu_baseline(F, N, seed_w=0):
     """The oracle (CPU port of the reference path; kind "port" -- the reference itself is not on the GPU box) running the
     reference's update_fn on host cores: zero_grad + forward + loss + backward + Adam(amsgrad) step
-    (train_DFOLD_dynamics.py:660-667), ONE window of F frames x N_res = N.  Bounded sample: one cheap 2-frame iteration to
-    warm up the thread pool / primitive caches, then one timed iteration at F frames."""
+    (train_DFOLD_dynamics.py:660-667), ONE window of F frames x N_res = N (the reference has no batch axis: B windows are B
+    sequential calls, so frames/s of one window is the rate).  Bounded sample: two SAME-SHAPE warm-up iterations, one with
+    every usable core and one with half of them (SMT siblings rarely help a GEMM-bound torch CPU run); the faster setting
+    then runs two timed iterations, and the reported rate is their mean."""
     from oracle import dfold_oracle as O
     from dynamicpdb_amd import synthetic
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
@@ -146,28 +170,41 @@ def cpu_baseline(F, N, seed_w=0):
         cores = len(os.sched_getaffinity(0))      # cores this process may actually use (cgroup / affinity aware)
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 128))
-    torch.set_num_threads(threads)
     sd = synthetic.seeded_state_dict(seed_w)
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(list(P.values()), lr=1e-4, amsgrad=True)
-    times = {}
-    for frames in (2, F):
-        conf = synthetic.default_conf(frames, cache_dir="/tmp/dfold_igso3_cache/")
-        w = synthetic.synthetic_window(7, frames, N, t=0.5, diffuser=SE3Diffuser(conf.diffuser))
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    w = synthetic.synthetic_window(7, F, N, t=0.5, diffuser=SE3Diffuser(conf.diffuser))
+
+    def one():
         t0 = time.time()
         opt.zero_grad(set_to_none=True)
         out = O.full_score_network(P, O.Schedules(), w)
         loss, _ = O.loss_fn(out, w)
         loss.backward()
         opt.step()
-        times[frames] = time.time() - t0
-        print(f"[bench cpu_baseline] {frames}-frame window: {times[frames]:.2f} s ({threads} threads)", file=sys.stderr, flush=True)
-    t = times[F]
+        return time.time() - t0
+
+    warm = {}
+    for threads in sorted({cores, max(1, cores // 2)}, reverse=True):
+        torch.set_num_threads(threads)
+        warm[threads] = one()
+        print(f"[bench cpu_baseline] warm-up, {F}-frame window, {threads} threads: {warm[threads]:.2f} s", file=sys.stderr, flush=True)
+    threads = min(warm, key=warm.get)
+    torch.set_num_threads(threads)
+    timed = [one() for _ in range(2)]
+    print(f"[bench cpu_baseline] timed, {threads} threads: {timed[0]:.2f} s, {timed[1]:.2f} s", file=sys.stderr, flush=True)
+    t = sum(timed) / len(timed)
     return {"value": round(F / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle update_fn (zero_grad+fwd+loss+bwd+Adam amsgrad), 1 window of {F} frames x N_res={N}, one timed "
-                      f"iteration ({t:.2f} s) after a 2-frame warm-up iteration ({times[2]:.2f} s); torch CPU threads={threads}, "
-                      f"{cores} usable cores"}
+            "sample": f"oracle update_fn (zero_grad+fwd+loss+bwd+Adam amsgrad), 1 window of {F} frames x N_res={N}: mean of 2 timed "
+                      f"iterations ({timed[0]:.2f} s, {timed[1]:.2f} s) after same-shape warm-up iterations at "
+                      + ", ".join(f"{k} threads {v:.2f} s" for k, v in sorted(warm.items())) + f"; {cores} usable cores, "
+                      f"{threads} torch CPU threads used (the faster setting); the bench's windows are 32 frames: the per-frame "
+                      "conv work T(F)/F grows from 4.25 taps (F=8) to 4.81 (F=32), so this 8-frame rate OVERSTATES the CPU's "
+                      "32-frame rate by up to 13 % (conservative for any GPU/CPU ratio)",
+            "reference_probe": {"value": 0.43, "unit": "frames/s", "cores": 8, "shape": "1 window, 2 frames x N_res=256, fwd+bwd",
+                                "source": "the reference's own code (FullScoreNetwork fwd+bwd) timed in the build container, "
+                                          "SURVEY.md section 6 [probe]; the reference does not exist on the GPU box"}}
 
 
 def respawn(args):
@@ -195,6 +232,47 @@ def selftest_dist(args, world, rank):
               flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def timed_steps(trainer, batches, steps, sync):
+    """`steps` update_fn calls on successive pre-staged batches between two (barrier + device sync)s; returns seconds
+    (this rank) and the last loss (device scalar)."""
+    sync()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        loss, _ = trainer.update_fn(batches[i % len(batches)])     # device scalars: no host sync inside the timed region
+    sync()
+    return time.perf_counter() - t0, loss
+
+
+def other_config(tag, B, F, N, dev, steps, tlog):
+    """Extra object: the same update_fn at another BASELINE configuration on ONE GPU (fresh model of that window length,
+    fresh device batches), all frames through the tower."""
+    from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    model.load_state_dict(synthetic.seeded_state_dict(0), strict=True)
+    model.to(dev)
+    tr = experiment.Trainer(model, lr=1e-4, last_frame_only=False, sync_params=False)
+    batches = make_batches(synthetic, diffuser, B, F, N, 0, dev, 2 + steps, False)
+    sync = torch.cuda.synchronize
+    for b in batches[:2]:
+        tr.update_fn(b)
+    el, loss = timed_steps(tr, batches[2:], steps, sync)
+    ms = el / steps * 1e3
+    fl = 3.0 * synthetic.step_flops_fwd(F, N) * B
+    tlog(f"{tag}: {ms:.1f} ms/step")
+    res = {"workload": f"{tag}: N_res={N}, {F}-frame windows, {B} windows on one GPU, full update_fn, all frames",
+           "windows": B, "frames": F, "n_res": N, "ms_per_step": round(ms, 3), "value": round(B * F / (el / steps), 2),
+           "unit": "frames/s", "steps": steps, "step_tflop": round(fl / 1e12, 2),
+           "step_mfma_frac": round(fl / (el / steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "loss": round(float(loss), 5)}
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -233,13 +311,24 @@ def main():
     conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
     diffuser = SE3Diffuser(conf.diffuser)
     model = FullScoreNetwork(conf.model, diffuser)
-    model.load_state_dict(synthetic.seeded_state_dict(0), strict=True)     # same weights on every rank
+    # like the reference, every rank initialises from its own seed (train_DFOLD_dynamics.py:419) and the trainer starts
+    # all of them from rank 0's parameters (DDP's start-up broadcast, :615); rank 0 = the seeded benchmark weights
+    model.load_state_dict(synthetic.seeded_state_dict(rank), strict=True)
     model.to(dev)
     # headline: every frame through the conv tower, the work the reference does (SURVEY 8d FLOP model)
     trainer = experiment.Trainer(model, lr=1e-4, last_frame_only=(args.mode == "last_frame"))
-    tlog("model ready")
-    batch = make_batch(synthetic, diffuser, B, F, N, rank, dev)
-    tlog("batch ready")
+    trainer.reducer.timing = world > 1
+    if world > 1:
+        ck = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(hi - lo) != 0.0:
+            raise SystemExit("ranks hold different parameters after the start-up broadcast")
+    tlog("model ready (%.1f MB of parameters broadcast from rank 0)" % (trainer.bytes_broadcast / 1e6))
+    nb = args.warmup + args.steps + 1
+    batches = make_batches(synthetic, diffuser, B, F, N, rank, dev, nb, args.same_batch)
+    tlog("%d batches staged in HBM" % nb)
 
     def sync():
         if world > 1:
@@ -247,21 +336,15 @@ def main():
         torch.cuda.synchronize()
 
     first_loss = None
-    for _ in range(args.warmup):
-        l0, _ = trainer.update_fn(batch)
+    for i in range(args.warmup):
+        l0, _ = trainer.update_fn(batches[i])
         torch.cuda.synchronize()
         first_loss = float(l0) if first_loss is None else first_loss
         tlog("warm-up step done")
-    sync()
-    t0 = time.perf_counter()
-    losses = []
-    for _ in range(args.steps):
-        loss, aux = trainer.update_fn(batch)
-        losses.append(loss)                      # device scalars: no host sync inside the timed region
-    sync()
-    elapsed = time.perf_counter() - t0
+    trainer.reducer.wait_ms.clear()
+    elapsed, loss = timed_steps(trainer, batches[args.warmup:args.warmup + args.steps], args.steps, sync)
     if first_loss is None:
-        first_loss = float(losses[0])
+        first_loss = float(loss)
     tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -269,20 +352,22 @@ def main():
     tlog(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     # the instrumented extra step contains the gradient all-reduce: EVERY rank runs it (a collective issued by rank 0
     # alone would pair with the other ranks' next step and hang the job at the end); rank 0 reports its own timings
-    roof = conv_kernel_roofline(model, trainer, batch, B, F, N) if args.mode == "all_frames" else None
+    roof = conv_kernel_roofline(model, trainer, batches[-1], B, F, N) if args.mode == "all_frames" else None
+    waits = None
+    if world > 1:        # how long each rank's stream sat in finish() waiting for the gradient collectives, per step
+        w = torch.tensor([sum(trainer.reducer.wait_ms) / max(1, len(trainer.reducer.wait_ms))], device=dev, dtype=torch.float64)
+        allw = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(allw, w)
+        waits = [round(float(x), 3) for x in allw]
     # second timed region: the engine's training-step mode (Trainer default).  Loss, gradients and the optimizer update
     # are identical (tests/test_network_gpu.py::test_last_frame_only_training_mode_equals_full); the conv tower only
     # evaluates the dependency cone of the last frame, the one frame the live loss terms and frame updates read.
     el2 = None
     if not args.no_last_frame_mode and args.mode == "all_frames":
         trainer.last_frame_only = True
-        trainer.update_fn(batch)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loss_l, _ = trainer.update_fn(batch)
-        sync()
-        el2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        trainer.update_fn(batches[0])
+        el2, _ = timed_steps(trainer, batches[1:1 + args.steps], args.steps, sync)
+        el2 = torch.tensor([el2], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(el2, op=dist.ReduceOp.MAX)
         el2 = float(el2)
@@ -290,19 +375,22 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * F * args.steps / elapsed
+        step_flop = 3.0 * synthetic.step_flops_fwd(F, N) * B
         tlog("roofline: %s" % json.dumps(roof))
         line = {
             "metric": "trajectory_frames_per_sec_fwd_bwd_nres%d" % N, "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: synthetic N_res=%d, %d-frame windows, %d windows/GPU, full "
-                                   "update_fn (fwd+loss+bwd+grad all-reduce+Adam amsgrad), random-init seeded weights"
-                                   % (N, F, B),
+                                   "update_fn (fwd+loss+bwd+grad all-reduce+Adam amsgrad), random-init seeded weights, %s"
+                                   % (N, F, B, "one batch repeated" if args.same_batch else
+                                      "a fresh synthetic batch every step (staged in HBM before the timed region)"),
                        "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world, "mode": args.mode},
-            # the same batch every step: the loss of the first step taken (warm-up included) and of the last timed step
-            # show the optimizer descending (every forward sees the parameters the previous step wrote)
             "loss": {"first_step": round(first_loss, 5), "last_step": round(float(loss), 5),
                      "steps_between": args.warmup + args.steps - 1},
+            # whole step against the MFMA peak: algorithmic fwd+bwd FLOPs of the step / step time / 2.5 PF
+            "step_tflop_per_gpu": round(step_flop / 1e12, 2),
+            "step_mfma_frac": round(step_flop / (elapsed / args.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
             "roofline": roof,
             "last_frame_mode": None if el2 is None else {
                 "value": round(world * B * F * args.steps / el2, 2), "unit": "frames/s",
@@ -312,10 +400,21 @@ def main():
                         "loss, gradients and parameter update identical to the all-frames step (bit-exact conv results), "
                         "4x fewer conv FLOPs at F=32"},
         }
-        if world == 1 and not args.no_triangle:
+        if waits is not None:
+            line["allreduce_wait_ms"] = waits
+            line["param_broadcast_mb"] = round(trainer.bytes_broadcast / 1e6, 1)
+    del batches
+    if world == 1 and rank == 0:
+        del trainer, model
+        torch.cuda.empty_cache()
+        if not args.no_other_configs and args.mode == "all_frames" and (B, F, N) == (8, 32, 256):
+            line["config2"] = other_config("BASELINE config 2", 4, 32, 128, dev, max(4, args.steps // 2), tlog)
+            line["config5_one_gpu"] = other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog)
+        if not args.no_triangle:
             line["triangle"] = triangle_roofline(dev)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -153,7 +153,10 @@ class InvariantPointAttention(nn.Module):
         self.no_heads, self.no_qk_points, self.no_v_points = ipa_conf.no_heads, ipa_conf.no_qk_points, ipa_conf.no_v_points
         self.inf, self.eps = inf, eps
         if self.no_qk_points != 8 or self.no_v_points != 12 or inf != 1e5:
-            raise ValueError("the HIP attention core is built for no_qk_points=8, no_v_points=12, inf=1e5")
+            raise ValueError("dynamicpdb_amd.InvariantPointAttention supports the configuration of config/train_DFOLDv2.yaml "
+                             "(no_qk_points=8, no_v_points=12, any c_s / c_z / c_hidden / no_heads that are multiples of 8) "
+                             f"with inf=1e5; got no_qk_points={self.no_qk_points}, no_v_points={self.no_v_points}, inf={inf}: "
+                             "the point tables of csrc/ipa_attn.hip are sized for 8 query / 12 value points")
         hc = self.c_hidden * self.no_heads
         self.linear_q = nn.Linear(self.c_s, hc)
         self.linear_kv = nn.Linear(self.c_s, 2 * hc)

@@ -250,7 +250,9 @@ class TriangleMultiplicativeUpdate(nn.Module):
         super().__init__()
         self.c_z, self.c_hidden, self._outgoing = c_z, c_hidden, _outgoing
         if c_z % 8 or c_hidden % 8:
-            raise ValueError("c_z and c_hidden must be multiples of 8")
+            raise ValueError(f"dynamicpdb_amd triangle multiplication needs c_z and c_hidden to be multiples of 8 (got {c_z}, "
+                             f"{c_hidden}); the fused streaming kernels run for c_z = c_hidden = 128 (openfold/config.py:347), "
+                             "other sizes take the unfused chain (N_res a multiple of 8)")
         self.linear_a_p = nn.Linear(c_z, c_hidden)
         self.linear_a_g = nn.Linear(c_z, c_hidden)
         self.linear_b_p = nn.Linear(c_z, c_hidden)
@@ -308,7 +310,8 @@ class TriangleMultiplicativeUpdate(nn.Module):
                 y = _trimul_fused(zs, ms, self._outgoing, pack, self._ws)[0]
             return y.reshape(z.shape)
         if z.shape[-2] % 8:
-            raise ValueError("the unfused triangle path needs N_res % 8 == 0")
+            raise ValueError(f"triangle multiplication with c_z={self.c_z}, c_hidden={self.c_hidden} runs the unfused chain, which "
+                             f"needs N_res % 8 == 0 (got {z.shape[-2]}); c_z = c_hidden = 128 takes any N_res")
         if z.dim() == 3:
             return self._one(z, mask)
         lead = z.shape[:-3]
@@ -545,7 +548,9 @@ class TriangleAttention(nn.Module):
                 y = _triatt_fused(xs, ms, self.starting, self.inf, pack, self._ws)[0]
             return y.reshape(x.shape)
         if x.shape[-2] % 8:
-            raise ValueError("the unfused triangle path needs N_res % 8 == 0")
+            raise ValueError(f"triangle attention with c_in={self.c_in}, c_hidden={self.c_hidden}, no_heads={self.no_heads} runs the "
+                             f"unfused chain, which needs N_res % 8 == 0 (got {x.shape[-2]}); c_in=128, c_hidden=32, no_heads=4 "
+                             "(openfold/config.py:348-350) takes any N_res")
         if not self.starting:
             x, mask = x.transpose(-2, -3), mask.transpose(-1, -2)
         if x.dim() == 3:

@@ -158,6 +158,64 @@ def synthetic_window(seed, F, N, t=0.5, diffuser=None, rigid_cls=None, holes=0.0
     return w
 
 
+def device_batch(rng, diffuser, B, F, N, t=0.5):
+    """A batch of B synthetic windows generated ON THE DEVICE (a few milliseconds: a fresh batch per training step can be
+    staged in HBM ahead of a timed region): same keys, shapes, dtypes and distributions as B stacked `synthetic_window`s
+    (smooth trajectories: rotvec sigma 0.05 rad, translation sigma 0.3 A per frame; 3.8 A random-walk chain), draws from
+    a dynamicpdb_amd.rng.DeviceRNG (Philox, reproducible from its seed), noising by SE3Diffuser.forward_marginal_t7."""
+    dev = rng.device
+    f32 = torch.float32
+    nrm = lambda *shape: rng.normal(shape)
+    q0 = nrm(B, N, 4)
+    q0 = q0 / q0.norm(dim=-1, keepdim=True)
+    steps = nrm(B, N, 3)
+    steps = steps * (3.8 / steps.norm(dim=-1, keepdim=True))
+    x0 = torch.cumsum(steps, 1)
+    x0 = x0 - x0.mean(1, keepdim=True)
+    rv = 0.05 * nrm(B, max(F - 1, 1), N, 3)
+    ang = rv.norm(dim=-1, keepdim=True)
+    dq = torch.cat([torch.cos(ang / 2), torch.sin(ang / 2) * rv / ang.clamp_min(1e-12)], -1)
+    quats = [q0]
+    for f in range(F - 1):
+        a1, b1, c1, d1 = quats[-1].unbind(-1)
+        a2, b2, c2, d2 = dq[:, f].unbind(-1)
+        qn = torch.stack([a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2, a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+                          a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2], -1)
+        quats.append(qn / qn.norm(dim=-1, keepdim=True))
+    drift = 0.3 * nrm(B, max(F - 1, 1), N, 3)
+    trans = torch.cat([x0[:, None], x0[:, None] + torch.cumsum(drift, 1)[:, :F - 1]], 1)
+    rigids_0 = torch.cat([torch.stack(quats, 1), trans], -1).to(f32)
+    angs = (rng.uniform((B, F, N, 7)) * 2 - 1) * math.pi
+    sincos = torch.stack([torch.sin(angs), torch.cos(angs)], -1).to(f32)
+    aatype = (rng.uniform((B, 1, N)) * 20).long().clamp_(0, 19).expand(B, F, N).contiguous()
+    w = dict(
+        aatype=aatype, seq_idx=torch.arange(1, N + 1, dtype=torch.int64, device=dev)[None, None].expand(B, F, N).contiguous(),
+        res_mask=torch.ones(B, F, N, device=dev), fixed_mask=torch.zeros(B, F, N, device=dev),
+        node_repr=nrm(B, N, 256).to(f32), edge_repr=nrm(B, N, N, 128).to(f32), rigids_0=rigids_0,
+        force=nrm(B, F, N, 3).to(f32), vel=nrm(B, F, N, 3).to(f32),
+        torsion_angles_sin_cos=sincos, alt_torsion_angles_sin_cos=-sincos,
+        torsion_angles_mask=torch.ones(B, F, N, 7, device=dev), sc_ca_t=torch.zeros(B, F, N, 3, device=dev),
+        t=torch.full((B,), float(t), dtype=f32, device=dev))
+    fm = diffuser.forward_marginal_t7(rigids_0, torch.full((B,), float(t), dtype=torch.float64), rng=rng)
+    w["rigids_t"] = fm["rigids_t"].to(f32)
+    w["rot_score"], w["trans_score"] = fm["rot_score"], fm["trans_score"]
+    w["rot_score_scaling"] = torch.as_tensor(np.asarray(fm["rot_score_scaling"], np.float64)).reshape(B, 1).to(dev)
+    w["trans_score_scaling"] = torch.as_tensor(np.asarray(fm["trans_score_scaling"], np.float64)).reshape(B, 1).to(dev)
+    return w
+
+
+def step_flops_fwd(F, N):
+    """Algorithmic forward FLOPs of one window (conv: non-padding taps only).  fwd + bwd = 3 x."""
+    T = lambda L: 5 * L - 6
+    P, H, C, PQ, PV = F * N, 8, 256, 8, 12
+    conv = 4 * 8 * 2 * 1280 * 640 * T(F) * T(N)
+    ipa = 4 * (2 * P * 256 * 6816 + 2 * N * N * 128 * 40 + 4 * F * H * N * N * C + 9 * F * N * N * H * PQ
+               + 6 * F * H * N * N * PV + 64 * F * H * N * N + 2 * P * 3072 * 256)
+    angle = 2 * P * (1280 * 1280 * 6 + 1280 * 14)
+    emb = 8 * P * (7 * 256 + 256 * 256) + 2 * P * (20 * 256 + 3 * 256 * 256)
+    return conv + ipa + angle + emb + 48 * P * 1280 + 2 * N * 256 * 256 + 2 * N * N * 128 * 128
+
+
 def default_conf(frame_time, cache_dir=".cache/"):
     """config/train_DFOLDv2.yaml + run_train.sh overrides of the reference, as an
     attribute dict (same tree: data / diffuser / model / experiment)."""

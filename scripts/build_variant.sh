@@ -9,10 +9,12 @@ out=$R/dynamicpdb_amd/csrc/variants
 mkdir -p $out/obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -pragma-unroll-threshold=100000 -mllvm -unroll-threshold=2000"
 objs=""
-for f in $R/dynamicpdb_amd/csrc/*.hip; do
+for f in $R/dynamicpdb_amd/csrc/*.hip; do  # the diagnostic switches live in scripts/variants/<src>_lab.hip (the production sources carry none)
   b=$(basename $f .hip)
   if [ "$b" = "${SRC:-gemm_bf16}" ]; then
-    /opt/rocm/bin/hipcc $FLAGS "$@" -I $R/include -c $f -o $out/obj_$name/$b.o
+    lab=$R/scripts/variants/${b}_lab.hip
+    [ -f $lab ] && f=$lab
+    /opt/rocm/bin/hipcc $FLAGS "$@" -I $R/include -I $R/dynamicpdb_amd/csrc -c $f -o $out/obj_$name/$b.o
     objs="$objs $out/obj_$name/$b.o"
   else
     objs="$objs $R/dynamicpdb_amd/csrc/build/$b.o"

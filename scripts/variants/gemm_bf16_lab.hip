@@ -17,10 +17,23 @@
 // *source* address (the LDS-DMA image is lane-linear) and on the ds_read_b128 side, which makes the
 // fragment reads bank-conflict free; the blockIdx -> tile map is XCD-aware (tiles that share an A row
 // panel sit on one XCD's L2).
-#include "dfold_common.h"
-#include "../../include/dfold_hip.h"
+#include "dfold_common.h"  // (built with -I dynamicpdb_amd/csrc by scripts/build_variant.sh)
+#include "dfold_hip.h"
 #include <stdlib.h>
 
+// Diagnostic builds only (scripts/exp_conv_variants.sh): -DDFOLD_EXP_NOWAIT drops the per-step wait for the LDS-DMA (wrong
+// results; its timing shows how much of the K loop is spent waiting for operand tiles), -DDFOLD_EXP_NOBARRIER drops the
+// per-step barrier as well.
+#if defined(DFOLD_EXP_NOWAIT)
+#define DFOLD_EXP_WAIT do { } while (0)
+#else
+#define DFOLD_EXP_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#if defined(DFOLD_EXP_NOBARRIER)
+#define DFOLD_EXP_BARRIER do { } while (0)
+#else
+#define DFOLD_EXP_BARRIER __builtin_amdgcn_s_barrier()
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -435,6 +448,15 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 // K step moves 72 KiB HBM/L2 -> LDS for 10.5 MFLOP (vs 48 KiB for 4.2): the LDS port stops being the limiter.
 // Two LDS stages (2 x 72 KiB): wait tile s, barrier, launch the LDS-DMA of tile s+1, run 40 MFMAs per wave on tile s.
 // ------------------------------------------------------------------------------------------------
+#ifndef DFOLD_SCHED_A
+#define DFOLD_SCHED_A 0     // placement of the LDS-DMA pieces inside a K step (scripts/exp_conv_variants.py)
+#endif
+#ifndef DFOLD_SCHED_B
+#define DFOLD_SCHED_B 0
+#endif
+#ifndef DFOLD_MMA_ORDER
+#define DFOLD_MMA_ORDER 0   // order of the 2 x NJ MFMAs of a K16 block
+#endif
 #define BM3 256
 #define BN3 320
 #define A3_BYTES (BM3 * BK * 2)
@@ -608,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       h_mid = mid;
       h_next += ((p.a_seg_s1 * 2) & -(long)more) + (ea3 & -(long)mw);
     }
+#if !defined(DFOLD_EXP_NODMA)
     if (!HALO) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -616,6 +639,9 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
 #pragma unroll
     for (int t = 0; t < NJ; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+#else
+    asm volatile("" ::"s"(sa), "s"(sb), "v"(aoff[0]), "v"(boff[0]), "r"(la), "r"(lb));
+#endif
   };
 
   f32x16 acc[2][NJ];
@@ -647,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   };
   auto ldfrag = [&](int set, const char* base, int k4) {
     const int ch = ((k4 * 2 + fhalf) ^ fsw) << 4;
+#if !defined(DFOLD_EXP_NOLDS)
     if (HALO) {
       const int cha = ((k4 * 2 + fhalf) ^ c_sw) << 4;
 #pragma unroll
@@ -657,13 +684,37 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bfr[set][j] = *(const bf16x8*)(base + fb + j * 32 * 128 + ch);
+#else
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(af[set][i]) : "r"(base), "r"(ch));     // fragments stay whatever they were
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(bfr[set][j]));
+#endif
   };
   auto mma = [&](int set) {
+#if DFOLD_MMA_ORDER == 1
+    // A-stationary: one A fragment against the NJ weight fragments, then the other (operand-bus toggling experiment)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+#elif DFOLD_MMA_ORDER == 2
+    // serpentine: every MFMA shares one operand with its predecessor
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = (j & 1) ? 1 - ii : ii;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+      }
+#else
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+#endif
   };
 
   if (HALO) {
@@ -694,8 +745,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
   if (w < 4) {
     // ---- group A (one wave per SIMD): per K step [fragment reads][40 MFMAs], DMA pieces between the MFMAs ----
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      DFOLD_EXP_WAIT;
+      DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
       const char* base = lds3 + bbase + (s & 1) * bstride;
       ldfrag(0, base, 0);
@@ -708,6 +759,50 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       mma(0);
       mma(1);
       if (HALO) halo_step();
+#if DFOLD_SCHED_A == 1
+      // [reads] [all DMA pieces] [2NJ MFMA] [reads] [2NJ MFMA] [reads] [4NJ MFMA]: pieces issued under the read latency
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#elif DFOLD_SCHED_A == 2
+      // pieces inside the last 4NJ MFMAs (no fragment reads around them)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+#pragma unroll
+      for (int g = 0; g < NJ + BLK2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 2 * (NJ + BLK2), 0);
+#elif DFOLD_SCHED_A == 3
+      // pieces spread over the whole step: one per 4 MFMAs while there are any
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+#pragma unroll
+      for (int g = 0; g < NJ + BLK2 - 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 4 * (NJ + BLK2 - 4), 0);
+#else
       // issue order: [2(2+NJ) reads] [NJ x (2 MFMA, 1 DMA)] [2+NJ reads] [BLK2 x (2 MFMA, 1 DMA)] [rest of mma(1)] [2+NJ reads] [4NJ MFMA]
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
 #pragma unroll
@@ -724,6 +819,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#endif
     }
   } else {
     // ---- group B (the second wave of every SIMD) runs HALF A K STEP BEHIND: it enters each step with the fragments of
@@ -742,8 +838,8 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     ldfrag(1, lds3 + bbase, 3);
     if (HALO) halo_step();
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      DFOLD_EXP_WAIT;
+      DFOLD_EXP_BARRIER;
       asm volatile("" ::: "memory");
       const char* base = lds3 + bbase + (s & 1) * bstride;
       stage((s + 1) & 1);
@@ -756,12 +852,25 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
       mma(1);
       ldfrag(1, base, 3);
       if (HALO) halo_step();
+#if DFOLD_SCHED_B == 1
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2, 0);      // all pieces first, then the 4NJ MFMAs of the previous tile
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ, 0);
+#elif DFOLD_SCHED_B == 3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                                     // one piece per 4 MFMAs, the rest later
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, NJ + BLK2 - 4, 0);
+#else
 #pragma unroll
       for (int g = 0; g < BLK2 + NJ; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
       if (2 * NJ - 2 * BLK2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - 2 * BLK2, 0);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NJ), 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);

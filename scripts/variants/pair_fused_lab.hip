@@ -24,12 +24,29 @@
 // [16w, 16w+16) of every 128-wide group as MFMA B fragments: 5 x 4 x 4 = 80 VGPRs), so a tile costs only its own
 // 32 KB of pair-tensor reads; the next tile's rows are prefetched into registers while the current tile's MFMAs
 // run.  Results are staged through LDS and leave as 16-byte vectors (128-byte plane segments / whole channel rows).
-#include "dfold_common.h"
-#include "../../include/dfold_hip.h"
+#include "dfold_common.h"  // (built with -I dynamicpdb_amd/csrc by scripts/build_variant.sh)
+#include "dfold_hip.h"
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+// Diagnostic builds only (scripts/build_variant.sh, timing experiments with wrong results): PF_EXP_NOSTORE drops the global
+// stores of pair_proj_kernel, PF_EXP_NOEPI its sigmoid / gate arithmetic, PF_EXP_NOMFMA its MFMAs.
+#if defined(PF_EXP_NOMFMA)
+#define MFMA16P(a, b, c) (c)
+#else
+#define MFMA16P(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#if defined(PF_EXP_NOEPI)
+#define SIGM_P(x) (x)
+#else
+#define SIGM_P(x) sigm_f(x)
+#endif
+#if defined(PF_EXP_NOSTORE)
+#define PF_STORE(ptr, val) do { if (p.eps < 0.f) *(uint4*)(ptr) = (val); } while (0)
+#else
+#define PF_STORE(ptr, val) *(uint4*)(ptr) = (val)
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 __device__ __forceinline__ float sigm_f(float y) { return __builtin_amdgcn_rcpf(1.f + __expf(-y)); }
@@ -187,14 +204,14 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(pbase + voff_pl[i]) = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
+        PF_STORE(pbase + voff_pl[i], *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16));
       }
       const long cell0 = p.swap ? ((long)b * N + pos0) * N + line : ((long)b * N + line) * N + pos0;
       char* const gbase = (char*)p.o1 + cell0 * 256;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        if (pos0 + cr < N) *(uint4*)(gbase + voff_cl[i]) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
+        if (pos0 + cr < N) PF_STORE(gbase + voff_cl[i], *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16));
       }
     } else {
       const long cell0 = ((long)b * N + line) * N + pos0;
@@ -202,20 +219,20 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
         if (pos0 + cr < N) {
-          *(uint4*)((char*)p.o0 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
-          *(uint4*)((char*)p.o1 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
-          *(uint4*)((char*)p.o3 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
+          PF_STORE((char*)p.o0 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16));
+          PF_STORE((char*)p.o1 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16));
+          PF_STORE((char*)p.o3 + cell0 * 256 + voff_cl[i], *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16));
         }
       }
       char* const vbase = (char*)p.o2 + ((((long)b * N + line) * 128) * NP + pos0) * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(vbase + voff_pl[i]) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
+        PF_STORE(vbase + voff_pl[i], *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16));
       }
       if (tid < 64) {
         const int h = tid >> 4, v = tid & 15;
-        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4);
+        PF_STORE(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4, *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4));
       }
     }
   };
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
 #pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
+        for (int g = 0; g < NG; ++g) acc[g] = MFMA16P(af, wf[g][ks], acc[g]);
       }
       // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
       const int cell0 = rt * 16 + l4 * 4;
@@ -304,9 +321,9 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         float a[4], bb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
-          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
-          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[4][r] + bv[4]));
+          a[r] = (acc[0][r] + bv[0]) * SIGM_P(acc[1][r] + bv[1]) * m[r];
+          bb[r] = (acc[2][r] + bv[2]) * SIGM_P(acc[3][r] + bv[3]) * m[r];
+          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(SIGM_P(acc[4][r] + bv[4]));
         }
         *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]));
         *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(bb[0], bb[1]), pack2bf_hw(bb[2], bb[3]));
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         for (int r = 0; r < 4; ++r) {
           *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[0][r] + bv[0]);
           *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[1][r] + bv[1]);
-          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[3][r] + bv[3]));
+          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(SIGM_P(acc[3][r] + bv[3]));
           vv[r] = acc[2][r] + bv[2];
         }
         *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(vv[0], vv[1]), pack2bf_hw(vv[2], vv[3]));

@@ -26,7 +26,7 @@ def golden_run():
     from dynamicpdb_amd import experiment
     dev = torch.device("cuda:0")
     g = load_golden("network_F3_N16.npz")
-    F, N, seed_w, _ = [int(v) for v in g["meta"]]
+    F, N, seed_w = [int(v) for v in g["meta"][:3]]
     model, _ = _build(F, seed_w, dev)
     w = window_from_golden(g, dev)
     out = model({k: v.clone() for k, v in w.items()})
