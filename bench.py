@@ -160,9 +160,10 @@ def cpu_baseline(F, N, seed_w=0):
     """The oracle (CPU port of the reference path; kind "port" -- the reference itself is not on the GPU box) running the
     reference's update_fn on host cores: zero_grad + forward + loss + backward + Adam(amsgrad) step
     (train_DFOLD_dynamics.py:660-667), ONE window of F frames x N_res = N (the reference has no batch axis: B windows are B
-    sequential calls, so frames/s of one window is the rate).  Bounded sample: two SAME-SHAPE warm-up iterations, one with
-    every usable core and one with half of them (SMT siblings rarely help a GEMM-bound torch CPU run); the faster setting
-    then runs two timed iterations, and the reported rate is their mean."""
+    sequential calls, so frames/s of one window is the rate).  Bounded sample: one SAME-SHAPE warm-up iteration, then two
+    timed iterations whose mean is reported.  Threads = one per physical core: on the MI355X box the 256 usable hardware
+    threads are 128 cores x SMT2, and 256 torch threads were measured 15x SLOWER than 128 on this workload (315.7 s vs
+    21.6 s per iteration, profiles/r3_bench_cpu_threads.txt) -- oversubscribed SMT siblings in the MKLDNN conv."""
     from oracle import dfold_oracle as O
     from dynamicpdb_amd import synthetic
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
@@ -185,21 +186,26 @@ def cpu_baseline(F, N, seed_w=0):
         opt.step()
         return time.time() - t0
 
-    warm = {}
-    for threads in sorted({cores, max(1, cores // 2)}, reverse=True):
-        torch.set_num_threads(threads)
-        warm[threads] = one()
-        print(f"[bench cpu_baseline] warm-up, {F}-frame window, {threads} threads: {warm[threads]:.2f} s", file=sys.stderr, flush=True)
-    threads = min(warm, key=warm.get)
+    smt = 1
+    try:
+        with open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list") as fh:
+            sib = fh.read().strip()
+        smt = max(1, len(sib.replace("-", ",").split(",")))
+    except OSError:
+        pass
+    threads = max(1, cores // smt)
     torch.set_num_threads(threads)
+    warm = {threads: one()}
+    print(f"[bench cpu_baseline] warm-up, {F}-frame window, {threads} threads: {warm[threads]:.2f} s", file=sys.stderr, flush=True)
     timed = [one() for _ in range(2)]
     print(f"[bench cpu_baseline] timed, {threads} threads: {timed[0]:.2f} s, {timed[1]:.2f} s", file=sys.stderr, flush=True)
     t = sum(timed) / len(timed)
     return {"value": round(F / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle update_fn (zero_grad+fwd+loss+bwd+Adam amsgrad), 1 window of {F} frames x N_res={N}: mean of 2 timed "
                       f"iterations ({timed[0]:.2f} s, {timed[1]:.2f} s) after same-shape warm-up iterations at "
-                      + ", ".join(f"{k} threads {v:.2f} s" for k, v in sorted(warm.items())) + f"; {cores} usable cores, "
-                      f"{threads} torch CPU threads used (the faster setting); the bench's windows are 32 frames: the per-frame "
+                      + ", ".join(f"{k} threads {v:.2f} s" for k, v in sorted(warm.items())) + f"; {cores} usable hardware threads = "
+                      f"{threads} physical cores x SMT{smt}, one torch CPU thread per core (all {cores}: measured 15x slower, "
+                      "profiles/r3_bench_cpu_threads.txt); the bench's windows are 32 frames: the per-frame "
                       "conv work T(F)/F grows from 4.25 taps (F=8) to 4.81 (F=32), so this 8-frame rate OVERSTATES the CPU's "
                       "32-frame rate by up to 13 % (conservative for any GPU/CPU ratio)",
             "reference_probe": {"value": 0.43, "unit": "frames/s", "cores": 8, "shape": "1 window, 2 frames x N_res=256, fwd+bwd",

@@ -98,6 +98,17 @@ __device__ __forceinline__ long row_off(const RowMap& r, long m) {
     hipLaunchKernelGGL(__VA_ARGS__); \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit ONCE per process (a driver call: not on the per-launch path).  One static flag per
+// expansion site, i.e. per kernel instantiation named there.
+#define DFOLD_MAX_LDS_ONCE(kernel, bytes)                                                                 \
+  do {                                                                                                    \
+    static bool dfold_attr_done_ = false;                                                                 \
+    if (!dfold_attr_done_) {                                                                              \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+      dfold_attr_done_ = true;                                                                            \
+    }                                                                                                     \
+  } while (0)
+
 static inline int dfold_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DFOLD_OK : DFOLD_ELAUNCH;

@@ -140,7 +140,7 @@ extern "C" int dfold_ipa_softmax_fwd(const float* S, const float* bias, const fl
   else if (N <= 512)
     DFOLD_LAUNCH(ipa_softmax_fwd_kernel<8>, grid, dim3(256), lds, st, S, bias, q_pts, k_pts, mask, hw, P, (bf16_t*)P_bf16, d, bias_scale, inf);
   else {
-    hipFuncSetAttribute((const void*)ipa_softmax_fwd_kernel<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_MAX_LDS_ONCE((ipa_softmax_fwd_kernel<MAXT>), 160 * 1024);
     DFOLD_LAUNCH(ipa_softmax_fwd_kernel<MAXT>, grid, dim3(256), lds, st, S, bias, q_pts, k_pts, mask, hw, P, (bf16_t*)P_bf16, d, bias_scale, inf);
   }
   return dfold_check_launch();
@@ -232,7 +232,7 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
     if (rows < 4) rows = (int)((160 * 1024 - (long)N * (VPS + 1) * 4) / ((long)N * 4));
     if (rows < 1) return DFOLD_EINVAL;
     const size_t lds = ((size_t)N * (VPS + 1) + (size_t)rows * N) * sizeof(float);
-    hipFuncSetAttribute((const void*)ipa_opt_fwd_scalar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DFOLD_MAX_LDS_ONCE((ipa_opt_fwd_scalar_kernel), 160 * 1024);
     DFOLD_LAUNCH(ipa_opt_fwd_scalar_kernel, dim3((N + rows - 1) / rows, H, B * F), dim3(256), lds, (hipStream_t)stream, P, v_pts,
                  o_pt, d, rows);
     return dfold_check_launch();
@@ -247,7 +247,7 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
   if (rows < 2) return DFOLD_EINVAL;
   const size_t lds = (size_t)(table + rows * row_bytes);
   dim3 grid((unsigned)((N + rows - 1) / rows), H, B * F);
-  hipFuncSetAttribute((const void*)ipa_opt_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  DFOLD_MAX_LDS_ONCE((ipa_opt_fwd_kernel), 160 * 1024);
   DFOLD_LAUNCH(ipa_opt_fwd_kernel, grid, dim3(OPT_THREADS), lds, (hipStream_t)stream, P, v_pts, o_pt, d, (int)rows);
   return dfold_check_launch();
 }
@@ -264,14 +264,14 @@ extern "C" int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt
 // 64 KB of LDS -> two workgroups (16 waves) per CU.  (With 64-row workgroups re-staging the tables for every row block,
 // 81 KB of LDS and one workgroup per CU, the row-serial load -> reduce -> store chain ran at 1.4 TB/s.)
 template <int MT>
-__global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __restrict__ P, const float* dP,
+__global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const bf16_t* __restrict__ P, const float* dP,
                                                               const float* __restrict__ q_pts,
                                                               const float* __restrict__ k_pts,
                                                               const float* __restrict__ v_pts,
                                                               const float* __restrict__ do_pt, const float* __restrict__ hw,
                                                               float* dS, bf16_t* __restrict__ dSb,
                                                               float* __restrict__ dq_pts, float* __restrict__ dhw,
-                                                              IpaDims d) {
+                                                              const float* __restrict__ ctr, IpaDims d) {
   // The rows of dS sum to zero (sum_j P_ij (g_ij - sum_j' P_ij' g_ij') = 0), so the q-dependent parts of the point
   // gradients drop out of the per-pair work:
   //   dq_pts[i,c] = -hw sum_j dS_ij (q_ic - k_jc)                      = +hw A_ic,           A_ic = sum_j dS_ij k_jc
@@ -286,9 +286,19 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* kbase = k_pts + ((long)bf * N * H + h) * KP;
   const float* vbase = v_pts + ((long)bf * N * H + h) * VP;
+  // Key points relative to a per-(window, frame) centre (the gradients below are invariant under a common shift of q and
+  // k: they depend on differences, and sum_j dS_ij = 0): |k_j|^2 and q_i . A_i cancel against each other in dhw, and with
+  // coordinates of tens of Angstrom the centred form loses an order of magnitude less to that cancellation.
+  const float c3[3] = {ctr ? ctr[bf * 3] : 0.f, ctr ? ctr[bf * 3 + 1] : 0.f, ctr ? ctr[bf * 3 + 2] : 0.f};
   for (int e = threadIdx.x; e < N * (KP / 4); e += 512) {
     const int j = e / (KP / 4), q = e - j * (KP / 4);
-    *(float4*)(kp + j * KPS + 4 * q) = *(const float4*)(kbase + (long)j * H * KP + 4 * q);
+    float4 v = *(const float4*)(kbase + (long)j * H * KP + 4 * q);
+    // component index 4q + {0,1,2,3}; its axis is (4q + r) % 3 = (q + r) % 3
+    v.x -= c3[q % 3];
+    v.y -= c3[(q + 1) % 3];
+    v.z -= c3[(q + 2) % 3];
+    v.w -= c3[q % 3];
+    *(float4*)(kp + j * KPS + 4 * q) = v;
   }
   for (int e = threadIdx.x; e < N * (VP / 4); e += 512) {
     const int j = e / (VP / 4), q = e - j * (VP / 4);
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
   for (int t = 0; t < MT; ++t) {
     const int j = lane + 64 * t;
     const bool ok = j < N && w < N;
-    pc[t] = ok ? P[base + (long)w * N + j] : 0.f;
+    pc[t] = ok ? bf2f(P[base + (long)w * N + j]) : 0.f;
     dc[t] = ok ? dP[base + (long)w * N + j] : 0.f;
   }
   for (int i = w; i < N; i += 8) {
@@ -323,11 +333,11 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
     for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
       const bool ok = j < N && i + 8 < N;
-      pn[t] = ok ? P[row + 8L * N + j] : 0.f;
+      pn[t] = ok ? bf2f(P[row + 8L * N + j]) : 0.f;
       dn[t] = ok ? dP[row + 8L * N + j] : 0.f;
     }
     float pv[MT], gv[MT];
-    float dot = 0.f;
+    float dot = 0.f, psum = 0.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int j = lane + 64 * t;
@@ -343,11 +353,15 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
         pv[t] = pc[t];
         gv[t] = g;
         dot += pv[t] * g;
+        psum += pv[t];
       }
       pc[t] = pn[t];
       dc[t] = dn[t];
     }
-    dot = wave_sum(dot);
+    // The probabilities are the forward's bf16 copy (what its o / o_pair products consumed); their rows sum to 1 only to
+    // 2^-9, so the row mean of g is taken with respect to THEM (dot / psum): sum_j dS_ij = 0 then holds to fp32 rounding,
+    // which is what the dropped q-dependent terms below rely on (g carries a large common mode, do_pt . v_pts).
+    dot = wave_sum(dot) / wave_sum(psum);
     float ak[KP];            // A_ic partial sums of this lane
     float akn = 0.f;         // sum_j dS_ij |k_j|^2
 #pragma unroll
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < KP; ++c) {
       const float sres = wave_sum(ak[c]);
-      qa += qv[c] * sres;
+      qa += (qv[c] - c3[c % 3]) * sres;
       if (lane == 0) dq_pts[pix * KP + c] = hwh * sres;
     }
     akn = wave_sum(akn);
@@ -383,26 +397,28 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const float* __res
   if (lane == 0 && dhw_acc != 0.f) atomicAdd(dhw + h, dhw_acc);
 }
 
-extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const float* q_pts, const float* k_pts,
+extern "C" int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const float* q_pts, const float* k_pts,
                                      const float* v_pts, const float* do_pt, const float* hw, float* dS, void* dS_bf16,
-                                     float* dq_pts, float* dhw, int32_t B, int32_t F, int32_t N, int32_t H, void* stream) {
-  if (!P || !dP || !q_pts || !k_pts || !v_pts || !do_pt || !hw || !dS || !dS_bf16 || !dq_pts || !dhw) return DFOLD_EINVAL;
+                                     float* dq_pts, float* dhw, const float* ctr, int32_t B, int32_t F, int32_t N, int32_t H,
+                                     void* stream) {
+  if (!P_bf16 || !dP || !q_pts || !k_pts || !v_pts || !do_pt || !hw || !dS || !dS_bf16 || !dq_pts || !dhw) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
+  const bf16_t* P = (const bf16_t*)P_bf16;
   const size_t lds = (size_t)N * (KPS + VPS) * sizeof(float);
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid(1, H, B * F);
   hipStream_t st = (hipStream_t)stream;
   bf16_t* dsb = (bf16_t*)dS_bf16;
   if (N <= 256) {
-    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<4>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+    DFOLD_MAX_LDS_ONCE((ipa_softmax_bwd_kernel<4>), 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<4>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, ctr, d);
   } else if (N <= 512) {
-    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<8>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+    DFOLD_MAX_LDS_ONCE((ipa_softmax_bwd_kernel<8>), 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<8>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, ctr, d);
   } else {
-    hipFuncSetAttribute((const void*)ipa_softmax_bwd_kernel<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<MAXT>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, d);
+    DFOLD_MAX_LDS_ONCE((ipa_softmax_bwd_kernel<MAXT>), 160 * 1024);
+    DFOLD_LAUNCH(ipa_softmax_bwd_kernel<MAXT>, grid, dim3(512), lds, st, P, dP, q_pts, k_pts, v_pts, do_pt, hw, dS, dsb, dq_pts, dhw, ctr, d);
   }
   return dfold_check_launch();
 }
@@ -411,7 +427,7 @@ extern "C" int dfold_ipa_softmax_bwd(const float* P, const float* dP, const floa
 // Backward, column pass.  Per key/value residue (b,f,h,j), lane <-> j, loop over rows i:
 //   dk_pts[j,c] = hw (sum_i dS_ij q_ic - k_jc sum_i dS_ij);    dv_pts[j,c] = sum_i P_ij do_pt[i,c]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dS,
+__global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dS,
                                                           const float* __restrict__ q_pts, const float* __restrict__ k_pts,
                                                           const float* __restrict__ do_pt, const float* __restrict__ hw,
                                                           float* __restrict__ dk_pts, float* __restrict__ dv_pts, IpaDims d) {
@@ -430,17 +446,46 @@ __global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restric
 #pragma unroll
   for (int c = 0; c < VP; ++c) av[c] = 0.f;
   const long base = ((long)bf * H + h) * N * N + (ok ? j : 0);
-#pragma unroll 4
-  for (int i = 0; i < N; ++i) {
-    const float ds = dS[base + (long)i * N];
-    const float p = P[base + (long)i * N];
-    const float* qi = qbase + (long)i * H * KP;
-    const float* di = dbase + (long)i * H * VP;
-    cs += ds;
+  // The two per-row loads of a lane (dS, P of its key in row i) are requested CU rows ahead: the loop is a chain of
+  // dependent FMAs on wave-uniform q / do_pt vectors, and with the loads issued inside the row that consumes them every
+  // row paid a full memory round trip (1.0 ms per launch at config 3; the fp32-P form before it 0.54 ms).
+  constexpr int CU = 8;
+  float dsn[CU];
+  bf16_t pn[CU];            // raw bits: converted where they are consumed, so that nothing waits on the loads here
 #pragma unroll
-    for (int c = 0; c < KP; ++c) aq[c] += ds * qi[c];
+  for (int u = 0; u < CU; ++u) {
+    const long r = u < N ? u : N - 1;                // branch-free: rows past the end re-read the last row (never used)
+    dsn[u] = dS[base + r * N];
+    pn[u] = P[base + r * N];
+  }
+  for (int i0 = 0; i0 < N; i0 += CU) {
+    float dsc[CU], pc[CU];
 #pragma unroll
-    for (int c = 0; c < VP; ++c) av[c] += p * di[c];
+    for (int u = 0; u < CU; ++u) {
+      dsc[u] = dsn[u];
+      pc[u] = bf2f(pn[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int i = i0 + CU + u;
+      const long r = i < N ? i : N - 1;
+      dsn[u] = dS[base + r * N];
+      pn[u] = P[base + r * N];
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int i = i0 + u;
+      if (i < N) {                                   // wave-uniform
+        const float ds = dsc[u], p = pc[u];
+        const float* qi = qbase + (long)i * H * KP;
+        const float* di = dbase + (long)i * H * VP;
+        cs += ds;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) aq[c] += ds * qi[c];
+#pragma unroll
+        for (int c = 0; c < VP; ++c) av[c] += p * di[c];
+      }
+    }
   }
   if (!ok) return;
   const float hwh = hw[h];
@@ -451,12 +496,13 @@ __global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const float* __restric
   for (int c = 0; c < VP; ++c) dv_pts[pix * VP + c] = av[c];
 }
 
-extern "C" int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
+extern "C" int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
                                  const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,
                                  void* stream) {
-  if (!P || !dS || !q_pts || !k_pts || !do_pt || !hw || !dk_pts || !dv_pts) return DFOLD_EINVAL;
+  if (!P_bf16 || !dS || !q_pts || !k_pts || !do_pt || !hw || !dk_pts || !dv_pts) return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
+  const bf16_t* P = (const bf16_t*)P_bf16;
   dim3 grid((N + 255) / 256, H, B * F);
   DFOLD_LAUNCH(ipa_col_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
                      dv_pts, d);

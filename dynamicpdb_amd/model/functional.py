@@ -2,6 +2,7 @@
 libdfold_hip.so (bf16 MFMA contraction engine + fused HIP kernels); torch only chains the nodes and owns
 the device buffers.  Activations crossing nodes are bf16, geometry (frames, points, scores) fp32."""
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -296,6 +297,28 @@ def _zT(z2d):
     return c
 
 
+_IPA_FUSED = os.environ.get("DFOLD_IPA_FUSED", "1") != "0"     # A/B switch: "0" = the unfused round-2 chain
+_IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
+_IPA_WS = {}
+
+
+def _ipa_workspace(dev):
+    ws = _IPA_WS.get(dev)
+    if ws is None:
+        ws = _IPA_WS[dev] = ops.Workspace(dev)
+    return ws
+
+
+def _ipa_centre(k_pts):
+    """[B*F, 3]: mean key point of every (window, frame), snapped to a 1/8 A grid (any centre is valid)"""
+    BF = k_pts.shape[0] * k_pts.shape[1]
+    return (torch.round(k_pts.reshape(BF, -1, 3).double().mean(1) * 8) / 8).float().contiguous()
+
+
+def _ipa_fused_ok(N, C, q_pts, v_pts):
+    return _IPA_FUSED and N % 8 == 0 and N <= 512 and C == 256 and q_pts.shape[-2] == 8 and v_pts.shape[-2] == 12
+
+
 class IpaCoreFn(Function):
     """Attention core of InvariantPointAttention.forward (src/model/ipa_pytorch_dynamic.py:396-502).
       q [B,F,N,H*C] bf16, kv [B,F,N,H*2C] bf16 (k | v per head), q_pts/k_pts [B,F,N,H,8,3], v_pts [B,F,N,H,12,3]
@@ -327,36 +350,60 @@ class IpaCoreFn(Function):
              sb=(NN * CZ, N * CZ), sc=(N * PZ * N, PZ * N))
         pz = torch.empty((B, N, N, PZ), dtype=BF16, device=dev)
         gemm(z, wdz, pz, B * NN, PZ, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(PZ), ldb=CZ)
-        # logits: S = sqrt(1/(3C)) q k^T  (:402-406)
-        P = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
-        gemm(q, kv, P, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=2 * HC, nbatch=B * F * H, nb1=H,
-             sa=(N * HC, C), sb=(N * 2 * HC, 2 * C), sc=(H * NN, NN), alpha=math.sqrt(1.0 / (3 * C)))
         Pb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
-        check(L.dfold_ipa_softmax_fwd(_p(P), _p(bias_t), _p(q_pts), _p(k_pts), _p(mask), _p(hwc), _p(P), _p(Pb),
-                                      c_int32(B), c_int32(F), c_int32(N), c_int32(H), ctypes_float(math.sqrt(1.0 / 3)),
-                                      ctypes_float(1e5), stream()), "dfold_ipa_softmax_fwd")
-        # o = P v  (:452-457)
-        vT = ops.transpose_bf16(kv, N, C, ld_src=2 * HC, nbatch=B * F * H, nb1=H, bs_src=(N * 2 * HC, 2 * C), src_off=C)
         o = torch.empty((B, F, N, HC), dtype=BF16, device=dev)
-        gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=B * F * H, nb1=H,
-             sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C))
-        # o_pt (fp32 VALU) (:460-469)
         o_pt = torch.empty((B, F, N, H, 12, 3), dtype=torch.float32, device=dev)
-        check(L.dfold_ipa_opt_fwd(_p(P), _p(v_pts), _p(o_pt), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
-              "dfold_ipa_opt_fwd")
+        alpha = math.sqrt(1.0 / (3 * C))
+        if _ipa_fused_ok(N, C, q_pts, v_pts):
+            # one launch for logits + softmax + o + o_pt (csrc/ipa_fused.hip): the point terms ride on the matrix cores as
+            # bf16-split extra columns of the two attention products, no [B,F,H,N,N] fp32 logits in HBM
+            P = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev) if _IPA_KEEP_P32 else None
+            NPv = (N + 63) // 64 * 64
+            ws = _ipa_workspace(dev)
+            QP = ws.get("QP/%d" % N, (B * F, H, N, 160))
+            KP = ws.get("KP/%d" % N, (B * F, H, N, 160))
+            kn = ws.get("kn/%d" % N, (B * F, H, N), torch.float32)
+            VT = ws.get("VT/%d" % N, (B * F, H, 400, NPv))       # zero-filled once: pad rows / columns are never written
+            # any per-(window, frame) centre will do: the mean key point, snapped to a 1/8 A grid so that its value (and with it
+            # every rounding downstream) does not depend on how the reduction was tiled for this batch shape
+            ctr = _ipa_centre(k_pts)
+            check(L.dfold_ipa_aug_prep(_p(q_pts), _p(k_pts), _p(v_pts), _p(hwc), _p(ctr), _p(QP), _p(KP), _p(kn), _p(VT),
+                                       c_int32(B), c_int32(F), c_int32(N), c_int32(H), c_int32(NPv), ctypes_float(alpha),
+                                       stream()), "dfold_ipa_aug_prep")
+            ops.transpose_bf16(kv, N, C, ld_src=2 * HC, out=VT, nbatch=B * F * H, nb1=H, bs_src=(N * 2 * HC, 2 * C), src_off=C,
+                               bs_dst=(H * 400 * NPv, 400 * NPv), ld_dst=NPv)                      # rows 0..255 = v^T
+            check(L.dfold_ipa_fused_fwd(_p(q), _p(kv), _p(QP), _p(KP), _p(VT), _p(kn), _p(bias_t), _p(mask), _p(ctr), _p(o),
+                                        _p(o_pt), _p(Pb), _p(P), c_int32(B), c_int32(F), c_int32(N), c_int32(H), c_int32(NPv),
+                                        ctypes_float(alpha), ctypes_float(math.sqrt(1.0 / 3)), ctypes_float(1e5), stream()),
+                  "dfold_ipa_fused_fwd")
+        else:
+            # unfused chain (N_res > 512): logits S = sqrt(1/(3C)) q k^T (:402-406) on the GEMM engine, row softmax with the
+            # fp32 point distances, o = P v, o_pt on the VALU
+            P = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
+            gemm(q, kv, P, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=2 * HC, nbatch=B * F * H, nb1=H,
+                 sa=(N * HC, C), sb=(N * 2 * HC, 2 * C), sc=(H * NN, NN), alpha=alpha)
+            check(L.dfold_ipa_softmax_fwd(_p(P), _p(bias_t), _p(q_pts), _p(k_pts), _p(mask), _p(hwc), _p(P), _p(Pb),
+                                          c_int32(B), c_int32(F), c_int32(N), c_int32(H), ctypes_float(math.sqrt(1.0 / 3)),
+                                          ctypes_float(1e5), stream()), "dfold_ipa_softmax_fwd")
+            vT = ops.transpose_bf16(kv, N, C, ld_src=2 * HC, nbatch=B * F * H, nb1=H, bs_src=(N * 2 * HC, 2 * C), src_off=C)
+            gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=B * F * H, nb1=H,
+                 sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C))
+            check(L.dfold_ipa_opt_fwd(_p(P), _p(v_pts), _p(o_pt), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
+                  "dfold_ipa_opt_fwd")
         # o_pair[b,f,i,h,:] = sum_j P[b,f,h,i,j] pz[b,i,j,:] + b_dz   (:498-502): per (b,i) a [F*H, N] x [N, PZ] product
         o_pair = torch.empty((B, F, N, H * PZ), dtype=BF16, device=dev)
         gemm(Pb, pzT, o_pair, F * H, PZ, N, a_rows=rows_plain(NN), c_rows=rows_grid(PZ, H, F, F, N * H), ldb=N,
              bias=b_dz.detach(), nbatch=B * N, nb1=N, sa=(F * H * NN, N), sb=(N * PZ * N, PZ * N),
              sc=(F * N * H * PZ, H * PZ))
-        ctx.save_for_backward(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, P, Pb, pz)
+        del P            # the backward reads the bf16 probabilities (what the forward products consumed)
+        ctx.save_for_backward(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, Pb, pz)
         ctx.dims = (B, F, N, H, C, CZ, PZ)
         return o, o_pt, o_pair
 
     @staticmethod
     def backward(ctx, do, do_pt, do_pair):
         L = _lib.lib()
-        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, P, Pb, pz = ctx.saved_tensors
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
         B, F, N, H, C, CZ, PZ = ctx.dims
         HC, NN, dev = H * C, N * N, q.device
         alpha = math.sqrt(1.0 / (3 * C))
@@ -373,11 +420,12 @@ class IpaCoreFn(Function):
         dk_pts = torch.empty_like(k_pts)
         dv_pts = torch.empty_like(v_pts)
         dhw = torch.zeros(H, dtype=torch.float32, device=dev)
-        check(L.dfold_ipa_softmax_bwd(_p(P), _p(dP), _p(q_pts), _p(k_pts), _p(v_pts), _p(do_pt), _p(hw), _p(dP), _p(dSb),
-                                      _p(dq_pts), _p(dhw), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
+        check(L.dfold_ipa_softmax_bwd(_p(Pb), _p(dP), _p(q_pts), _p(k_pts), _p(v_pts), _p(do_pt), _p(hw), _p(dP), _p(dSb),
+                                      _p(dq_pts), _p(dhw), _p(_ipa_centre(k_pts)), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                      stream()),
               "dfold_ipa_softmax_bwd")
         dS = dP
-        check(L.dfold_ipa_col_bwd(_p(P), _p(dS), _p(q_pts), _p(k_pts), _p(do_pt), _p(hw), _p(dk_pts), _p(dv_pts),
+        check(L.dfold_ipa_col_bwd(_p(Pb), _p(dS), _p(q_pts), _p(k_pts), _p(do_pt), _p(hw), _p(dk_pts), _p(dv_pts),
                                   c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()), "dfold_ipa_col_bwd")
         nb = B * F * H
         # dq = alpha dS k

@@ -157,17 +157,37 @@ int dfold_ipa_softmax_fwd(const float* S, const float* bias, const float* q_pts,
 /* o_pt[b,f,i,h,:] = sum_j P[b,f,h,i,j] v_pts[b,f,j,h,:]  (:460-469) */
 int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt, int32_t B, int32_t F, int32_t N, int32_t H,
                       void* stream);
-/* row pass of the backward: dS, dq_pts, dhw (dhw accumulated atomically: zero it first) */
-int dfold_ipa_softmax_bwd(const float* P, const float* dP, const float* q_pts, const float* k_pts, const float* v_pts,
+/* row pass of the backward: dS, dq_pts, dhw (dhw accumulated atomically: zero it first).  P_bf16: the forward's bf16
+ * probabilities [B,F,H,N,N] (renormalised per row inside, so that the rows of dS sum to zero); ctr [B,F,3] or NULL: a
+ * per-(window, frame) centre the points are taken relative to (the result is invariant; the fp32 cancellation in dhw is not) */
+int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const float* q_pts, const float* k_pts, const float* v_pts,
                           const float* do_pt, const float* hw, float* dS, void* dS_bf16, float* dq_pts, float* dhw,
-                          int32_t B, int32_t F, int32_t N, int32_t H, void* stream);
-/* column pass of the backward: dk_pts, dv_pts */
-int dfold_ipa_col_bwd(const float* P, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
+                          const float* ctr, int32_t B, int32_t F, int32_t N, int32_t H, void* stream);
+/* column pass of the backward: dk_pts, dv_pts (P_bf16 as above) */
+int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
                       const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,
                       void* stream);
 /* dbias = scale * sum_f dS, bf16, as [B][H][N*N] and as [B][N*N][8] (H zero-padded to 8) */
 int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, int32_t F, int32_t N, int32_t H,
                         float scale, void* stream);
+
+/* Fused forward of the attention core (src/model/ipa_pytorch_dynamic.py:402-469: logits, softmax, o = a v, o_pt = a v_pts)
+ * for one launch per IPA block: csrc/ipa_fused.hip.  N % 8 == 0, N <= 512, 8 query / 12 value points, 256 channels per head.
+ * dfold_ipa_aug_prep builds the augmented MFMA operands from the global-frame points (ctr [B,F,3]: any per-(window, frame)
+ * centre, e.g. the mean key point): QP, KP bf16 [B,F,H,N,160] (three-piece bf16 splits of the 24 point coordinates laid out as
+ * the six products hh, hm, mh, hl, lh, mm; QP pre-scaled by hw / alpha), kn fp32 [B,F,H,N] = -hw/2 |k_pts - ctr|^2, and rows
+ * 256..399 of VT bf16 [B,F,H,400,NP] (three pieces x 48 rows of v_pts - ctr, key-contiguous; rows 0..255 = v^T are the
+ * caller's, e.g. dfold_transpose_bf16; NP % 64 == 0, pad columns zero).
+ * dfold_ipa_fused_fwd: q [B,F,N,H*256], kv [B,F,N,H*512] (k | v per head) bf16; bias fp32 [B,H,N,N] (linear_b(z), :396);
+ * mask [B,F,N] -> o bf16 [B,F,N,H*256], o_pt fp32 [B,F,N,H,12,3] (global frame), P bf16 [B,F,H,N,N] and, if P_f32 != NULL,
+ * the same probabilities in fp32. */
+int dfold_ipa_aug_prep(const float* q_pts, const float* k_pts, const float* v_pts, const float* hw, const float* ctr,
+                       void* QP_bf16, void* KP_bf16, float* kn, void* VT_bf16, int32_t B, int32_t F, int32_t N, int32_t H,
+                       int32_t NP, float alpha, void* stream);
+int dfold_ipa_fused_fwd(const void* q_bf16, const void* kv_bf16, const void* QP_bf16, const void* KP_bf16, const void* VT_bf16,
+                        const float* kn, const float* bias, const float* mask, const float* ctr, void* o_bf16, float* o_pt,
+                        void* P_bf16, float* P_f32, int32_t B, int32_t F, int32_t N, int32_t H, int32_t NP, float alpha,
+                        float bias_scale, float inf, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Triangle pair operators (openfold/model/triangular_multiplicative_update.py:26-126 TriangleMultiplication

@@ -42,7 +42,7 @@ DIFFUSER_KEYS = ("rigids_t", "rot_score", "trans_score", "rot_score_scaling", "t
 
 
 def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_stride=9973, compact=False, holes=0.0,
-                   tag=""):
+                   tag="", no_torsion_grads=False):
     """compact=True (BASELINE-sized captures): only the diffuser-dependent inputs are stored; every other input is
     regenerated bit-identically on the test side from dynamicpdb_amd.synthetic.synthetic_window(seed_x, F, N, t) and
     pinned by a float64 checksum."""
@@ -108,6 +108,26 @@ def golden_network(F=3, N=16, seed_w=0, seed_x=1, t=0.5, captures=True, grad_str
         g = p.grad
         fix[f"gnorm_{name}"] = np_(g.double().norm())
         fix[f"gsub_{name}"] = np_(subsample(g, grad_stride) if g.numel() > 70000 else g)
+    if no_torsion_grads:
+        # second reference run with experiment.torsion_loss_weight = 0 (the reference's own knob, train:1220): the torsion
+        # term normalises the raw 2-vectors (openfold/utils/loss.py:58-59), its gradient ~ 1/|raw| is dominated by the few
+        # torsions with a short raw vector, and at 1792 torsions (N_res 256) that alone moves whole gradient tensors by
+        # tens of per cent under ANY change of rounding; the frame terms (translation x0, rotation score) are well
+        # conditioned, so their gradients can be compared raw
+        exp._exp_conf.torsion_loss_weight = 0.0
+        random.seed(0)
+        model.zero_grad()
+        loss0, aux0 = exp.loss_fn({k: v.clone() for k, v in win.items()})
+        loss0.backward()
+        fix["loss_notorsion"] = np_(loss0)
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad
+            fix[f"g0norm_{name}"] = np_(g.double().norm())
+            fix[f"g0sub_{name}"] = np_(subsample(g, grad_stride) if g.numel() > 70000 else g)
+        exp._exp_conf.torsion_loss_weight = 1.0
+        print("   torsion-free loss", float(loss0))
     fix["meta"] = np.array([F, N, seed_w, seed_x, grad_stride], np.int64)
     fix["t"] = np.array([t])
     fix["holes"] = np.array([holes])
@@ -416,24 +436,29 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_cfg1":
         # BASELINE config 1 shape: one window of 16 frames x N_res 96 (the reference's CPU-runnable configuration)
-        golden_network(F=16, N=96, seed_w=11, seed_x=12, t=0.4, captures=False, grad_stride=39989, compact=True)
+        golden_network(F=16, N=96, seed_w=11, seed_x=12, t=0.4, captures=False, grad_stride=39989, compact=True,
+                       no_torsion_grads=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_n256":
         # run_train.sh window (frame_time = 2) at the headline N_res = 256
-        golden_network(F=2, N=256, seed_w=13, seed_x=14, t=0.6, captures=False, grad_stride=39989, compact=True)
+        golden_network(F=2, N=256, seed_w=13, seed_x=14, t=0.6, captures=False, grad_stride=39989, compact=True,
+                       no_torsion_grads=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_cfg3":
         # BASELINE config 3 / 4: one 32-frame window at N_res 256 (the shape bench.py times, B = 8 independent windows)
-        golden_network(F=32, N=256, seed_w=21, seed_x=22, t=0.45, captures=False, grad_stride=39989, compact=True)
+        golden_network(F=32, N=256, seed_w=21, seed_x=22, t=0.45, captures=False, grad_stride=39989, compact=True,
+                       no_torsion_grads=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_cfg2":
         # BASELINE config 2: one 32-frame window at N_res 128
-        golden_network(F=32, N=128, seed_w=23, seed_x=24, t=0.35, captures=False, grad_stride=39989, compact=True)
+        golden_network(F=32, N=128, seed_w=23, seed_x=24, t=0.35, captures=False, grad_stride=39989, compact=True,
+                       no_torsion_grads=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_cfg5":
         # BASELINE config 5 is 64 frames x N_res 512: the reference cannot hold its IPA intermediates;
         # 8 frames at N_res 512 is what it can run
-        golden_network(F=8, N=512, seed_w=25, seed_x=26, t=0.55, captures=False, grad_stride=39989, compact=True)
+        golden_network(F=8, N=512, seed_w=25, seed_x=26, t=0.55, captures=False, grad_stride=39989, compact=True,
+                       no_torsion_grads=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "network_holes":
         # res_mask with holes (10 % dead residues + both chain ends dead): masks of IPA, frame update, score heads,

@@ -302,3 +302,49 @@ def test_compose_q_update_vec_node():
     assert max_abs(u.grad, ur.grad) < 2e-5 * max(1.0, float(ur.grad.abs().max()))
     out2 = Fm.compose_q_update_vec(a.detach(), u.detach(), None)          # no mask = all frames move
     assert max_abs(out2, G.compose_q_update_vec(t7.double(), upd.double(), torch.ones(B, F, N, 1, dtype=torch.float64))) < 1e-5
+
+
+@pytest.mark.parametrize("B,F,N", [(1, 2, 256), (2, 1, 40), (1, 1, 512)])
+def test_ipa_fused_forward_protein_scale_coordinates(B, F, N):
+    """The fused attention forward (csrc/ipa_fused.hip) with points of protein scale -- a 3.8 A random-walk chain, i.e.
+    global-frame coordinates of tens of Angstrom whose DIFFERENCES of a few Angstrom decide the logits -- against the fp64
+    formulas of src/model/ipa_pytorch_dynamic.py:402-469 and against the unfused chain (fp32 VALU distances): the bf16-split
+    point columns of the two MFMA products must carry fp32-grade accuracy (o_pt within 2e-3 A absolute, the probabilities
+    within the bf16 class), masked keys get exactly zero weight, both workgroup shapes (N_res <= 256: 8 waves, <= 512: 4)."""
+    from dynamicpdb_amd.model import functional as Fm
+    dev = torch.device("cuda:0")
+    H, C, CZ, PZ = 8, 256, 128, 32
+    gen = torch.Generator(device="cpu").manual_seed(100 + N)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=gen) * scale).to(dev)
+    q = rn(B, F, N, H * C).to(torch.bfloat16)
+    kv = rn(B, F, N, 2 * H * C).to(torch.bfloat16)
+    steps = torch.randn(B, F, N, 3, generator=gen)
+    steps = 3.8 * steps / steps.norm(dim=-1, keepdim=True)
+    chain = (torch.cumsum(steps, 2) + torch.tensor([40.0, -25.0, 10.0])).to(dev)[:, :, :, None, None, :]   # off-centre
+    q_pts, k_pts, v_pts = chain + rn(B, F, N, H, 8, 3, scale=2.0), chain + rn(B, F, N, H, 8, 3, scale=2.0), chain + rn(B, F, N, H, 12, 3, scale=2.0)
+    z = rn(B, N, N, CZ).to(torch.bfloat16)
+    w_b, w_dz, b_dz = rn(H, CZ, scale=0.1), rn(PZ, CZ, scale=0.1), rn(PZ, scale=0.1)
+    mask = torch.ones(B, F, N, device=dev)
+    mask[0, 0, N - 5:] = 0
+    mask[0, 0, 3] = 0
+    hw = (0.05 + 0.02 * torch.rand(H, generator=gen)).to(dev)
+    args = (q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw)
+    old = Fm._IPA_FUSED
+    try:
+        Fm._IPA_FUSED = True
+        with torch.no_grad():
+            o, o_pt, o_pair = Fm.IpaCoreFn.apply(*args)
+        Fm._IPA_FUSED = False
+        with torch.no_grad():
+            o_u, o_pt_u, o_pair_u = Fm.IpaCoreFn.apply(*args)
+    finally:
+        Fm._IPA_FUSED = old
+    d = [t.double() for t in (q, kv, q_pts, k_pts, v_pts, z)]
+    ro, ropt, ropair = _ref_core(*d, w_b.to(torch.bfloat16).double(), w_dz.to(torch.bfloat16).double(), b_dz.double(), mask.double(),
+                                 hw.double(), H, C)
+    e_pt, e_pt_u = float((o_pt.double() - ropt).abs().max()), float((o_pt_u.double() - ropt).abs().max())
+    print(f"[fused IPA N={N}] o rel {rel_l2(o, ro):.2e} (unfused {rel_l2(o_u, ro):.2e}), o_pt max abs {e_pt:.2e} A (unfused {e_pt_u:.2e}), "
+          f"o_pair rel {rel_l2(o_pair, ropair):.2e} (unfused {rel_l2(o_pair_u, ropair):.2e})")
+    assert rel_l2(o, ro) < 6e-3 and rel_l2(o_pair, ropair) < 1e-2
+    assert e_pt < (2e-3 if N <= 256 else 5e-3), e_pt       # logit rounding ~ eps * hw * R^2 grows with the chain radius R
+    assert torch.isfinite(o.float()).all() and torch.isfinite(o_pt).all()
