@@ -63,33 +63,45 @@ def _linear_grads(x2d, g2d):
 # triangle multiplicative update
 # ------------------------------------------------------------------------------------------------
 
-def _to_planes(ab, N, outgoing):
-    """ab bf16 [N*N][C2] -> planes bf16 [C2][N][N] with plane[c][i][k] = ab[(i,k)][c] (outgoing) or ab[(k,i)][c]."""
+def _to_planes(ab, B, N, outgoing):
+    """ab bf16 [B*N*N][C2] -> planes bf16 [B][C2][N][N] with plane[b][c][i][k] = ab[(b,i,k)][c] (outgoing) or ab[(b,k,i)][c]."""
     R, C2 = ab.shape
+    NN = N * N
     if outgoing:
-        return ops.transpose_bf16(ab, R, C2)
-    out = torch.empty((C2, R), dtype=BF16, device=ab.device)
-    return ops.transpose_bf16(ab, N, C2, ld_src=N * C2, out=out, nbatch=N, nb1=1, bs_src=(C2, 0), bs_dst=(N, 0), ld_dst=R)
+        return ops.transpose_bf16(ab, NN, C2, nbatch=B, nb1=1, bs_src=(NN * C2, 0)).view(B, C2, N, N) if B > 1 else \
+            ops.transpose_bf16(ab, NN, C2).view(1, C2, N, N)
+    out = torch.empty((B, C2, N, N), dtype=BF16, device=ab.device)
+    # batch z = (b, i): source rows k of column block i (row stride N*C2), destination plane row i
+    return ops.transpose_bf16(ab, N, C2, ld_src=N * C2, out=out, nbatch=B * N, nb1=N, bs_src=(NN * C2, C2),
+                              bs_dst=(C2 * NN, N), ld_dst=NN)
 
 
-def _from_planes(planes, N, outgoing):
-    C2, R = planes.shape
+def _from_planes(planes, B, N, outgoing):
+    """inverse of _to_planes: planes bf16 [B][C2][N][N] -> [B*N*N][C2]"""
+    C2 = planes.shape[1]
+    NN = N * N
     if outgoing:
-        return ops.transpose_bf16(planes, C2, R)
-    out = torch.empty((R, C2), dtype=BF16, device=planes.device)
-    return ops.transpose_bf16(planes, C2, N, ld_src=R, out=out, nbatch=N, nb1=1, bs_src=(N, 0), bs_dst=(C2, 0), ld_dst=N * C2)
+        return ops.transpose_bf16(planes, C2, NN, nbatch=B, nb1=1, bs_src=(C2 * NN, 0)).view(B * NN, C2) if B > 1 else \
+            ops.transpose_bf16(planes.view(C2, NN), C2, NN)
+    out = torch.empty((B * NN, C2), dtype=BF16, device=planes.device)
+    return ops.transpose_bf16(planes, C2, N, ld_src=NN, out=out, nbatch=B * N, nb1=N, bs_src=(C2 * NN, N),
+                              bs_dst=(NN * C2, C2), ld_dst=N * C2)
 
 
 class TriangleMultiplicationFn(Function):
-    """z fp32 [N,N,c_z], mask fp32 [N,N] -> fp32 [N,N,c_z]   (AF2 Alg. 11 / 12)"""
+    """z fp32 [N,N,c_z] or [B,N,N,c_z], mask fp32 [N,N] / [B,N,N] -> same shape as z   (AF2 Alg. 11 / 12).  The chain that
+    keeps its intermediates: row kernels on the flattened [B*N*N, .] cell matrix, the ik,jk->ij contraction and its two
+    transposed products batched over (batch item, channel) on the MFMA engine.  N % 8 == 0."""
 
     @staticmethod
     def forward(ctx, z, mask, outgoing, g_in, b_in, w_ap, b_ap, w_ag, b_ag, w_bp, b_bp, w_bg, b_bg, w_g, b_g, w_z, b_z,
                 g_out, b_out):
         L = _lib.lib()
-        N, cz = z.shape[0], z.shape[-1]
+        B = z.shape[0] if z.dim() == 4 else 1
+        N, cz = z.shape[-2], z.shape[-1]
         c = w_ap.shape[0]
-        R = N * N
+        NN = N * N
+        R = B * NN
         dev = z.device
         zf = z.reshape(R, cz).contiguous().float()
         maskf = mask.reshape(R).contiguous().float()
@@ -101,11 +113,11 @@ class TriangleMultiplicationFn(Function):
         gemm(zn, wcat, proj, R, P5, cz, a_rows=rows_plain(cz), c_rows=rows_plain(P5), ldb=cz, bias=bcat)
         ab = torch.empty((R, 2 * c), dtype=BF16, device=dev)
         check(L.dfold_trimul_gate_fwd(_p(proj), _p(maskf), _p(ab), c_int64(R), c_int32(c), stream()), "dfold_trimul_gate_fwd")
-        planes = _to_planes(ab, N, outgoing)                                           # [2c][N][N]
-        xp = torch.empty((c, N, N), dtype=BF16, device=dev)
-        gemm(planes, planes, xp, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
-             sa=(R, 0), sb=(R, 0), sc=(R, 0), b_off=c * R)                            # x_c = a_c b_c^T   (:113-118)
-        x = ops.transpose_bf16(xp.view(c, R), c, R)                                    # [R][c]
+        planes = _to_planes(ab, B, N, outgoing)                                        # [B][2c][N][N]
+        xp = torch.empty((B, c, N, N), dtype=BF16, device=dev)
+        gemm(planes, planes, xp, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
+             sa=(2 * c * NN, NN), sb=(2 * c * NN, NN), sc=(c * NN, NN), b_off=c * NN)  # x_c = a_c b_c^T   (:113-118)
+        x = _from_planes(xp, B, N, True)                                               # [R][c]
         xn, st_out = _row_ln_fwd(x, g_out.detach(), b_out.detach())
         y = torch.empty((R, cz), dtype=torch.float32, device=dev)
         gemm(xn, CACHE.w(w_z), y, R, cz, c, a_rows=rows_plain(c), c_rows=rows_plain(cz), ldb=c, bias=b_z.detach())
@@ -114,15 +126,16 @@ class TriangleMultiplicationFn(Function):
               "dfold_gate_mul_fwd")
         ctx.save_for_backward(zf, maskf, zn, st_in, proj, planes, x, xn, st_out, y, g_in, g_out, w_ap, w_ag, w_bp, w_bg,
                               w_g, w_z)
-        ctx.dims = (N, cz, c, outgoing, z.shape)
+        ctx.dims = (B, N, cz, c, outgoing, z.shape)
         return out.view(z.shape)
 
     @staticmethod
     def backward(ctx, dout):
         L = _lib.lib()
         (zf, maskf, zn, st_in, proj, planes, x, xn, st_out, y, g_in, g_out, w_ap, w_ag, w_bp, w_bg, w_g, w_z) = ctx.saved_tensors
-        N, cz, c, outgoing, zshape = ctx.dims
-        R, dev = N * N, zf.device
+        B, N, cz, c, outgoing, zshape = ctx.dims
+        NN = N * N
+        R, dev = B * NN, zf.device
         P5 = proj.shape[1]
         dout = dout.reshape(R, cz).contiguous().float()
         dy = torch.empty((R, cz), dtype=BF16, device=dev)
@@ -133,16 +146,16 @@ class TriangleMultiplicationFn(Function):
         dxn = torch.empty((R, c), dtype=BF16, device=dev)
         gemm(dy, CACHE.wt(w_z), dxn, R, c, cz, a_rows=rows_plain(cz), c_rows=rows_plain(c), ldb=cz)
         dx, dg_out, db_out = _row_ln_bwd(x, st_out, g_out.detach(), dxn, dx_bf16=True)
-        dxp = ops.transpose_bf16(dx, R, c)                                             # [c][N][N]
-        planesT = ops.transpose_bf16(planes, N, N, nbatch=2 * c, nb1=1, bs_src=(R, 0))  # [2c][k][i|j]
-        dxpT = ops.transpose_bf16(dxp, N, N, nbatch=c, nb1=1, bs_src=(R, 0))
-        dplanes = torch.empty((2 * c, R), dtype=BF16, device=dev)
-        # da_c[i,k] = sum_j dx_c[i,j] b_c[j,k];   db_c[j,k] = sum_i dx_c[i,j] a_c[i,k]
-        gemm(dxp, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
-             sa=(R, 0), sb=(R, 0), sc=(R, 0), b_off=c * R)
-        gemm(dxpT, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=c, nb1=1,
-             sa=(R, 0), sb=(R, 0), sc=(R, 0), c_off=c * R)
-        dab = _from_planes(dplanes, N, outgoing)
+        dxp = _to_planes(dx, B, N, True)                                               # [B][c][N][N]
+        planesT = ops.transpose_bf16(planes, N, N, nbatch=B * 2 * c, nb1=1, bs_src=(NN, 0))   # [B][2c][k][i|j]
+        dxpT = ops.transpose_bf16(dxp, N, N, nbatch=B * c, nb1=1, bs_src=(NN, 0))
+        dplanes = torch.empty((B, 2 * c, N, N), dtype=BF16, device=dev)
+        # da_c[i,k] = sum_j dx_c[i,j] b_c[j,k];   db_c[j,k] = sum_i dx_c[i,j] a_c[i,k]     (batch = (item, channel))
+        gemm(dxp, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
+             sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), b_off=c * NN)
+        gemm(dxpT, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
+             sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), c_off=c * NN)
+        dab = _from_planes(dplanes, B, N, outgoing)
         check(L.dfold_trimul_gate_bwd(_p(proj), _p(maskf), _p(dab), _p(dproj), c_int64(R), c_int32(c), stream()),
               "dfold_trimul_gate_bwd")
         dwcat, dbcat = _linear_grads(zn, dproj)
@@ -165,26 +178,25 @@ def _np64(N):
 
 
 def _recompute_grads(fn, x, mask, dout, head_args, params, transpose=False):
-    """Backward of the fused forwards: run the unfused chain (`fn`, which keeps its intermediates) per batch item on the
-    saved inputs and differentiate it.  N_res is zero-padded (masked) to a multiple of 8 for the chain's 16-byte rows:
-    padded cells carry mask 0 and receive a zero output gradient, so they contribute exactly nothing."""
+    """Backward of the fused forwards: ONE batched pass of the chain that keeps its intermediates (`fn`: row kernels on the
+    flattened [B*N*N, .] cell matrix, contractions batched over (item, channel) / (item, row, head) on the MFMA engine) on
+    the saved inputs, differentiated.  N_res is zero-padded (masked) to a multiple of 8 for the chain's 16-byte rows: padded
+    cells carry mask 0 and receive a zero output gradient, so they contribute exactly nothing."""
     import torch.nn.functional as Fn_
     B, N = x.shape[0], x.shape[1]
     N8 = (N + 7) // 8 * 8
     with torch.enable_grad():
         xs = x.detach().float().requires_grad_(True)
         ps = [p.detach().requires_grad_(True) for p in params]
-        ys = []
-        for b in range(B):
-            xb, mb = xs[b], mask[b].float()
-            if transpose:
-                xb, mb = xb.transpose(0, 1), mb.transpose(0, 1)
-            if N8 != N:
-                xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
-                mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
-            yb = fn.apply(xb.contiguous(), mb.contiguous(), *head_args, *ps)[:N, :N]
-            ys.append(yb.transpose(0, 1) if transpose else yb)
-        y = torch.stack(ys)
+        xb, mb = xs, mask.float()
+        if transpose:
+            xb, mb = xb.transpose(1, 2), mb.transpose(1, 2)
+        if N8 != N:
+            xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
+            mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
+        y = fn.apply(xb.contiguous(), mb.contiguous(), *head_args, *ps)[:, :N, :N]
+        if transpose:
+            y = y.transpose(1, 2)
         return torch.autograd.grad(y, [xs] + ps, dout.reshape(y.shape).float(), allow_unused=True)
 
 
@@ -314,9 +326,8 @@ class TriangleMultiplicativeUpdate(nn.Module):
                              f"needs N_res % 8 == 0 (got {z.shape[-2]}); c_z = c_hidden = 128 takes any N_res")
         if z.dim() == 3:
             return self._one(z, mask)
-        lead = z.shape[:-3]
         zs, ms = z.reshape((-1,) + z.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
-        return torch.stack([self._one(zs[i], ms[i]) for i in range(zs.shape[0])]).reshape(lead + z.shape[-3:])
+        return self._one(zs, ms).reshape(z.shape)
 
 
 class TriangleMultiplicationOutgoing(TriangleMultiplicativeUpdate):
@@ -334,16 +345,20 @@ class TriangleMultiplicationIncoming(TriangleMultiplicativeUpdate):
 # ------------------------------------------------------------------------------------------------
 
 class TriangleAttentionFn(Function):
-    """x fp32 [I,J,c_in] (already transposed for the ending node), mask [I,J] -> fp32 [I,J,c_in]   (AF2 Alg. 13 / 14)
-    logits[i,h,q,k] = q_{iqh}.k_{ikh}/sqrt(c) + inf*(mask[i,k]-1) + tri[h,q,k], tri = Linear_nobias(LN(x))"""
+    """x fp32 [I,J,c_in] or [B,I,J,c_in] (already transposed for the ending node), mask [I,J] / [B,I,J] -> same shape as x
+    (AF2 Alg. 13 / 14).  logits[i,h,q,k] = q_{iqh}.k_{ikh}/sqrt(c) + inf*(mask[i,k]-1) + tri[h,q,k], tri = Linear_nobias(LN(x)).
+    The chain that keeps its intermediates: row kernels on the flattened [B*I*J, .] cell matrix, attention products batched
+    over (batch item, row, head) on the MFMA engine.  N % 8 == 0."""
 
     @staticmethod
     def forward(ctx, x, mask, H, inf, g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o):
         L = _lib.lib()
-        I, J, cin = x.shape
+        B = x.shape[0] if x.dim() == 4 else 1
+        I, J, cin = x.shape[-3:]
         if I != J:
             raise ValueError("triangle attention expects a square pair tensor")
-        N, R, dev = I, I * J, x.device
+        N, NN, dev = I, I * J, x.device
+        R = B * NN
         HC = w_q.shape[0]
         C = HC // H
         xf = x.reshape(R, cin).contiguous().float()
@@ -353,20 +368,24 @@ class TriangleAttentionFn(Function):
         bcat = torch.cat([torch.zeros(3 * HC, device=dev), b_g.detach().float()]).contiguous()
         proj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)                        # [q | k | v | g]
         gemm(xn, wcat, proj, R, 4 * HC, cin, a_rows=rows_plain(cin), c_rows=rows_plain(4 * HC), ldb=cin, bias=bcat)
-        # triangle bias tri[h][q][k] = w_tri[h] . xn[(q,k)]  -> rows h (M = H), columns = pair cells
-        tri = torch.empty((H, R), dtype=torch.float32, device=dev)
-        gemm(CACHE.w(w_tri), xn, tri, H, R, cin, a_rows=rows_plain(cin), c_rows=rows_plain(R), ldb=cin)
-        # S[i,h,q,k] = q.k / sqrt(C): batch (i,h), rows q (stride 4HC), K = C
-        P = torch.empty((I, H, N, N), dtype=torch.float32, device=dev)
+        # triangle bias tri[b][h][q][k] = w_tri[h] . xn[(b,q,k)]  -> rows h (M = H), columns = the pair cells of one item
+        tri = torch.empty((B, H, NN), dtype=torch.float32, device=dev)
+        gemm(CACHE.w(w_tri), xn, tri, H, NN, cin, a_rows=rows_plain(cin), c_rows=rows_plain(NN), ldb=cin, nbatch=B, nb1=1,
+             sb=(NN * cin, 0), sc=(H * NN, 0))
+        # S[(b,i),h,q,k] = q.k / sqrt(C): batch ((b,i),h), rows q (stride 4HC), K = C
+        BI = B * I
+        P = torch.empty((BI, H, N, N), dtype=torch.float32, device=dev)
         ld = 4 * HC
-        gemm(proj, proj, P, N, N, C, a_rows=rows_plain(ld), c_rows=rows_plain(N), ldb=ld, nbatch=I * H, nb1=H,
+        gemm(proj, proj, P, N, N, C, a_rows=rows_plain(ld), c_rows=rows_plain(N), ldb=ld, nbatch=BI * H, nb1=H,
              sa=(N * ld, C), sb=(N * ld, C), sc=(H * N * N, N * N), b_off=HC, alpha=1.0 / math.sqrt(C))
-        Pb = torch.empty((I, H, N, N), dtype=BF16, device=dev)
-        check(L.dfold_triatt_softmax_fwd(_p(P), _p(maskf), _p(tri), _p(Pb), c_int32(I), c_int32(H), c_int32(N),
-                                         ctypes_float(inf), stream()), "dfold_triatt_softmax_fwd")
-        vT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=I * H, nb1=H, bs_src=(N * ld, C), src_off=2 * HC)  # [I,H,C,N]
-        o = torch.empty((R, HC), dtype=torch.float32, device=dev)                      # [i,q,h,c]
-        gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=I * H, nb1=H,
+        Pb = torch.empty((BI, H, N, N), dtype=BF16, device=dev)
+        for b in range(B):          # the row softmax takes one item's triangle bias / mask rows per launch
+            check(L.dfold_triatt_softmax_fwd(_p(P, b * I * H * NN), _p(maskf, b * NN), _p(tri, b * H * NN), _p(Pb, b * I * H * NN),
+                                             c_int32(I), c_int32(H), c_int32(N), ctypes_float(inf), stream()),
+                  "dfold_triatt_softmax_fwd")
+        vT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=BI * H, nb1=H, bs_src=(N * ld, C), src_off=2 * HC)  # [BI,H,C,N]
+        o = torch.empty((R, HC), dtype=torch.float32, device=dev)                      # [(b,i),q,h,c]
+        gemm(Pb, vT, o, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=BI * H, nb1=H,
              sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * HC, C))
         og = torch.empty((R, HC), dtype=torch.float32, device=dev)
         check(L.dfold_gate_mul_fwd(_p(o), _p(proj, 3 * HC), _p(og), c_int64(R), c_int32(HC), c_int64(ld), stream()),
@@ -375,15 +394,16 @@ class TriangleAttentionFn(Function):
         out = torch.empty((R, cin), dtype=torch.float32, device=dev)
         gemm(ogb, CACHE.w(w_o), out, R, cin, HC, a_rows=rows_plain(HC), c_rows=rows_plain(cin), ldb=HC, bias=b_o.detach())
         ctx.save_for_backward(xf, xn, st, proj, P, Pb, o, ogb, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o)
-        ctx.dims = (N, cin, H, C, x.shape)
+        ctx.dims = (B, N, cin, H, C, x.shape)
         return out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dout):
         L = _lib.lib()
         xf, xn, st, proj, P, Pb, o, ogb, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o = ctx.saved_tensors
-        N, cin, H, C, xshape = ctx.dims
-        I, R, HC, dev = N, N * N, H * C, xf.device
+        B, N, cin, H, C, xshape = ctx.dims
+        I, NN, HC, dev = N, N * N, H * C, xf.device
+        R, BI = B * NN, B * N
         ld = 4 * HC
         dob = ops.cast_bf16(dout.reshape(R, cin).contiguous().float())
         dw_o, db_o = _linear_grads(ogb, dob)
@@ -393,17 +413,18 @@ class TriangleAttentionFn(Function):
         do = torch.empty((R, HC), dtype=BF16, device=dev)
         check(L.dfold_gate_mul_bwd(_p(o), _p(proj, 3 * HC), _p(dog), _p(do), _p(dproj, 3 * HC), c_int64(R), c_int32(HC),
                                    c_int64(ld), stream()), "dfold_gate_mul_bwd")
-        nb = I * H
+        nb = BI * H
         # dP = do v^T ; dS = softmax bwd ; dtri = sum_i dS
-        dP = torch.empty((I, H, N, N), dtype=torch.float32, device=dev)
+        dP = torch.empty((BI, H, N, N), dtype=torch.float32, device=dev)
         gemm(do, proj, dP, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=ld, nbatch=nb, nb1=H,
              sa=(N * HC, C), sb=(N * ld, C), sc=(H * N * N, N * N), b_off=2 * HC)
-        dSb = torch.empty((I, H, N, N), dtype=BF16, device=dev)
-        check(L.dfold_triatt_softmax_bwd(_p(P), _p(dP), _p(dSb), c_int64(I * H * N), c_int32(N), stream()),
+        dSb = torch.empty((BI, H, N, N), dtype=BF16, device=dev)
+        check(L.dfold_triatt_softmax_bwd(_p(P), _p(dP), _p(dSb), c_int64(BI * H * N), c_int32(N), stream()),
               "dfold_triatt_softmax_bwd")
-        dtri = torch.empty((H, R), dtype=torch.float32, device=dev)
-        check(L.dfold_sum_leading(_p(dP), _p(dtri), c_int32(I), c_int64(H * N * N), c_int64(H * N * N), stream()),
-              "dfold_sum_leading")
+        dtri = torch.empty((B, H, NN), dtype=torch.float32, device=dev)
+        for b in range(B):
+            check(L.dfold_sum_leading(_p(dP, b * I * H * NN), _p(dtri, b * H * NN), c_int32(I), c_int64(H * NN), c_int64(H * NN),
+                                      stream()), "dfold_sum_leading")
         alpha = 1.0 / math.sqrt(C)
         # dq = alpha dS k ; dk = alpha dS^T q ; dv = P^T do   (written straight into the q|k|v column blocks of dproj)
         kT = ops.transpose_bf16(proj, N, C, ld_src=ld, nbatch=nb, nb1=H, bs_src=(N * ld, C), src_off=HC)
@@ -422,14 +443,16 @@ class TriangleAttentionFn(Function):
         wcatT = ops.transpose_bf16(_cat_w([w_q, w_k, w_v, w_g]), ld, cin)
         dxn32 = torch.empty((R, cin), dtype=torch.float32, device=dev)
         gemm(dproj, wcatT, dxn32, R, cin, ld, a_rows=rows_plain(ld), c_rows=rows_plain(cin), ldb=ld)
-        dtri_b = ops.cast_bf16(dtri)                                                   # [H][R]
+        dtri_b = ops.cast_bf16(dtri)                                                   # [B][H][NN]
         H8 = (H + 7) // 8 * 8
         dtriT = torch.zeros((R, H8), dtype=BF16, device=dev)
-        ops.transpose_bf16(dtri_b, H, R, out=dtriT, ld_dst=H8, bs_dst=(0, 0))
+        ops.transpose_bf16(dtri_b, H, NN, out=dtriT, nbatch=B, nb1=1, bs_src=(H * NN, 0), ld_dst=H8, bs_dst=(NN * H8, 0))
         gemm(dtriT, CACHE.wt(w_tri), dxn32, R, cin, H8, a_rows=rows_plain(H8), c_rows=rows_plain(cin), ldb=H8,
              flags=ops.GEMM_ACCUM)
-        xnT = ops.transpose_bf16(xn, R, cin)
-        dw_tri = ops.gemm_reduce_rows(dtri_b, xnT, H, cin, R)
+        xnT = ops.transpose_bf16(xn, NN, cin, nbatch=B, nb1=1, bs_src=(NN * cin, 0)) if B > 1 else ops.transpose_bf16(xn, NN, cin)
+        dw_tri = torch.zeros((H, cin), dtype=torch.float32, device=dev)
+        for b in range(B):
+            ops.gemm_reduce_rows(dtri_b[b], xnT[b] if B > 1 else xnT, H, cin, NN, out=dw_tri)
         dxn = ops.cast_bf16(dxn32)
         dx, dg_ln, db_ln = _row_ln_bwd(xf, st, g_ln.detach(), dxn, dx_bf16=False)
         return (dx.view(xshape), None, None, None, dg_ln, db_ln, dw_tri, dwcat[:HC], dwcat[HC:2 * HC], dwcat[2 * HC:3 * HC],
@@ -556,10 +579,8 @@ class TriangleAttention(nn.Module):
         if x.dim() == 3:
             y = self._one(x.contiguous(), mask.contiguous())
         else:
-            lead = x.shape[:-3]
             xs, ms = x.reshape((-1,) + x.shape[-3:]), mask.reshape((-1,) + mask.shape[-2:])
-            y = torch.stack([self._one(xs[i].contiguous(), ms[i].contiguous()) for i in range(xs.shape[0])])
-            y = y.reshape(lead + x.shape[-3:])
+            y = self._one(xs.contiguous(), ms.contiguous()).reshape(x.shape)
         if not self.starting:
             y = y.transpose(-2, -3)
         return y

@@ -320,3 +320,25 @@ def test_fused_nres256_gradients_vs_oracle(name):
     assert rel_l2(zz.grad, zr.grad) < 3e-2, rel_l2(zz.grad, zr.grad)
     for k, p in m.named_parameters():
         assert rel_l2(p.grad, P[k].grad) < 3e-2, (k, rel_l2(p.grad, P[k].grad))
+
+
+@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
+def test_fused_batched_backward_vs_oracle(name):
+    """Backward of a BATCH (two items, ragged N_res = 27: zero-padded to 32 inside) in one pass of the batched chain -- input
+    and parameter gradients against the oracle's autograd summed over the items."""
+    dev = torch.device(DEV)
+    B, N = 2, 27
+    m = _rand_module(_names()[name](), 81)
+    P = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m.to(dev)
+    z, mask = _inputs(B, N, 82)
+    gy = torch.tensor(np.random.default_rng(83).standard_normal((B, N, N, 128), dtype=np.float32))
+    zr = z.clone().requires_grad_(True)
+    for b in range(B):
+        _oracle(name, P, zr[b], mask[b]).backward(gy[b])
+    zz = z.to(dev).requires_grad_(True)
+    y = m(zz, mask=mask.to(dev))
+    y.backward(gy.to(dev))
+    assert rel_l2(zz.grad, zr.grad) < 3e-2, rel_l2(zz.grad, zr.grad)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, P[k].grad) < 3e-2, (k, rel_l2(p.grad, P[k].grad))
