@@ -300,8 +300,12 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        # (DFOLD_BENCH_BACKEND=gloo + DFOLD_BENCH_ONE_GPU=1: N ranks sharing cuda:0, a dry run of the multi-rank path where
+        # only one GPU is available; RCCL itself refuses two ranks on one device)
+        dist.init_process_group(backend=os.environ.get("DFOLD_BENCH_BACKEND", "nccl"))
         assert dist.get_world_size() == args.gpus
+    if os.environ.get("DFOLD_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import __graft_entry__
