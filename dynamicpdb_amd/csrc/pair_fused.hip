@@ -72,6 +72,7 @@ struct PairProjParams {
   float* f0;
   int B, N, NP, swap;
   float eps;
+  int tri_blocked;   // MODE 1: triangle bias in 16 x 16 blocks of MFMA-accumulator order (triatt_fused.hip) instead of rows
 };
 
 // MODE 0: triangle multiplication (o0 = planes [B][N][256][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
@@ -198,10 +199,11 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       }
     } else {
       const long cell0 = ((long)b * N + line) * N + pos0;
+      const bool planes_out = p.o0 != nullptr;      // null q / k / v / gate: only the triangle bias is wanted (triatt_fused.hip)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        if (pos0 + cr < N) {
+        if (planes_out && pos0 + cr < N) {
           *(uint4*)((char*)p.o0 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsQ + cr * PP_GPITCH + v * 16);
           *(uint4*)((char*)p.o1 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsK + cr * PP_GPITCH + v * 16);
           *(uint4*)((char*)p.o3 + cell0 * 256 + voff_cl[i]) = *(const uint4*)(ldsG1 + cr * PP_GPITCH + v * 16);
@@ -211,11 +213,19 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(vbase + voff_pl[i]) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
+        if (planes_out) *(uint4*)(vbase + voff_pl[i]) = *(const uint4*)(ldsV + pl * PP_SPITCH + v * 16);
       }
       if (tid < 64) {
-        const int h = tid >> 4, v = tid & 15;
-        *(uint4*)(p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4) = *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4);
+        const int h = tid >> 4, v = tid & 15;        // keys pos0 + 4v .. +4 of line (= query) `line`
+        float* dst = p.f0 + (((long)b * 4 + h) * N + line) * NP + pos0 + v * 4;
+        if (p.tri_blocked) {
+          // [B][4][NP/16 query tiles][NP/16 key tiles][64 lanes][4]: element (q, key) sits where the lane that holds it in a
+          // 16 x 16 S^T accumulator tile (lane = ((key & 15) >> 2) * 16 + (q & 15), register key & 3) finds it with ONE
+          // contiguous 16-byte load per lane (1 KB per wave instruction instead of 16 rows x 64 bytes)
+          const int nt16 = NP >> 4;
+          dst = p.f0 + (((((long)b * 4 + h) * nt16 + (line >> 4)) * nt16 + (pos0 >> 4) + (v >> 2)) * 64 + (v & 3) * 16 + (line & 15)) * 4;
+        }
+        *(uint4*)dst = *(const uint4*)(ldsT + par * 256 + h * 64 + v * 4);
       }
     }
   };
@@ -371,7 +381,7 @@ extern "C" int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const flo
   PairProjParams p;
   p.x = z; p.mask = mask; p.gamma = ln_gamma; p.beta = ln_beta; p.W = (const bf16_t*)w_cat_bf16; p.bias = bias_cat;
   p.wtri = nullptr; p.o0 = (bf16_t*)planes_bf16; p.o1 = (bf16_t*)gate_bf16; p.o2 = nullptr; p.o3 = nullptr; p.f0 = stats;
-  p.B = B; p.N = N; p.NP = NP; p.swap = incoming ? 1 : 0; p.eps = eps;
+  p.B = B; p.N = N; p.NP = NP; p.swap = incoming ? 1 : 0; p.eps = eps; p.tri_blocked = 0;
   return pair_proj_launch(0, p, z_is_bf16, (hipStream_t)stream);
 }
 
@@ -379,13 +389,15 @@ extern "C" int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const flo
                                      const void* w_cat_bf16, const float* bias_cat, const float* w_tri, void* q_bf16,
                                      void* k_bf16, void* vT_bf16, void* gate_bf16, float* tri, int32_t B, int32_t N,
                                      int32_t NP, int32_t ending, float eps, void* stream) {
-  if (!x || !ln_gamma || !ln_beta || !w_cat_bf16 || !bias_cat || !w_tri || !q_bf16 || !k_bf16 || !vT_bf16 || !gate_bf16 ||
-      !tri || !pf_dims_ok(B, N, NP))
+  const bool none = !q_bf16 && !k_bf16 && !vT_bf16 && !gate_bf16;      // triangle bias only
+  const bool all = q_bf16 && k_bf16 && vT_bf16 && gate_bf16;
+  if (!x || !ln_gamma || !ln_beta || !w_cat_bf16 || !bias_cat || !w_tri || !(none || all) || !tri || !pf_dims_ok(B, N, NP))
     return DFOLD_EINVAL;
   PairProjParams p;
   p.x = x; p.mask = nullptr; p.gamma = ln_gamma; p.beta = ln_beta; p.W = (const bf16_t*)w_cat_bf16; p.bias = bias_cat;
   p.wtri = w_tri; p.o0 = (bf16_t*)q_bf16; p.o1 = (bf16_t*)k_bf16; p.o2 = (bf16_t*)vT_bf16; p.o3 = (bf16_t*)gate_bf16;
   p.f0 = tri; p.B = B; p.N = N; p.NP = NP; p.swap = ending ? 1 : 0; p.eps = eps;
+  p.tri_blocked = none ? 1 : 0;          // the row kernel's layout (tri then needs [B][4][NP][NP] floats)
   return pair_proj_launch(1, p, x_is_bf16, (hipStream_t)stream);
 }
 

@@ -173,6 +173,14 @@ def _use_fused():
     return os.environ.get("DFOLD_TRI_FUSED", "1") != "0"
 
 
+def _use_row_kernel():
+    """triangle attention at N_res <= 256: the row kernel that keeps q|k|v|g on chip ("0": the two-kernel form)"""
+    return os.environ.get("DFOLD_TRIATT_ROW", "1") != "0"
+
+
+_TRIATT_DBG = None      # tests: fp32 [4][N][32] device tensor receiving q|k|v|gate of head 0, row 0, item 0
+
+
 def _np64(N):
     return (N + 63) // 64 * 64
 
@@ -472,17 +480,30 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
     if xc.dtype not in (torch.float32, BF16):
         xc = xc.float()
     maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
+    row_kernel = N <= 256 and _use_row_kernel()
+    # (the row kernel reads the bias in 16 x 16 accumulator-order blocks: NP x NP floats per head)
+    tri = _ws_get(ws, "tri_blk" if row_kernel else "tri", (B, 4, NP if row_kernel else N, NP), torch.float32, dev)
+    ending = 0 if starting else 1
+    st = stream()
+    out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
+    if row_kernel:
+        # projections kept on chip (csrc/triatt_fused.hip): pass 0 writes only the triangle bias, then one workgroup per
+        # (item, row) does LayerNorm + q|k|v|g + gated attention + linear_o
+        check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(wcat), _p(bcat),
+                                      _p(w_tri), c_void_p(0), c_void_p(0), c_void_p(0), c_void_p(0), _p(tri), c_int32(B),
+                                      c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), st), "dfold_triatt_proj_fwd")
+        check(L.dfold_triatt_fused_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat),
+                                       _p(bcat), _p(tri), _p(wo), _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0),
+                                       _p(_TRIATT_DBG), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf),
+                                       ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), st), "dfold_triatt_fused_fwd")
+        return out, xc, maskf
     q = _ws_get(ws, "q", (B, N, N, 128), BF16, dev)
     k = _ws_get(ws, "k", (B, N, N, 128), BF16, dev)
     gate = _ws_get(ws, "gate", (B, N, N, 128), BF16, dev)
     vT = _ws_get(ws, "vT", (B, N, 128, NP), BF16, dev)
-    tri = _ws_get(ws, "tri", (B, 4, N, NP), torch.float32, dev)
-    ending = 0 if starting else 1
-    st = stream()
     check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(wcat), _p(bcat),
                                   _p(w_tri), _p(q), _p(k), _p(vT), _p(gate), _p(tri), c_int32(B), c_int32(N), c_int32(NP),
                                   c_int32(ending), ctypes_float(1e-5), st), "dfold_triatt_proj_fwd")
-    out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
     check(L.dfold_triatt_core_fwd(_p(q), _p(k), _p(vT), _p(gate), _p(tri), _p(maskf), _p(wo), _p(b_o), _p(out),
                                   c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
                                   c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)), st),

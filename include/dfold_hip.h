@@ -237,7 +237,10 @@ int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const
 /* Triangle attention, stage 1 (triangular_attention.py:92-113, primitives.py:363-383): LayerNorm, q|k|v|g projections
  * (w_cat [512][128] bf16, bias_cat [512] = 0|0|0|b_g), triangle bias (w_tri fp32 [4][128]).  ending != 0: the operator
  * acts on x' = x^T (cell (i,j) of every output = cell (j,i) of x).  q, k, gate(=sigmoid) bf16 [B][N][N][128];
- * vT bf16 [B][N][128][NP] (keys contiguous); tri fp32 [B][4][N][NP] = log2(e) * bias (the core's softmax runs on exp2) */
+ * vT bf16 [B][N][128][NP] (keys contiguous); tri fp32 [B][4][N][NP] = log2(e) * bias (the core's softmax runs on exp2);
+ * q_bf16 = k_bf16 = vT_bf16 = gate_bf16 = NULL: only tri is produced (pass 0 of dfold_triatt_fused_fwd), and in that kernel's
+ * layout: fp32 [B][4][NP/16][NP/16][64][4], 16 x 16 (query, key) blocks in MFMA-accumulator order (element (q, key) at lane
+ * ((key & 15) >> 2) * 16 + (q & 15), register key & 3 of block (q >> 4, key >> 4)); tri must then hold B*4*NP*NP floats. */
 int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const void* w_cat_bf16,
                           const float* bias_cat, const float* w_tri, void* q_bf16, void* k_bf16, void* vT_bf16, void* gate_bf16,
                           float* tri, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps, void* stream);
@@ -248,6 +251,16 @@ int dfold_triatt_proj_fwd(const void* x, int32_t x_is_bf16, const float* ln_gamm
 int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, const void* vT_bf16, const void* gate_bf16, const float* tri,
                           const float* mask, const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, int32_t B,
                           int32_t N, int32_t NP, int32_t ending, float inf, float scale, void* stream);
+
+/* Triangle attention with the projections kept on chip (N <= 256): per (batch item, row) LayerNorm + q|k|v|g projections +
+ * gated attention over the row's keys (exact softmax) + linear_o in one workgroup; x is read once here and once by pass 0
+ * (dfold_triatt_proj_fwd with null q/k/v/gate -> tri).  w_cat [512][128] bf16 (q|k|v|g), bias_cat [512], tri as written by pass 0,
+ * mask [B][N][N] in the coordinates of x, out [B][N][N][128] fp32 | bf16.  dbg (tests, may be NULL): fp32 [4][N][32] =
+ * q | k | v | sigmoid(g) of head 0 of row 0 of item 0. */
+int dfold_triatt_fused_fwd(const void* x, int32_t x_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
+                           const void* w_cat_bf16, const float* bias_cat, const float* tri, const void* w_o_bf16, const float* b_o,
+                           void* out, int32_t out_is_bf16, float* dbg, int32_t B, int32_t N, int32_t NP, int32_t ending,
+                           float inf, float scale, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * First layer of the feature embedders (force/vel/index/rigid/angle_embeder[0:2], src/model/ipa_pytorch_dynamic.py:

@@ -342,3 +342,44 @@ def test_fused_batched_backward_vs_oracle(name):
     assert rel_l2(zz.grad, zr.grad) < 3e-2, rel_l2(zz.grad, zr.grad)
     for k, p in m.named_parameters():
         assert rel_l2(p.grad, P[k].grad) < 3e-2, (k, rel_l2(p.grad, P[k].grad))
+
+
+@pytest.mark.parametrize("N,ending", [(256, 0), (200, 1), (27, 0)])
+def test_triatt_row_kernel_stages_and_output(N, ending, monkeypatch):
+    """csrc/triatt_fused.hip (projections kept on chip, N_res <= 256): (a) the q | k | v | sigmoid(g) tiles of head 0 of
+    row 0 against fp32 torch math on the same LayerNorm output (debug tap of the kernel), (b) the whole operator against the
+    two-kernel form and against fp32 torch math (the oracle's formulas) on device."""
+    from dynamicpdb_amd.model import triangle as T
+    dev = torch.device(DEV)
+    B = 2
+    ctor = T.TriangleAttentionEndingNode if ending else T.TriangleAttentionStartingNode
+    m = _rand_module(ctor(128, 32, 4), 91).to(dev)
+    x, mask = _inputs(B, N, 92 + N, holes=0.08)
+    x, mask = x.to(dev), mask.to(dev)
+    dbg = torch.zeros(4, N, 32, device=dev)
+    monkeypatch.setattr(T, "_TRIATT_DBG", dbg)
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "1")
+    with torch.no_grad():
+        y = m(x, mask=mask)
+        yb = m(x.to(BF16), mask=mask)
+    monkeypatch.setattr(T, "_TRIATT_DBG", None)
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "0")
+    with torch.no_grad():
+        y2 = m(x, mask=mask)
+    # (a) row 0 of item 0 in the operator's coordinates
+    xr = x[0, :, 0] if ending else x[0, 0]                    # [N, 128]
+    xn = _ln(xr, m.layer_norm.weight, m.layer_norm.bias).to(BF16).float()
+    mh = m.mha
+    for pj, (lin, act) in enumerate(((mh.linear_q, None), (mh.linear_k, None), (mh.linear_v, None), (mh.linear_g, torch.sigmoid))):
+        ref = xn @ lin.weight[:32].to(BF16).float().t()
+        if lin.bias is not None:
+            ref = ref + lin.bias[:32]
+        if act is not None:
+            ref = act(ref)
+        assert rel_l2(dbg[pj], ref) < 5e-3, (pj, rel_l2(dbg[pj], ref))     # (the LN output is rounded to bf16 on both sides, from last-bit-different fp32 values)
+    # (b)
+    assert torch.isfinite(y).all()
+    assert rel_l2(y, y2) < 6e-3, rel_l2(y, y2)                    # both round the same intermediates to bf16, in other places
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = torch.stack([_oracle("tri_att_end" if ending else "tri_att_start", P, x[b].cpu(), mask[b].cpu()) for b in range(B)])
+    assert rel_l2(y, ref) < 1.5e-2 and rel_l2(yb.float(), ref) < 2.5e-2, (rel_l2(y, ref), rel_l2(yb.float(), ref))
