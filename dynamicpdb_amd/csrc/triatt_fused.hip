@@ -324,6 +324,91 @@ __global__ __launch_bounds__(512) void triatt_fused_kernel(const TriAttFusedPara
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// pass 0: triangle bias only.  tri[b][h][q][k] = log2(e) * w_tri[h] . LN(x'[q][k]) in the blocked layout read above -- a
+// pure streaming pass (x in, 4 floats per cell out): 16 lanes per cell, four cells per pass, one wave per 64-key tile.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tri_bias_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ wtri,
+                                                       float* __restrict__ tri, int B, int N, int NP, int ending, int x_bf16,
+                                                       float eps) {
+  __shared__ __attribute__((aligned(16))) float stage[4][4][64];      // [wave][head][key]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  float gam[8], bet[8], wt[4][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gam[e] = gamma[l15 * 8 + e];
+    bet[e] = beta[l15 * 8 + e];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) wt[h][e] = wtri[h * 128 + l15 * 8 + e] * 1.44269504088896341f;
+  }
+  const int tpl = NP >> 6, nt16 = NP >> 4;
+  const long ntiles = (long)B * N * tpl;
+  const unsigned esz = x_bf16 ? 2u : 4u;
+  for (long t = (long)blockIdx.x * 4 + w; t < ntiles; t += (long)gridDim.x * 4) {
+    const int pt = (int)(t % tpl);
+    const long bl = t / tpl;
+    const int line = (int)(bl % N), b = (int)(bl / N);
+#pragma unroll 4
+    for (int ps = 0; ps < 16; ++ps) {
+      const int pos = pt * 64 + ps * 4 + l4;
+      const int pc = pos < N ? pos : N - 1;                 // (keys past the end: a valid cell; their bias meets a -inf mask)
+      const long cell = ending ? ((long)b * N + pc) * N + line : ((long)b * N + line) * N + pc;
+      const char* src = (const char*)x + cell * (128 * (long)esz) + (unsigned)l15 * (8u * esz);
+      float v[8];
+      if (x_bf16) {
+        const uint4 u = *(const uint4*)src;
+        v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+        v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+      } else {
+        const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 16);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+      }
+      const float mean = tf_row16_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * (1.f / 128.f);
+      float q2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] -= mean;
+        q2 = __builtin_fmaf(v[e], v[e], q2);
+      }
+      const float rstd = rsqrtf(tf_row16_sum(q2) * (1.f / 128.f) + eps);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e] * rstd, gam[e], bet[e]);     // fp32, as the two-kernel form's bias
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        float th = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) th = __builtin_fmaf(v[e], wt[h][e], th);
+        th = tf_row16_sum(th);
+        if (l15 == 0) stage[w][h][ps * 4 + l4] = th;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int h = lane >> 4, v16 = lane & 15;            // keys pt*64 + 4 v16 .. +4 of query `line`, head h
+      float* dst = tri + (((((long)b * 4 + h) * nt16 + (line >> 4)) * nt16 + pt * 4 + (v16 >> 2)) * 64 + (v16 & 3) * 16 + (line & 15)) * 4;
+      *(f32x4*)dst = *(const f32x4*)&stage[w][h][v16 * 4];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int dfold_triatt_bias_blocked(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta,
+                                         const float* w_tri, float* tri, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps,
+                                         void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w_tri || !tri || B <= 0 || N <= 0 || NP < N || (NP & 63)) return DFOLD_EINVAL;
+  const long ntiles = (long)B * N * (NP >> 6);
+  long grid = (ntiles + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  DFOLD_LAUNCH(tri_bias_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ln_gamma, ln_beta, w_tri, tri, B, N, NP,
+               ending ? 1 : 0, x_is_bf16 ? 1 : 0, eps);
+  return dfold_check_launch();
+}
+
 extern "C" int dfold_triatt_fused_fwd(const void* x, int32_t x_is_bf16, const float* mask, const float* ln_gamma,
                                       const float* ln_beta, const void* w_cat_bf16, const float* bias_cat, const float* tri,
                                       const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, float* dbg, int32_t B,

@@ -489,9 +489,9 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
     if row_kernel:
         # projections kept on chip (csrc/triatt_fused.hip): pass 0 writes only the triangle bias, then one workgroup per
         # (item, row) does LayerNorm + q|k|v|g + gated attention + linear_o
-        check(L.dfold_triatt_proj_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(wcat), _p(bcat),
-                                      _p(w_tri), c_void_p(0), c_void_p(0), c_void_p(0), c_void_p(0), _p(tri), c_int32(B),
-                                      c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), st), "dfold_triatt_proj_fwd")
+        check(L.dfold_triatt_bias_blocked(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(w_tri), _p(tri),
+                                          c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), st),
+              "dfold_triatt_bias_blocked")
         check(L.dfold_triatt_fused_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat),
                                        _p(bcat), _p(tri), _p(wo), _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0),
                                        _p(_TRIATT_DBG), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf),

@@ -254,9 +254,12 @@ int dfold_triatt_core_fwd(const void* q_bf16, const void* k_bf16, const void* vT
 
 /* Triangle attention with the projections kept on chip (N <= 256): per (batch item, row) LayerNorm + q|k|v|g projections +
  * gated attention over the row's keys (exact softmax) + linear_o in one workgroup; x is read once here and once by pass 0
- * (dfold_triatt_proj_fwd with null q/k/v/gate -> tri).  w_cat [512][128] bf16 (q|k|v|g), bias_cat [512], tri as written by pass 0,
+ * (dfold_triatt_bias_blocked: LayerNorm + the 4-wide bias projection only, a streaming pass that writes tri in the blocked
+ * layout described at dfold_triatt_proj_fwd; that entry point with null q/k/v/gate produces the same).  w_cat [512][128] bf16 (q|k|v|g), bias_cat [512], tri as written by pass 0,
  * mask [B][N][N] in the coordinates of x, out [B][N][N][128] fp32 | bf16.  dbg (tests, may be NULL): fp32 [4][N][32] =
  * q | k | v | sigmoid(g) of head 0 of row 0 of item 0. */
+int dfold_triatt_bias_blocked(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const float* w_tri,
+                              float* tri, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps, void* stream);
 int dfold_triatt_fused_fwd(const void* x, int32_t x_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
                            const void* w_cat_bf16, const float* bias_cat, const float* tri, const void* w_o_bf16, const float* b_o,
                            void* out, int32_t out_is_bf16, float* dbg, int32_t B, int32_t N, int32_t NP, int32_t ending,
