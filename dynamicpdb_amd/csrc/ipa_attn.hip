@@ -510,9 +510,10 @@ extern "C" int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const floa
 }
 
 // dbias[b,h,i,j] = scale * sum_f dS[b,f,h,i,j]; written as bf16 in two layouts:
-//   out_hn [B][H][N*N]  (K-contiguous over (i,j): A operand of dW_b)  and  out_nh [B][N*N][H8] (H padded to 8, for dz)
+//   out_hn [B][H][N*N]  (K-contiguous over (i,j): A operand of dW_b)  and  out_nh [B][N*N] rows of 8 (H padded to 8, for dz)
+//   with a row pitch of nh_pitch elements (a multiple of 8: the rows may be the tail columns of a wider operand matrix)
 __global__ __launch_bounds__(256) void ipa_bias_grad_kernel(const float* __restrict__ dS, bf16_t* __restrict__ out_hn,
-                                                            bf16_t* __restrict__ out_nh, IpaDims d, float scale) {
+                                                            bf16_t* __restrict__ out_nh, IpaDims d, float scale, long nh_pitch) {
   const long NN = (long)d.N * d.N;
   const long ij = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
@@ -527,15 +528,15 @@ __global__ __launch_bounds__(256) void ipa_bias_grad_kernel(const float* __restr
     out_hn[((long)b * d.H + h) * NN + ij] = v;
     row[h] = v;
   }
-  *(uint4*)(out_nh + ((long)b * NN + ij) * 8) = *(const uint4*)row;
+  *(uint4*)(out_nh + ((long)b * NN + ij) * nh_pitch) = *(const uint4*)row;
 }
 
-extern "C" int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, int32_t F, int32_t N, int32_t H,
-                                   float scale, void* stream) {
-  if (!dS || !out_hn || !out_nh || B <= 0 || F <= 0 || N <= 0 || H <= 0 || H > 8) return DFOLD_EINVAL;
+extern "C" int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int64_t nh_pitch, int32_t B, int32_t F, int32_t N,
+                                   int32_t H, float scale, void* stream) {
+  if (!dS || !out_hn || !out_nh || B <= 0 || F <= 0 || N <= 0 || H <= 0 || H > 8 || nh_pitch < 8 || (nh_pitch & 7)) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
   dim3 grid((unsigned)(((long)N * N + 255) / 256), B);
   DFOLD_LAUNCH(ipa_bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dS, (bf16_t*)out_hn, (bf16_t*)out_nh, d,
-                     scale);
+                     scale, (long)nh_pitch);
   return dfold_check_launch();
 }

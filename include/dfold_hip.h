@@ -167,9 +167,10 @@ int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const float* q_pt
 int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
                       const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,
                       void* stream);
-/* dbias = scale * sum_f dS, bf16, as [B][H][N*N] and as [B][N*N][8] (H zero-padded to 8) */
-int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int32_t B, int32_t F, int32_t N, int32_t H,
-                        float scale, void* stream);
+/* dbias = scale * sum_f dS, bf16, as out_hn [B][H][N*N] and as out_nh: rows of 8 (H zero-padded to 8) per pair cell with a
+ * row pitch of nh_pitch elements (multiple of 8; 8 = dense [B][N*N][8]) */
+int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int64_t nh_pitch, int32_t B, int32_t F, int32_t N,
+                        int32_t H, float scale, void* stream);
 
 /* Fused forward of the attention core (src/model/ipa_pytorch_dynamic.py:402-469: logits, softmax, o = a v, o_pt = a v_pts)
  * for one launch per IPA block: csrc/ipa_fused.hip.  N % 8 == 0, N <= 512, 8 query / 12 value points, 256 channels per head.
