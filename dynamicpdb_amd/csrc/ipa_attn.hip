@@ -315,6 +315,21 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const bf16_t* __re
   const float hwh = hw[h];
   float dhw_acc = 0.f;
   const long base = ((long)bf * H + h) * N * N;
+  // The row's own q_pts (24) / do_pt (36) vectors are the same for every lane.  They used to come through the scalar unit
+  // (s_load -> SGPR operands): the waves sat parked on s_waitcnt for 57 % of their cycles (profiles/r3_ipa_pmc_sq.txt).
+  // Now lane c < 60 fetches element c with one coalesced vector load, one row AHEAD, and the wave reads it back from a
+  // private 256-byte LDS slot as broadcast float4s.
+  float* const rowbuf = sm + (size_t)N * (KPS + VPS) + w * 128;      // two slots of 64 floats per wave
+  const float* const qrow0 = q_pts + ((long)bf * N * H + h) * KP;
+  const float* const drow0 = do_pt + ((long)bf * N * H + h) * VP;
+  auto row_elem = [&](int i) __attribute__((always_inline)) -> float {
+    const int ii = i < N ? i : N - 1;
+    if (lane < KP) return qrow0[(long)ii * H * KP + lane];
+    if (lane < KP + VP) return drow0[(long)ii * H * VP + (lane - KP)];
+    return 0.f;
+  };
+  float rv = row_elem(w);
+  int par = 0;
   float pc[MT], dc[MT];                       // P / dP of the row in flight (the next row is requested one row ahead)
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -325,8 +340,14 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const bf16_t* __re
   }
   for (int i = w; i < N; i += 8) {
     const long pix = ((long)bf * N + i) * H + h;
-    const float* qv = q_pts + pix * KP;        // wave-uniform rows: scalar loads
-    const float* dov = do_pt + pix * VP;
+    float* const rb = rowbuf + par * 64;       // [q (24) | do_pt (36)] of row i
+    rb[lane] = rv;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    rv = row_elem(i + 8);
+    par ^= 1;
+    const float* qv = rb;
+    const float* dov = rb + KP;
     const long row = base + (long)i * N;
     float pn[MT], dn[MT];
 #pragma unroll
@@ -340,23 +361,27 @@ __global__ __launch_bounds__(512) void ipa_softmax_bwd_kernel(const bf16_t* __re
     float dot = 0.f, psum = 0.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      const int j = lane + 64 * t;
-      pv[t] = 0.f;
-      gv[t] = 0.f;
-      if (j < N) {
-        float g = dc[t];
-#pragma unroll
-        for (int c4 = 0; c4 < VP / 4; ++c4) {
-          const float4 vv = *(const float4*)(vp + j * VPS + 4 * c4);
-          g += dov[4 * c4] * vv.x + dov[4 * c4 + 1] * vv.y + dov[4 * c4 + 2] * vv.z + dov[4 * c4 + 3] * vv.w;
-        }
-        pv[t] = pc[t];
-        gv[t] = g;
-        dot += pv[t] * g;
-        psum += pv[t];
-      }
+      pv[t] = (lane + 64 * t < N) ? pc[t] : 0.f;
+      gv[t] = (lane + 64 * t < N) ? dc[t] : 0.f;
       pc[t] = pn[t];
       dc[t] = dn[t];
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < VP / 4; ++c4) {
+      const float4 dv = *(const float4*)(dov + 4 * c4);          // broadcast
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int j = lane + 64 * t;
+        if (j < N) {
+          const float4 vv = *(const float4*)(vp + j * VPS + 4 * c4);
+          gv[t] += dv.x * vv.x + dv.y * vv.y + dv.z * vv.z + dv.w * vv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      dot += pv[t] * gv[t];
+      psum += pv[t];
     }
     // The probabilities are the forward's bf16 copy (what its o / o_pair products consumed); their rows sum to 1 only to
     // 2^-9, so the row mean of g is taken with respect to THEM (dot / psum): sum_j dS_ij = 0 then holds to fp32 rounding,
@@ -405,7 +430,7 @@ extern "C" int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const 
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || N > 64 * MAXT || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
   const bf16_t* P = (const bf16_t*)P_bf16;
-  const size_t lds = (size_t)N * (KPS + VPS) * sizeof(float);
+  const size_t lds = ((size_t)N * (KPS + VPS) + 8 * 128) * sizeof(float);      // point tables + 8 wave-private row slots
   if (lds > 160 * 1024) return DFOLD_EINVAL;
   dim3 grid(1, H, B * F);
   hipStream_t st = (hipStream_t)stream;
@@ -427,73 +452,131 @@ extern "C" int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const 
 // Backward, column pass.  Per key/value residue (b,f,h,j), lane <-> j, loop over rows i:
 //   dk_pts[j,c] = hw (sum_i dS_ij q_ic - k_jc sum_i dS_ij);    dv_pts[j,c] = sum_i P_ij do_pt[i,c]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ipa_col_bwd_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dS,
+// lane <-> KPL adjacent key/value residues; the loop runs over query rows i.  The per-row vectors q_pts[i] (24 floats) and
+// do_pt[i] (36) are the same for every lane: tiles of 32 rows are staged in LDS (coalesced 16-byte loads, one tile ahead)
+// and read back as broadcast float4s.  (Round 2 fetched them through the scalar unit -- s_load into SGPR operands: with 32
+// waves per CU each streaming 61 KB the scalar cache thrashed, and rocprofv3 showed the waves parked on s_waitcnt for 77 %
+// of their cycles, SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r3_ipa_pmc_sq.txt: ~2500 cycles per row.)
+#define CB_TR 32                 // rows per LDS tile
+#define CB_RP 64                 // floats per staged row: q (24) | do_pt (36) | pad (4)
+template <int KPL, int NTHR>
+__global__ __launch_bounds__(NTHR) void ipa_col_bwd_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dS,
                                                           const float* __restrict__ q_pts, const float* __restrict__ k_pts,
                                                           const float* __restrict__ do_pt, const float* __restrict__ hw,
                                                           float* __restrict__ dk_pts, float* __restrict__ dv_pts, IpaDims d) {
-  // lane <-> key/value residue j; the loop runs over query rows i.  The per-row vectors q_pts[i], do_pt[i] have
-  // wave-uniform addresses: they are fetched through the scalar unit (s_load) and enter the FMAs as SGPR operands --
-  // no LDS traffic at all (the LDS-broadcast version spent 61 ds_read per row iteration).
+  __shared__ __attribute__((aligned(16))) float tile[2][CB_TR][CB_RP];
   const int N = d.N, H = d.H;
-  const int bf = blockIdx.z, h = blockIdx.y;
+  const int bf = blockIdx.z, h = blockIdx.y, tid = threadIdx.x;
+  constexpr int nthr = NTHR;
   const float* qbase = q_pts + ((long)bf * N * H + h) * KP;
   const float* dbase = do_pt + ((long)bf * N * H + h) * VP;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = j < N;
-  float aq[KP], av[VP], cs = 0.f;
+  const int j0 = (blockIdx.x * nthr + tid) * KPL;            // first key of this lane (N % KPL == 0)
+  const bool ok = j0 < N;
+  float aq[KPL][KP], av[KPL][VP], cs[KPL];
 #pragma unroll
-  for (int c = 0; c < KP; ++c) aq[c] = 0.f;
+  for (int e = 0; e < KPL; ++e) {
+    cs[e] = 0.f;
 #pragma unroll
-  for (int c = 0; c < VP; ++c) av[c] = 0.f;
-  const long base = ((long)bf * H + h) * N * N + (ok ? j : 0);
-  // The two per-row loads of a lane (dS, P of its key in row i) are requested CU rows ahead: the loop is a chain of
-  // dependent FMAs on wave-uniform q / do_pt vectors, and with the loads issued inside the row that consumes them every
-  // row paid a full memory round trip (1.0 ms per launch at config 3; the fp32-P form before it 0.54 ms).
-  constexpr int CU = 8;
-  float dsn[CU];
-  bf16_t pn[CU];            // raw bits: converted where they are consumed, so that nothing waits on the loads here
+    for (int c = 0; c < KP; ++c) aq[e][c] = 0.f;
 #pragma unroll
-  for (int u = 0; u < CU; ++u) {
-    const long r = u < N ? u : N - 1;                // branch-free: rows past the end re-read the last row (never used)
-    dsn[u] = dS[base + r * N];
-    pn[u] = P[base + r * N];
+    for (int c = 0; c < VP; ++c) av[e][c] = 0.f;
   }
-  for (int i0 = 0; i0 < N; i0 += CU) {
-    float dsc[CU], pc[CU];
+  const long base = ((long)bf * H + h) * N * N + (ok ? j0 : 0);
+  // tile staging: CB_TR rows x 15 float4 (6 of q, 9 of do_pt); thread t fetches chunks t, t + nthr, ... of the tile
+  constexpr int NCH = CB_TR * 15;
+  constexpr int MAXS = (NCH + NTHR - 1) / NTHR;
+  float4 stg[MAXS];
+  auto fetch = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      dsc[u] = dsn[u];
-      pc[u] = bf2f(pn[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      const int i = i0 + CU + u;
-      const long r = i < N ? i : N - 1;
-      dsn[u] = dS[base + r * N];
-      pn[u] = P[base + r * N];
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u) {
-      const int i = i0 + u;
-      if (i < N) {                                   // wave-uniform
-        const float ds = dsc[u], p = pc[u];
-        const float* qi = qbase + (long)i * H * KP;
-        const float* di = dbase + (long)i * H * VP;
-        cs += ds;
-#pragma unroll
-        for (int c = 0; c < KP; ++c) aq[c] += ds * qi[c];
-#pragma unroll
-        for (int c = 0; c < VP; ++c) av[c] += p * di[c];
+    for (int s_ = 0; s_ < MAXS; ++s_) {
+      const int id = tid + s_ * nthr;
+      if (id < NCH) {
+        const int r = id / 15, c = id - r * 15;
+        int i = t0 + r;
+        i = i < N ? i : N - 1;
+        stg[s_] = c < 6 ? *(const float4*)(qbase + (long)i * H * KP + 4 * c) : *(const float4*)(dbase + (long)i * H * VP + 4 * (c - 6));
       }
     }
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s_ = 0; s_ < MAXS; ++s_) {
+      const int id = tid + s_ * nthr;
+      if (id < NCH) {
+        const int r = id / 15, c = id - r * 15;
+        *(float4*)&tile[buf][r][4 * c] = stg[s_];
+      }
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  const int ntile = (N + CB_TR - 1) / CB_TR;
+  for (int t = 0; t < ntile; ++t) {
+    const int t0 = t * CB_TR, buf = t & 1;
+    if (t + 1 < ntile) fetch(t0 + CB_TR);
+    // this lane's dS / P values of the tile's rows: independent loads, issued 8 rows at a time
+#pragma unroll 1
+    for (int r0 = 0; r0 < CB_TR; r0 += 8) {
+      float dsv[8][KPL], pv[8][KPL];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int i = t0 + r0 + u;
+        i = i < N ? i : N - 1;
+        if (KPL == 2) {
+          const float2 dd = *(const float2*)(dS + base + (long)i * N);
+          const uint32_t pp = *(const uint32_t*)(P + base + (long)i * N);
+          dsv[u][0] = dd.x; dsv[u][KPL - 1] = dd.y;
+          pv[u][0] = bf_lo(pp); pv[u][KPL - 1] = bf_hi(pp);
+        } else {
+          dsv[u][0] = dS[base + (long)i * N];
+          pv[u][0] = bf2f(P[base + (long)i * N]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + r0 + u < N) {                        // wave-uniform
+          const float* row = &tile[buf][r0 + u][0];
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) cs[e] += dsv[u][e];
+#pragma unroll
+          for (int c4 = 0; c4 < KP / 4; ++c4) {
+            const float4 qv = *(const float4*)(row + 4 * c4);          // broadcast
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+              aq[e][4 * c4] = __builtin_fmaf(dsv[u][e], qv.x, aq[e][4 * c4]);
+              aq[e][4 * c4 + 1] = __builtin_fmaf(dsv[u][e], qv.y, aq[e][4 * c4 + 1]);
+              aq[e][4 * c4 + 2] = __builtin_fmaf(dsv[u][e], qv.z, aq[e][4 * c4 + 2]);
+              aq[e][4 * c4 + 3] = __builtin_fmaf(dsv[u][e], qv.w, aq[e][4 * c4 + 3]);
+            }
+          }
+#pragma unroll
+          for (int c4 = 0; c4 < VP / 4; ++c4) {
+            const float4 dv = *(const float4*)(row + KP + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+              av[e][4 * c4] = __builtin_fmaf(pv[u][e], dv.x, av[e][4 * c4]);
+              av[e][4 * c4 + 1] = __builtin_fmaf(pv[u][e], dv.y, av[e][4 * c4 + 1]);
+              av[e][4 * c4 + 2] = __builtin_fmaf(pv[u][e], dv.z, av[e][4 * c4 + 2]);
+              av[e][4 * c4 + 3] = __builtin_fmaf(pv[u][e], dv.w, av[e][4 * c4 + 3]);
+            }
+          }
+        }
+      }
+    }
+    if (t + 1 < ntile) commit(buf ^ 1);
+    __syncthreads();
   }
   if (!ok) return;
   const float hwh = hw[h];
-  const long pix = ((long)bf * N + j) * H + h;
 #pragma unroll
-  for (int c = 0; c < KP; ++c) dk_pts[pix * KP + c] = hwh * (aq[c] - cs * k_pts[pix * KP + c]);
+  for (int e = 0; e < KPL; ++e) {
+    const long pix = ((long)bf * N + j0 + e) * H + h;
 #pragma unroll
-  for (int c = 0; c < VP; ++c) dv_pts[pix * VP + c] = av[c];
+    for (int c = 0; c < KP; ++c) dk_pts[pix * KP + c] = hwh * (aq[e][c] - cs[e] * k_pts[pix * KP + c]);
+#pragma unroll
+    for (int c = 0; c < VP; ++c) dv_pts[pix * VP + c] = av[e][c];
+  }
 }
 
 extern "C" int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
@@ -503,9 +586,13 @@ extern "C" int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const floa
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || (long)B * F > 65535) return DFOLD_EINVAL;
   IpaDims d{B, F, N, H};
   const bf16_t* P = (const bf16_t*)P_bf16;
-  dim3 grid((N + 255) / 256, H, B * F);
-  DFOLD_LAUNCH(ipa_col_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts,
-                     dv_pts, d);
+  if ((N & 1) == 0 && (((uintptr_t)P_bf16 & 3) | ((uintptr_t)dS & 7)) == 0) {       // two keys per lane: 8- / 4-byte loads
+    dim3 grid((N / 2 + 127) / 128, H, B * F);
+    DFOLD_LAUNCH((ipa_col_bwd_kernel<2, 128>), grid, dim3(128), 0, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts, dv_pts, d);
+  } else {
+    dim3 grid((N + 255) / 256, H, B * F);
+    DFOLD_LAUNCH((ipa_col_bwd_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, P, dS, q_pts, k_pts, do_pt, hw, dk_pts, dv_pts, d);
+  }
   return dfold_check_launch();
 }
 

@@ -69,36 +69,41 @@ __global__ __launch_bounds__(256) void ipa_aug_prep_qk_kernel(const float* __res
   const float* k = k_pts + idx * 24;
   const float c0 = ctr[bf * 3], c1 = ctr[bf * 3 + 1], c2 = ctr[bf * 3 + 2];
   const float hwh = hw[h], s = hwh * inv_alpha;
-  __attribute__((aligned(16))) bf16_t qo[IF_PK], ko[IF_PK];
+  // outputs as packed pairs (one v_cvt_pk_bf16_f32 per pair and piece; coordinate pairs never straddle a product block)
+  __attribute__((aligned(16))) uint32_t qo[IF_PK / 2], ko[IF_PK / 2];
   float k2 = 0.f;
 #pragma unroll
-  for (int c = 0; c < 24; ++c) {
-    const float cc = (c % 3 == 0) ? c0 : ((c % 3 == 1) ? c1 : c2);
-    const float qv = (q[c] - cc) * s, kv = k[c] - cc;
-    k2 = __builtin_fmaf(kv, kv, k2);
-    bf16_t qh, qm, ql, kh, km, kl;
-    if_split3(qv, qh, qm, ql);
-    if_split3(kv, kh, km, kl);
+  for (int c = 0; c < 24; c += 2) {
+    const float ca = (c % 3 == 0) ? c0 : ((c % 3 == 1) ? c1 : c2);
+    const float cb = ((c + 1) % 3 == 0) ? c0 : (((c + 1) % 3 == 1) ? c1 : c2);
+    const float qa = (q[c] - ca) * s, qb = (q[c + 1] - cb) * s, ka = k[c] - ca, kb = k[c + 1] - cb;
+    k2 = __builtin_fmaf(ka, ka, k2);
+    k2 = __builtin_fmaf(kb, kb, k2);
+    const uint32_t qh = pack2bf_hw(qa, qb), kh = pack2bf_hw(ka, kb);
+    const float qra = qa - bf_lo(qh), qrb = qb - bf_hi(qh), kra = ka - bf_lo(kh), krb = kb - bf_hi(kh);
+    const uint32_t qm = pack2bf_hw(qra, qrb), km = pack2bf_hw(kra, krb);
+    const uint32_t ql = pack2bf_hw(qra - bf_lo(qm), qrb - bf_hi(qm)), kl = pack2bf_hw(kra - bf_lo(km), krb - bf_hi(km));
+    const int i2 = c >> 1;
     // products hh, hm, mh, hl, lh, mm
-    qo[c] = qh;       ko[c] = kh;
-    qo[24 + c] = qh;  ko[24 + c] = km;
-    qo[48 + c] = qm;  ko[48 + c] = kh;
-    qo[72 + c] = qh;  ko[72 + c] = kl;
-    qo[96 + c] = ql;  ko[96 + c] = kh;
-    qo[120 + c] = qm; ko[120 + c] = km;
+    qo[i2] = qh;       ko[i2] = kh;
+    qo[12 + i2] = qh;  ko[12 + i2] = km;
+    qo[24 + i2] = qm;  ko[24 + i2] = kh;
+    qo[36 + i2] = qh;  ko[36 + i2] = kl;
+    qo[48 + i2] = ql;  ko[48 + i2] = kh;
+    qo[60 + i2] = qm;  ko[60 + i2] = km;
   }
 #pragma unroll
-  for (int c = 144; c < IF_PK; ++c) {
-    qo[c] = 0;
-    ko[c] = 0;
+  for (int c = 72; c < IF_PK / 2; ++c) {
+    qo[c] = 0u;
+    ko[c] = 0u;
   }
   const long row = (bf * H + h) * N + n;
   uint4* qd = (uint4*)(QP + row * IF_PK);
   uint4* kd = (uint4*)(KP + row * IF_PK);
 #pragma unroll
   for (int v = 0; v < IF_PK / 8; ++v) {
-    qd[v] = ((const uint4*)qo)[v];
-    kd[v] = ((const uint4*)ko)[v];
+    qd[v] = make_uint4(qo[4 * v], qo[4 * v + 1], qo[4 * v + 2], qo[4 * v + 3]);
+    kd[v] = make_uint4(ko[4 * v], ko[4 * v + 1], ko[4 * v + 2], ko[4 * v + 3]);
   }
   kn[row] = -0.5f * hwh * k2;
 }

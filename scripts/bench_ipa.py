@@ -42,6 +42,19 @@ def main():
             torch.cuda.synchronize()
         print(f"{tag}: {e0.elapsed_time(e1) / reps:.3f} ms per IpaCoreFn forward (incl. pair projections + o_pair)", flush=True)
 
+    if "--fwdbwd" in sys.argv:       # one forward + backward of the node (the PMC passes of scripts/gpu_ipa_pmc.sh profile this)
+        Fm._IPA_FUSED, Fm._IPA_KEEP_P32 = True, False
+        leaves = [t.clone().requires_grad_(True) for t in (q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz)] + [mask, hw.clone().requires_grad_(True)]
+        for rep in range(2):
+            o, o_pt, o_pair = Fm.IpaCoreFn.apply(*leaves)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.autograd.backward([o, o_pt, o_pair], [torch.ones_like(o), torch.ones_like(o_pt), torch.ones_like(o_pair)])
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"IpaCoreFn backward: {e0.elapsed_time(e1):.3f} ms", flush=True)
+        return
     run("unfused chain", False, True)
     run("fused, fp32 P kept", True, True)
     run("fused, bf16 P only", True, False)
