@@ -107,7 +107,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r2_pmc_conv.json")     # HBM-side bytes per launch from the committed PMC passes
+    pmc = os.path.join(ROOT, "profiles", "r3_pmc_conv.json")     # HBM-side bytes per launch from the committed PMC passes
     if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
         with open(pmc) as fh:
             c = json.load(fh)

@@ -125,12 +125,32 @@ def _stages_att(m, x, mask, reps):
                                       ctypes_float(1.0 / math.sqrt(32.0)), stream()), "core")
 
     cells = B * N * N
-    return [
-        dict(stage="proj (LN+q|k|v|g+bias)", s=_time(s1, reps), bytes=cells * (128 * es + 4 * 128 * 2 + 16),
+    rows = [
+        dict(stage="two-kernel form: proj (LN+q|k|v|g+bias)", s=_time(s1, reps), bytes=cells * (128 * es + 4 * 128 * 2 + 16),
              flop=2.0 * cells * 128 * 516),
-        dict(stage="core (flash attention+gate+linear_o)", s=_time(s2, reps), bytes=cells * (4 * 128 * 2 + 16 + 4 + 128 * es),
-             flop=4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
+        dict(stage="two-kernel form: core (flash attention+gate+linear_o)", s=_time(s2, reps),
+             bytes=cells * (4 * 128 * 2 + 16 + 4 + 128 * es), flop=4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
     ]
+    if N <= 256:        # the row kernel (csrc/triatt_fused.hip): bias pass + one workgroup per (item, row)
+        trib = torch.empty((B, 4, NP, NP), dtype=torch.float32, device=dev)
+
+        def r0():
+            check(L.dfold_triatt_bias_blocked(_p(x), c_int32(xb), _p(g), _p(b), _p(wt), _p(trib), c_int32(B), c_int32(N), c_int32(NP),
+                                              c_int32(ending), ctypes_float(1e-5), stream()), "bias")
+
+        def r1():
+            check(L.dfold_triatt_fused_fwd(_p(x), c_int32(xb), _p(mask), _p(g), _p(b), _p(wcat), _p(bcat), _p(trib), _p(wo), _p(bo),
+                                           _p(out), c_int32(xb), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending),
+                                           ctypes_float(1e9), ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), stream()), "row")
+        r0()
+        rows += [
+            dict(stage="row form: triangle-bias pass (LN + 4-wide projection)", s=_time(r0, reps), bytes=cells * (128 * es + 16),
+                 flop=2.0 * cells * 128 * 4),
+            dict(stage="row form: LN+q|k|v|g+attention+gate+linear_o per row", s=_time(r1, reps),
+                 bytes=cells * (2 * 128 * es + 4) + B * N * 4 * NP * NP * 4,        # x, out, mask + the bias re-read per row (L2)
+                 flop=2.0 * cells * 128 * 512 + 4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
+        ]
+    return rows
 
 
 def main():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes (own runs, no tracing domains besides --kernel-trace) for the conv kernel's HBM-side traffic:
 #   gpurun --timeout 500 -- 'bash scripts/gpu_pmc.sh'
-# Writes gpurun_out/r2_pmc_{fetch_hit,write_miss_req}.txt (per-kernel averages, scripts/pmc_summary.py).
+# Writes gpurun_out/r3_pmc_{fetch_hit,write_miss_req}.txt (per-kernel averages, scripts/pmc_summary.py).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p "$R/gpurun_out"
@@ -10,10 +10,10 @@ run() {  # $1 = tag, rest = counters
   tag=$1; shift
   rm -rf /tmp/pmc_$tag
   timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- \
-      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-triangle > /tmp/pmc_$tag.log 2>&1 < /dev/null
+      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-triangle --no-other-configs > /tmp/pmc_$tag.log 2>&1 < /dev/null
   echo "pmc $tag rc=$?"
-  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/pmc_$tag > "$R/gpurun_out/r2_pmc_$tag.txt" 2>&1 < /dev/null
-  head -n 3 "$R/gpurun_out/r2_pmc_$tag.txt" | cut -c1-260
+  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/pmc_$tag > "$R/gpurun_out/r3_pmc_$tag.txt" 2>&1 < /dev/null
+  head -n 3 "$R/gpurun_out/r3_pmc_$tag.txt" | cut -c1-260
 }
 run fetch_hit FETCH_SIZE TCC_HIT_sum
 run write_miss_req WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
