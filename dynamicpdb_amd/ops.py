@@ -293,7 +293,41 @@ def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):
     return out
 
 
-def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf=None):
+# DFOLD_WGRAD_TN=0: weight gradients through the transposed, column-shifted copies (dfold_grid_transpose_shift + the NT engine)
+# also where the direct form applies.  Default: csrc/conv_wgrad_tn.hip reads the channels-last grids as they lie.
+_WGRAD_TN = os.environ.get("DFOLD_WGRAD_TN", "1") != "0"
+
+
+def wgrad_tn_ok(g, CI, CO):
+    """shapes the direct (transpose-read) weight-gradient kernel covers: frame rows of whole 64-cell K chunks, the wider
+    channel count a multiple of its 256-row tile, the narrower of its 320-column tile"""
+    return g.N % 64 == 0 and max(CI, CO) % 256 == 0 and min(CI, CO) % 320 == 0
+
+
+def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=None):
+    """conv5x5_wgrad without operand copies (same accumulator layouts, same frame-range semantics)."""
+    CI, CO = x.shape[-1], gy.shape[-1]
+    F = g.F - f_lo if nf is None else nf
+    if bias_grad is not None:      # the bias gradient used to ride on the transposing copy of gy: one column-sum pass now
+        if F == g.F:
+            colsum_bf16(gy, bias_grad, g.Wn * g.Fp * g.Wp, CO, CO)          # the border of the grid is zero
+        else:
+            for w in range(g.Wn):
+                colsum_bf16(gy[w, 2 + f_lo:2 + f_lo + F], bias_grad, F * g.Wp, CO, CO)
+    if CI <= CO:     # rows = gy channels, columns = x channels shifted by the tap
+        a, b, flip = gy, x, 0
+    else:            # rows = x channels over the gy range widened by 2 frames, columns = gy shifted by the flipped tap
+        lo = max(0, f_lo - 2)
+        F = min(g.F, f_lo + F + 2) - lo
+        f_lo = lo
+        a, b, flip = x, gy, 1
+    check(_lib.lib().dfold_conv_wgrad_tn(_p(a), _p(b), _p(dwg), c_int32(a.shape[-1]), c_int32(b.shape[-1]), c_int32(g.Wn),
+                                         c_int32(g.Fp), c_int32(g.Wp), c_int32(g.N), c_int32(f_lo), c_int32(F), c_int32(flip),
+                                         c_int32(1 if accumulate else 0), stream()), "dfold_conv_wgrad_tn")
+    return dwg
+
+
+def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf=None, tn=None):
     """dW (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.  The narrower operand gets the 5
     column-shifted transposed copies, the wider one a single copy; the WIDER operand is always the GEMM's M side
     (1280 = 5 x 256 rows, the narrow 640 = 2 x 320 columns: both tile exactly), so
@@ -302,6 +336,8 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
     bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass).
     f_lo / nf: gy is zero outside frames [f_lo, f_lo + nf): only those cells enter the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
+    if (_WGRAD_TN if tn is None else tn) and wgrad_tn_ok(g, CI, CO):
+        return conv5x5_wgrad_tn(g, x, gy, dwg, accumulate, bias_grad, f_lo, nf)
     plane, N = g.plane, g.NP        # N: K-run length of one frame row in the transposed copies
     tag = "" if g.N == g.NP else "_n%d" % g.N   # ragged N: own scratch (its pad columns must never have been written)
     F = g.F - f_lo if nf is None else nf

@@ -111,6 +111,15 @@ int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, 
    gradient, fused) */
 int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, int32_t Wp, int32_t C, int32_t N, int32_t NP,
                                int32_t d0, int32_t nd, int32_t f0, int32_t nf, float* colsum, void* stream);
+/* 5x5 conv weight gradient straight from the zero-padded channels-last grids (the autograd of nn.Conv2d,
+   src/model/ipa_pytorch_dynamic.py:669-690), no operand copies (csrc/conv_wgrad_tn.hip, ds_read_b64_tr_b16 fragments):
+     dWg[a][tap][b] (+)= sum_{w < W, f0 <= f < f0+nf, n < N}  A[w][2+f][2+n][a] * B[w][f+z0][n+z1][b],   z0, z1 = 0..4,
+     tap = 5 z0 + z1, or 24 - (5 z0 + z1) when flip != 0
+   A bf16 [W][Fp][Wp][CA], B bf16 [W][Fp][Wp][CB], dWg fp32 [CA][25][CB] (overwritten unless accumulate != 0).
+   With A = dL/dy (CA = CO), B = x: dWg = dW in the [CO][25][CI] layout of dfold_conv_wgrad_unpack; with A = x, B = dL/dy and
+   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 320 == 0, N % 64 == 0, grids 16-byte aligned. */
+int dfold_conv_wgrad_tn(const void* A, const void* B, float* dWg, int32_t CA, int32_t CB, int32_t W, int32_t Fp, int32_t Wp,
+                        int32_t N, int32_t f0, int32_t nf, int32_t flip, int32_t accumulate, void* stream);
 /* out[c] += sum_r X[r*ld + c]   (X bf16, out fp32, atomics) */
 int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream);
 /* out = v > 0 ? g : 0  (bf16) */

@@ -1,0 +1,311 @@
+// 5x5 conv weight gradient straight from the channels-last activation grids (gfx950, MI355X).
+//
+//   dW[a][tap][b] (+)= sum over cells  A[cell][a] * B[cell + tap shift][b]       (reference: the autograd of nn.Conv2d,
+//                                                                                src/model/ipa_pytorch_dynamic.py:669-690)
+//
+// Both operands of this contraction are stored with the REDUCTION index (the cell) as the slow axis and the channel as the
+// fast one ([window][frame + 4][residue + 4][C] grids), whereas v_mfma_f32_32x32x16_bf16 wants 8 consecutive k values of
+// one row / column per lane.  The engine of gemm_bf16.hip therefore runs this product on transposed, column-shifted COPIES
+// of the grids (dfold_grid_transpose_shift: 6 copies per weight gradient).  This kernel needs no copies: K tiles of
+// 64 cells x 256 / 320 channels go HBM -> LDS as they lie (LDS-DMA, 16-byte chunks, rows stay channel-contiguous) and the
+// MFMA fragments are read with ds_read_b64_tr_b16, the LDS transpose read of gfx950: a 16-lane group fetches a
+// [4 cells][16 channels] block and every lane receives the 4 cells of ITS channel.  Two such reads make one 8-deep
+// fragment.  Which 8 cells of a K16 block a lane holds is a free choice as long as the A and the B fragment agree (a
+// permutation of the reduction index): lanes 0-31 take cells 0-3 and 4-7, lanes 32-63 cells 8-11 and 12-15.
+//
+// LDS image: A tile [64 cells][256 ch] (512-byte rows), B tile [64 cells][320 ch] (640-byte rows), two stages.  One
+// transpose read touches, per 32-lane half, 4 cells x 64 bytes: the 16-byte chunks of a row are XOR-permuted on the DMA
+// *source* side (the LDS-DMA image itself is lane-linear) so that those 4 x 64 bytes fall into four different 64-byte
+// bank groups:   A: chunk ^= (cell & 3) << 2        B (rows 128 bytes apart mod 256): chunk ^= ((cell >> 1) & 1) << 2.
+//
+// Work split as in the 256 x 320 kernel of gemm_bf16.hip: 8 waves as 4 (M) x 2 (N), 2 x 5 MFMA tiles per wave -- here the
+// tiles of a wave are INTERLEAVED with those of its neighbours (rows wm*32 + i*128, columns (2j + wn)*32): the bits of the
+// chunk index that the XOR keys touch are then the same for all tiles of a wave, and one address register per operand plus
+// immediate offsets reaches every fragment.  The second wave of every SIMD runs half a K step behind the first; one workgroup per (m tile, tap, n tile), m tile fastest, so
+// that the workgroups of one XCD share the B rows of one tap and the 5 frame taps re-read rows a few K steps apart.
+#include "dfold_common.h"
+#include "dfold_hip.h"
+
+#define TBK 64
+#define TBM 256
+#define TBN 320
+#define TA_PITCH (TBM * 2)            // bytes per cell row of the A tile
+#define TB_PITCH (TBN * 2)
+#define TA_BYTES (TBK * TA_PITCH)     // 32 KiB
+#define TB_BYTES (TBK * TB_PITCH)     // 40 KiB
+#define TSTAGE (TA_BYTES + TB_BYTES)  // 72 KiB
+#define TNJ 5
+
+typedef __attribute__((address_space(3))) void* tn_lds_ptr_t;
+typedef __attribute__((address_space(3))) char tn_lchar;   // LDS byte pointer: 32-bit address arithmetic
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
+typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
+
+struct WgradTnParams {
+  const char* A;       // unshifted operand: first cell of the reduction (window 0, first frame row, residue 0), channel 0
+  const char* B;       // shifted operand: the cell that pairs with it for shift (0, 0)
+  float* C;            // accumulators [CA][25][CB]
+  int CA, CB;          // channels = cell pitch of the two grids (elements)
+  long rowA, rowB;     // bytes from one frame row of the grid to the next
+  long winA, winB;     // bytes from one window to the next
+  int nchunk, nF, nW;  // K walk: 64-cell chunks per frame row, frame rows, windows
+  int flip, accumulate;
+};
+
+// one MFMA operand fragment: cells (k) 0-3 and 4-7 of this lane's K-half, its own channel
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tn_frag(tn_lchar* a) {
+#if defined(TNX_PLAIN)
+  const tn_s16x4 lo = *(__attribute__((address_space(3))) tn_s16x4*)a;
+  const tn_s16x4 hi = *(__attribute__((address_space(3))) tn_s16x4*)(a + 4 * PITCH);
+#else
+  const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)a);
+  const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4*)(a + 4 * PITCH));
+#endif
+  const tn_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return *(const bf16x8*)&v;
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char tl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  // XCD-aware workgroup id (bijective for any grid size), then (m tile fastest, frame tap, residue tap, n tile)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  const int tiles_m = p.CA / TBM;
+  int r = lid;
+  const int m0 = (r % tiles_m) * TBM;
+  r /= tiles_m;
+  const int z0 = r % 5;   // frame shift of the B operand
+  r /= 5;
+  const int z1 = r % 5;   // residue shift
+  const int n0 = (r / 5) * TBN;
+  const int tap = p.flip ? 24 - (z0 * 5 + z1) : z0 * 5 + z1;
+  const long pitchA = (long)p.CA * 2, pitchB = (long)p.CB * 2;
+  const char* pa = p.A + (long)m0 * 2;
+  const char* pb = p.B + (long)z0 * p.rowB + ((long)z1 * p.CB + n0) * 2;
+
+  // ---- staging: A pieces j = t*8 + w hold cells 2j, 2j+1 (32 chunks each); B pieces are 1 KiB runs of the 640-byte rows.
+  // LDS position (cell, physical chunk pc) receives logical chunk pc ^ key(cell).
+  unsigned aoff0, boff[TNJ];     // A: piece t of this wave lies 16 cells below piece t - 1 (a scalar step on the pointer)
+  {
+    const int cell = 2 * w + (lane >> 5);
+    const int lc = (lane & 31) ^ ((cell & 3) << 2);
+    aoff0 = (unsigned)(cell * pitchA + lc * 16);
+  }
+#pragma unroll
+  for (int t = 0; t < TNJ; ++t) {
+    const int b = (t * 8 + w) * 1024 + lane * 16;
+    const int cell = b / TB_PITCH;
+    const int pc = (b - cell * TB_PITCH) >> 4;
+    const int lc = pc ^ (((cell >> 1) & 1) << 2);
+    boff[t] = (unsigned)(cell * pitchB + lc * 16);
+  }
+  // K walk (window, frame row, 64-cell chunk), chunk fastest: byte deltas, branch-free on the scalar unit
+  const long dA = TBK * pitchA, dB = TBK * pitchB;
+  const long eA1 = p.rowA - (long)p.nchunk * dA, eB1 = p.rowB - (long)p.nchunk * dB;
+  const long eA2 = p.winA - (long)p.nF * p.rowA, eB2 = p.winB - (long)p.nF * p.rowB;
+  const int nsteps = p.nchunk * p.nF * p.nW;
+  int st_c = 0, st_f = 0, st_left = nsteps;
+  auto stage = [&](int buf) {
+    const char* sa = pa;
+    const char* sb = pb;
+    const unsigned adv = (unsigned)(1 - st_left) >> 31;        // a tile after this one exists
+    st_left -= (int)adv;
+    int c = st_c + 1;
+    const unsigned w0 = (unsigned)(p.nchunk - 1 - c) >> 31;    // frame row finished
+    c &= (int)(w0 - 1u);
+    int f = st_f + (int)w0;
+    const unsigned w1 = (unsigned)(p.nF - 1 - f) >> 31;        // window finished
+    f &= (int)(w1 - 1u);
+    st_c = c;
+    st_f = f;
+    const long k0 = -(long)w0, k1 = -(long)w1, ka = -(long)adv;
+    pa += (dA + (eA1 & k0) + (eA2 & k1)) & ka;
+    pb += (dB + (eB1 & k0) + (eB2 & k1)) & ka;
+    char* la = tl + buf * TSTAGE;
+    char* lb = la + TA_BYTES;
+#if !defined(TNX_NODMA)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sa + t * 16 * pitchA + aoff0), (tn_lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TNJ; ++t)
+      __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (tn_lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+#endif
+  };
+
+  f32x16 acc[2][TNJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- fragment addresses: 16-lane group g reads the [4 cells][16 channels] block of K-half g >> 1, channel half g & 1;
+  // lane p16 of the group points at cell p16 >> 2, channel quad p16 & 3 of that block (8 bytes) and receives channel p16
+  // A tile i of the wave = rows (wm + 4i) * 32 (chunks wm*4 + 16i + ..), B tile j = columns (wn + 2j) * 32 (chunks wn*4 + 8j + ..)
+  const int p16 = lane & 15, g = lane >> 4;
+  const int cell_l = (g >> 1) * 8 + (p16 >> 2);
+  const int c0 = (g & 1) * 2 + ((p16 >> 1) & 1);
+  const int fa = cell_l * TA_PITCH + (((wm * 4 + c0) ^ ((p16 >> 2) << 2)) << 4) + (p16 & 1) * 8;
+  const int fb = TA_BYTES + cell_l * TB_PITCH + (((wn * 4 + c0) ^ (((p16 >> 3) & 1) << 2)) << 4) + (p16 & 1) * 8;
+  tn_lchar* const tls = (tn_lchar*)tl;
+  bf16x8 af[2][2], bfr[2][TNJ];
+  auto ldfrag_real = [&](int set, int stage_off, int kb) {
+    tn_lchar* const ba = tls + (stage_off + fa);
+    tn_lchar* const bb = tls + (stage_off + fb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[set][i] = tn_frag<TA_PITCH>(ba + (i * 256 + kb * 16 * TA_PITCH));
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j) bfr[set][j] = tn_frag<TB_PITCH>(bb + (j * 128 + kb * 16 * TB_PITCH));
+  };
+#if defined(TNX_NOREAD)
+  ldfrag_real(0, 0, 0);
+  ldfrag_real(1, 0, 1);
+  auto ldfrag = [&](int set, int, int) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(af[set][i]));
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j) asm volatile("" : "+v"(bfr[set][j]));
+  };
+#else
+  auto ldfrag = ldfrag_real;
+#endif
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+  };
+
+  stage(0);
+  constexpr int NRD = 2 * (2 + TNJ);   // LDS reads of one K16 block (two transpose reads per fragment)
+#if !defined(TNX_PRIO0)
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  if (w < 4) {
+    // group A (one wave per SIMD): per K step [fragment reads][40 MFMAs], the 9 DMA pieces between the MFMAs
+    for (int s = 0; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int base = (s & 1) * TSTAGE;
+      ldfrag(0, base, 0);
+      ldfrag(1, base, 1);
+      stage((s + 1) & 1);
+      mma(0);
+      ldfrag(0, base, 2);
+      mma(1);
+      ldfrag(1, base, 3);
+      mma(0);
+      mma(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+#pragma unroll
+      for (int k = 0; k < TNJ; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TNJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TNJ, 0);
+    }
+  } else {
+    // group B (the second wave of every SIMD) runs half a K step behind: it issues the second half of the previous tile's
+    // MFMAs while group A reads its fragments, and reads the current tile after A
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ldfrag(0, 0, 0);
+    ldfrag(1, 0, 1);
+    stage(1);
+    mma(0);
+    ldfrag(0, 0, 2);
+    mma(1);
+    ldfrag(1, 0, 3);
+    for (int s = 1; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int base = (s & 1) * TSTAGE;
+      stage((s + 1) & 1);
+      mma(0);                 // previous tile, K16 blocks 2 and 3
+      mma(1);
+      ldfrag(0, base, 0);
+      ldfrag(1, base, 1);
+      mma(0);
+      ldfrag(0, base, 2);
+      mma(1);
+      ldfrag(1, base, 3);
+#pragma unroll
+      for (int k = 0; k < 4 + TNJ; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TNJ - 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TNJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TNJ, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+    }
+    mma(0);
+    mma(1);
+  }
+
+  // ---- epilogue: fp32 accumulators [CA][25][CB]; every element belongs to exactly one workgroup (plain read-modify-write)
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const long ldc = 25L * p.CB;
+  float* cb = p.C + (long)tap * p.CB + n0 + wn * 32 + frow;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long m = (long)m0 + wm * 32 + i * 128 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+      float* row = cb + m * ldc;
+      float cv[TNJ];
+#pragma unroll
+      for (int j = 0; j < TNJ; ++j) cv[j] = p.accumulate ? row[j * 64] : 0.f;
+#pragma unroll
+#if defined(TNX_NOEPI)
+      for (int j = 0; j < TNJ; ++j) if (acc[i][j][e] == 123.456f) row[j * 64] = cv[j];
+#else
+      for (int j = 0; j < TNJ; ++j) row[j * 64] = acc[i][j][e] + cv[j];
+#endif
+    }
+  }
+}
+
+extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float* dwg, int32_t CA, int32_t CB, int32_t W,
+                                   int32_t Fp, int32_t Wp, int32_t N, int32_t f0, int32_t nf, int32_t flip,
+                                   int32_t accumulate, void* stream) {
+  if (!a_grid || !b_grid || !dwg) return DFOLD_EINVAL;
+  if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBN) || W <= 0 || N <= 0 || (N % TBK) || N + 4 > Wp) return DFOLD_EINVAL;
+  if (f0 < 0 || nf <= 0 || f0 + nf + 4 > Fp) return DFOLD_EINVAL;
+  if (((uintptr_t)a_grid | (uintptr_t)b_grid) & 15) return DFOLD_EINVAL;
+  if ((long)TBK * CA * 2 + 1024 >= (1L << 31) || (long)TBK * CB * 2 + 1024 >= (1L << 31)) return DFOLD_EINVAL;
+  WgradTnParams p;
+  p.A = (const char*)a_grid + (((long)(2 + f0) * Wp + 2) * CA) * 2;
+  p.B = (const char*)b_grid + ((long)f0 * Wp * CB) * 2;
+  p.C = dwg;
+  p.CA = CA; p.CB = CB;
+  p.rowA = (long)Wp * CA * 2; p.rowB = (long)Wp * CB * 2;
+  p.winA = (long)Fp * p.rowA; p.winB = (long)Fp * p.rowB;
+  p.nchunk = N / TBK; p.nF = nf; p.nW = W;
+  p.flip = flip ? 1 : 0; p.accumulate = accumulate ? 1 : 0;
+  const unsigned nwg = (unsigned)((CA / TBM) * 25 * (CB / TBN));
+  DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel, 2 * TSTAGE);
+  DFOLD_LAUNCH(conv_wgrad_tn_kernel, dim3(nwg), dim3(512), (size_t)(2 * TSTAGE), (hipStream_t)stream, p);
+  return dfold_check_launch();
+}

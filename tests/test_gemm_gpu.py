@@ -345,3 +345,43 @@ def test_convnet_vs_oracle_golden(dev):
     g.interior(h0).copy_(cin.to(torch.bfloat16)[None])
     h4, _ = tower.forward(g, h0, save=False)
     assert rel_l2(g.interior(h4)[0].cpu(), cout) < 1e-2     # bf16 operands, fp32 accumulate (tolerance: DESIGN.md)
+
+
+@pytest.mark.parametrize("CI,CO", [(512, 320), (320, 512), (640, 768)])
+def test_conv_wgrad_direct_matches_copy_form(dev, CI, CO):
+    """conv_wgrad_tn_kernel (channels-last grids read as they lie, ds_read_b64_tr_b16 fragments) against the copy form of
+    the same weight gradient and against fp64: both operand orders (wider channel count on the row side, flipped taps for
+    CI > CO), a frame sub-range with stale data outside it, overwrite and accumulate, the bias gradient."""
+    from dynamicpdb_amd import ops
+    Wn, F, N = 2, 6, 128
+    g = ops.Grid(Wn, F, N, dev)
+    assert ops.wgrad_tn_ok(g, CI, CO)
+    gen = torch.Generator(device="cpu").manual_seed(CI + 3 * CO)
+    x, gy = g.alloc(CI), g.alloc(CO)
+    g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(torch.bfloat16))
+    g.interior(gy).copy_((torch.randn(Wn, F, N, CO, generator=gen) * 0.25).to(torch.bfloat16))
+    big, small = max(CI, CO), min(CI, CO)
+    ws = ops.Workspace(dev)
+    for (f_lo, nf) in ((0, None), (2, 3)):
+        gyr = gy
+        if nf is not None:      # the weight gradient of a frame range: gy counts as zero outside it
+            gyr = g.alloc(CO)
+            gyr[:, 2 + f_lo:2 + f_lo + nf] = gy[:, 2 + f_lo:2 + f_lo + nf]
+        outs = []
+        for tn in (False, True):
+            dwg = torch.full((big, 25, small), 7.0, dtype=torch.float32, device=dev)
+            db = torch.zeros(CO, dtype=torch.float32, device=dev)
+            ops.conv5x5_wgrad(g, x, gyr, dwg, ws, accumulate=False, bias_grad=db, f_lo=f_lo, nf=nf, tn=tn)
+            ops.conv5x5_wgrad(g, x, gyr, dwg, ws, accumulate=True, bias_grad=db, f_lo=f_lo, nf=nf, tn=tn)
+            outs.append((dwg, db))
+        assert rel_l2(outs[1][0], outs[0][0]) < 1e-5, (f_lo, nf, rel_l2(outs[1][0], outs[0][0]))
+        assert rel_l2(outs[1][1], outs[0][1]) < 1e-5
+        # fp64 on the same bf16 operands: dW[co, df, dn, ci] = sum_cells gy[cell, co] x[cell + (df-2, dn-2), ci]
+        gyi = g.interior(gyr).double().reshape(-1, CO)
+        for (df, dn) in ((0, 0), (2, 2), (4, 1), (1, 4)):
+            xs = x[:, df:df + F, dn:dn + N].double().reshape(-1, CI)
+            ref = 2 * gyi.t() @ xs                                          # [CO, CI]
+            tap = df * 5 + dn
+            got = outs[1][0][:, tap, :] if CI <= CO else outs[1][0][:, tap, :].t()
+            assert rel_l2(got, ref) < 1e-5, (f_lo, nf, df, dn, rel_l2(got, ref))
+        assert rel_l2(outs[1][1], 2 * gyi.sum(0)) < 1e-5

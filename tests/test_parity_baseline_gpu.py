@@ -325,8 +325,9 @@ def _sample_cells(Wn, F, N, k, gen):
     return cells
 
 
+@pytest.mark.parametrize("tn", [False, True])
 @pytest.mark.parametrize("CI,CO", [(1280, 640), (640, 1280)])
-def test_conv_fwd_dgrad_wgrad_config3_grid_vs_fp64(CI, CO):
+def test_conv_fwd_dgrad_wgrad_config3_grid_vs_fp64(CI, CO, tn):
     """One conv layer of the tower on the config-3 grid (M = 8*32*256 = 65536 rows): forward (bias + ReLU epilogue),
     data gradient (tap-flipped weights, ReLU-mask epilogue) and weight / bias gradient (dfold_mfma_gemm320_kernel role 2,
     the transposed-accumulator form for 1280 -> 640) against fp64 sums over the same bf16 operands on sampled cells and
@@ -366,8 +367,8 @@ def test_conv_fwd_dgrad_wgrad_config3_grid_vs_fp64(CI, CO):
     big, small = max(CI, CO), min(CI, CO)
     dwg = torch.zeros((big, 25, small), dtype=torch.float32, device=dev)
     db = torch.zeros(CO, dtype=torch.float32, device=dev)
-    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=True, bias_grad=db)
-    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=True, bias_grad=db)      # accumulates (shared tower: 4 uses)
+    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=False, bias_grad=db, tn=tn)
+    ops.conv5x5_wgrad(g, x, gy, dwg, tower_like, accumulate=True, bias_grad=db, tn=tn)      # accumulates (shared tower: 4 uses)
     from ctypes import c_int32
     from dynamicpdb_amd import _lib
     gw = torch.empty((CO, CI, 5, 5), dtype=torch.float32, device=dev)
