@@ -13,28 +13,38 @@
 // fragment.  Which 8 cells of a K16 block a lane holds is a free choice as long as the A and the B fragment agree (a
 // permutation of the reduction index): lanes 0-31 take cells 0-3 and 4-7, lanes 32-63 cells 8-11 and 12-15.
 //
-// LDS image: A tile [64 cells][256 ch] (512-byte rows), B tile [64 cells][320 ch] (640-byte rows), two stages.  One
-// transpose read touches, per 32-lane half, 4 cells x 64 bytes: the 16-byte chunks of a row are XOR-permuted on the DMA
-// *source* side (the LDS-DMA image itself is lane-linear) so that those 4 x 64 bytes fall into four different 64-byte
-// bank groups:   A: chunk ^= (cell & 3) << 2        B (rows 128 bytes apart mod 256): chunk ^= ((cell >> 1) & 1) << 2.
+// Work unit: one workgroup per (256-channel A tile, frame shift z0, 64-channel B tile) computes ALL FIVE residue shifts z1 of
+// its tap row: the five shifted B operands are the same 64 + 4 consecutive cells read 0..4 rows further down, so the B tile
+// of a K step is a 68-cell x 64-channel "halo" tile (8.5 KiB instead of 5 x 8 KiB) and the 256 x 320 accumulator tile is
+// 256 A channels x (5 shifts x 64 B channels).  8 waves as 4 (M) x 2 (N), 2 x 5 MFMA tiles per wave: rows wm*32 + i*128
+// (interleaved with the neighbours: the chunk-index bits that the XOR key touches are then the same for both tiles, one
+// address register + immediates), columns = shift j, channels wn*32..+32 of the B tile.
 //
-// Work split as in the 256 x 320 kernel of gemm_bf16.hip: 8 waves as 4 (M) x 2 (N), 2 x 5 MFMA tiles per wave -- here the
-// tiles of a wave are INTERLEAVED with those of its neighbours (rows wm*32 + i*128, columns (2j + wn)*32): the bits of the
-// chunk index that the XOR keys touch are then the same for all tiles of a wave, and one address register per operand plus
-// immediate offsets reaches every fragment.  The second wave of every SIMD runs half a K step behind the first; one workgroup per (m tile, tap, n tile), m tile fastest, so
-// that the workgroups of one XCD share the B rows of one tap and the 5 frame taps re-read rows a few K steps apart.
+// LDS image, three stages of 41 KiB: A tile [64 cells][256 ch] (512-byte rows), B tile [68 (+4 pad) cells][64 ch] (128-byte
+// rows).  One transpose read touches, per 32-lane half, 4 cells x 64 bytes: the 16-byte chunks of a row are XOR-permuted on
+// the DMA *source* side (the LDS-DMA image itself is lane-linear) so that those 4 x 64 bytes fall into four different
+// 64-byte bank groups:   A: chunk ^= (cell & 3) << 2        B (rows 128 bytes apart): chunk ^= ((cell >> 1) & 1) << 2
+// (any 4 consecutive cells, whatever the shift, cover the four (parity, key) combinations).
+//
+// K pipeline: the DMA of tile s + 2 is issued during step s (6 pieces per wave: 4 A, the wave's B piece, the shared halo
+// piece), the wait in front of step s + 1 leaves exactly those 6 outstanding (s_waitcnt vmcnt(6): loads retire in order), so
+// a tile has two full K steps to arrive.  The second wave of every SIMD runs half a K step behind the first.  Workgroup ids
+// are XCD-aware with the m tile fastest: the workgroups of one XCD share few B streams and the five A streams.
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
 
 #define TBK 64
 #define TBM 256
-#define TBN 320
+#define TBC 64                         // B channels per workgroup (x 5 residue shifts = 320 accumulator columns)
 #define TA_PITCH (TBM * 2)            // bytes per cell row of the A tile
-#define TB_PITCH (TBN * 2)
+#define TB_PITCH (TBC * 2)
 #define TA_BYTES (TBK * TA_PITCH)     // 32 KiB
-#define TB_BYTES (TBK * TB_PITCH)     // 40 KiB
-#define TSTAGE (TA_BYTES + TB_BYTES)  // 72 KiB
+#define TB_ROWS 68                    // 64 cells + 4 halo cells
+#define TB_BYTES (9 * 1024)           // 9 DMA pieces of 8 rows (rows 68..71 are padding)
+#define TSTAGE (TA_BYTES + TB_BYTES)  // 41 KiB
+#define TNSTAGE 3
 #define TNJ 5
+#define TN_DMA_PER_STEP 6
 
 typedef __attribute__((address_space(3))) void* tn_lds_ptr_t;
 typedef __attribute__((address_space(3))) char tn_lchar;   // LDS byte pointer: 32-bit address arithmetic
@@ -66,16 +76,16 @@ __device__ __forceinline__ bf16x8 tn_frag(unsigned base) {
   const tn_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return *(const bf16x8*)&v;
 }
-// the 7 fragments (2 A, 5 B) of K16 block KB into register set `set`
+// the 7 fragments (2 A row tiles, 5 residue shifts of the B tile) of K16 block KB into one register set
 template <int KB>
-__device__ __forceinline__ void tn_ldfrag(bf16x8 (&af)[2], bf16x8 (&bfr)[TNJ], unsigned ba, unsigned bb) {
+__device__ __forceinline__ void tn_ldfrag(bf16x8 (&af)[2], bf16x8 (&bfr)[TNJ], unsigned ba, const unsigned (&bb)[TNJ]) {
   af[0] = tn_frag<KB * 16 * TA_PITCH, TA_PITCH>(ba);
   af[1] = tn_frag<KB * 16 * TA_PITCH + 256, TA_PITCH>(ba);
-  bfr[0] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb);
-  bfr[1] = tn_frag<KB * 16 * TB_PITCH + 128, TB_PITCH>(bb);
-  bfr[2] = tn_frag<KB * 16 * TB_PITCH + 256, TB_PITCH>(bb);
-  bfr[3] = tn_frag<KB * 16 * TB_PITCH + 384, TB_PITCH>(bb);
-  bfr[4] = tn_frag<KB * 16 * TB_PITCH + 512, TB_PITCH>(bb);
+  bfr[0] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb[0]);
+  bfr[1] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb[1]);
+  bfr[2] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb[2]);
+  bfr[3] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb[3]);
+  bfr[4] = tn_frag<KB * 16 * TB_PITCH, TB_PITCH>(bb[4]);
 }
 // MFMA / LDS-DMA interleave of a block of 10 MFMAs that carries N DMA pieces: (2 MFMA, 1 DMA) pairs, then the rest
 template <int N>
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
-  // XCD-aware workgroup id (bijective for any grid size), then (m tile fastest, frame tap, residue tap, n tile)
+  // XCD-aware workgroup id (bijective for any grid size), then (m tile fastest, frame shift, B channel tile)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
@@ -107,38 +117,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
   const int m0 = (r % tiles_m) * TBM;
   r /= tiles_m;
   const int z0 = r % 5;   // frame shift of the B operand
-  r /= 5;
-  const int z1 = r % 5;   // residue shift
-  const int n0 = (r / 5) * TBN;
-  const int tap = p.flip ? 24 - (z0 * 5 + z1) : z0 * 5 + z1;
+  const int n0 = (r / 5) * TBC;
   const long pitchA = (long)p.CA * 2, pitchB = (long)p.CB * 2;
   const char* pa = p.A + (long)m0 * 2;
-  const char* pb = p.B + (long)z0 * p.rowB + ((long)z1 * p.CB + n0) * 2;
+  const char* pb = p.B + (long)z0 * p.rowB + (long)n0 * 2;
 
-  // ---- staging: A pieces j = t*8 + w hold cells 2j, 2j+1 (32 chunks each); B pieces are 1 KiB runs of the 640-byte rows.
+  // ---- staging: A pieces j = t*8 + w hold cells 2j, 2j+1 (32 chunks each); B piece w holds cells 8w..8w+7 (8 chunks each),
+  // B piece 8 (issued by every wave: same bytes, same place) the halo cells 64..67 (+ 4 padding rows that re-read cell 67).
   // LDS position (cell, physical chunk pc) receives logical chunk pc ^ key(cell).
-  unsigned aoff0, boff[TNJ];     // A: piece t of this wave lies 16 cells below piece t - 1 (a scalar step on the pointer)
+  unsigned aoff0, boff0, boff8;  // A: piece t of this wave lies 16 cells below piece t - 1 (a scalar step on the pointer)
   {
     const int cell = 2 * w + (lane >> 5);
     const int lc = (lane & 31) ^ ((cell & 3) << 2);
     aoff0 = (unsigned)(cell * pitchA + lc * 16);
+    const int cb = 8 * w + (lane >> 3);
+    boff0 = (unsigned)(cb * pitchB + (((lane & 7) ^ (((cb >> 1) & 1) << 2)) << 4));
+    const int ch = 64 + (lane >> 3), chs = ch < TB_ROWS ? ch : TB_ROWS - 1;
+    boff8 = (unsigned)(chs * pitchB + (((lane & 7) ^ (((ch >> 1) & 1) << 2)) << 4));
   }
-#pragma unroll
-  for (int t = 0; t < TNJ; ++t) {
-    const int b = (t * 8 + w) * 1024 + lane * 16;
-    const int cell = b / TB_PITCH;
-    const int pc = (b - cell * TB_PITCH) >> 4;
-    const int lc = pc ^ (((cell >> 1) & 1) << 2);
-    boff[t] = (unsigned)(cell * pitchB + lc * 16);
-  }
-  // K walk (window, frame row, 64-cell chunk), chunk fastest: byte deltas, branch-free on the scalar unit
+  // K walk (window, frame row, 64-cell chunk), chunk fastest: byte deltas, branch-free on the scalar unit.  After the last
+  // tile the pointers stay put: the surplus prefetches re-read it into a stage nobody reads any more.
   const long dA = TBK * pitchA, dB = TBK * pitchB;
   const long eA1 = p.rowA - (long)p.nchunk * dA, eB1 = p.rowB - (long)p.nchunk * dB;
   const long eA2 = p.winA - (long)p.nF * p.rowA, eB2 = p.winB - (long)p.nF * p.rowB;
   const int nsteps = p.nchunk * p.nF * p.nW;
   int st_c = 0, st_f = 0, st_left = nsteps;
   const char* sa_keep = pa;
-  auto stage_b = [&](int buf) {          // advance the K walk, issue the 5 B pieces of the tile
+  auto stage_1 = [&](int soff) {         // advance the K walk; the two B pieces and the first A piece of the tile
     sa_keep = pa;
     const char* sb = pb;
     const unsigned adv = (unsigned)(1 - st_left) >> 31;        // a tile after this one exists
@@ -154,15 +159,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     const long k0 = -(long)w0, k1 = -(long)w1, ka = -(long)adv;
     pa += (dA + (eA1 & k0) + (eA2 & k1)) & ka;
     pb += (dB + (eB1 & k0) + (eB2 & k1)) & ka;
-    char* lb = tl + buf * TSTAGE + TA_BYTES;
-#pragma unroll
-    for (int t = 0; t < TNJ; ++t)
-      __builtin_amdgcn_global_load_lds((const void*)(sb + boff[t]), (tn_lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+    char* la = tl + soff;
+    char* lb = la + TA_BYTES;
+    __builtin_amdgcn_global_load_lds((const void*)(sb + boff0), (tn_lds_ptr_t)(lb + w * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)(sb + boff8), (tn_lds_ptr_t)(lb + 8 * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void*)(sa_keep + aoff0), (tn_lds_ptr_t)(la + w * 1024), 16, 0, 0);
   };
-  auto stage_a = [&](int buf) {          // the 4 A pieces of the same tile
-    char* la = tl + buf * TSTAGE;
+  auto stage_2 = [&](int soff) {         // the other three A pieces
+    char* la = tl + soff;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 1; t < 4; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(sa_keep + t * 16 * pitchA + aoff0), (tn_lds_ptr_t)(la + (t * 8 + w) * 1024), 16, 0, 0);
   };
 
@@ -175,14 +181,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // ---- fragment addresses: 16-lane group g reads the [4 cells][16 channels] block of K-half g >> 1, channel half g & 1;
-  // lane p16 of the group points at cell p16 >> 2, channel quad p16 & 3 of that block (8 bytes) and receives channel p16
-  // A tile i of the wave = rows (wm + 4i) * 32 (chunks wm*4 + 16i + ..), B tile j = columns (wn + 2j) * 32 (chunks wn*4 + 8j + ..)
+  // lane p16 of the group points at cell p16 >> 2, channel quad p16 & 3 of that block (8 bytes) and receives channel p16.
+  // A tile i of the wave = rows (wm + 4i) * 32 (chunks wm*4 + 16i + ..); B fragment j = the wave's 32 channels (chunks wn*4 + ..)
+  // read j cells further down.  fa / fb hold the addresses for the stage being read and move on by one stage per K step.
   const int p16 = lane & 15, g = lane >> 4;
   const int cell_l = (g >> 1) * 8 + (p16 >> 2);
   const int c0 = (g & 1) * 2 + ((p16 >> 1) & 1);
-  const int fa = cell_l * TA_PITCH + (((wm * 4 + c0) ^ ((p16 >> 2) << 2)) << 4) + (p16 & 1) * 8;
-  const int fb = TA_BYTES + cell_l * TB_PITCH + (((wn * 4 + c0) ^ (((p16 >> 3) & 1) << 2)) << 4) + (p16 & 1) * 8;
   const unsigned tls = (unsigned)(uintptr_t)(tn_lchar*)tl;     // LDS byte address of the dynamic region
+  unsigned fa = tls + cell_l * TA_PITCH + (((wm * 4 + c0) ^ ((p16 >> 2) << 2)) << 4) + (p16 & 1) * 8;
+  unsigned fb[TNJ];
+#pragma unroll
+  for (int j = 0; j < TNJ; ++j) {
+    const int cell = cell_l + j;
+    fb[j] = tls + TA_BYTES + cell * TB_PITCH + (((wn * 4 + c0) ^ (((cell >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8;
+  }
   bf16x8 af[2][2], bfr[2][TNJ];
   auto mma = [&](int set) {
 #pragma unroll
@@ -191,76 +203,87 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
       for (int i = 0; i < 2; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
   };
-  stage_b(0);
-  stage_a(0);
+  int rd = 0, wr = 2 * TSTAGE;          // byte offsets of the stage being read / the stage the next prefetch goes to
+  auto next_stage = [&]() {             // called once per K step by every wave
+    const int wrap = rd == (TNSTAGE - 1) * TSTAGE;
+    const int d = wrap ? -(TNSTAGE - 1) * TSTAGE : TSTAGE;
+    rd += d;
+    fa += d;
+#pragma unroll
+    for (int j = 0; j < TNJ; ++j) fb[j] += d;
+    wr = wr == (TNSTAGE - 1) * TSTAGE ? 0 : wr + TSTAGE;
+  };
+
+  stage_1(0);
+  stage_2(0);
+  stage_1(TSTAGE);
+  stage_2(TSTAGE);
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
   if (w < 4) {
-    // group A (one wave per SIMD): per K step [28 fragment reads][4 x 10 MFMAs], the 9 DMA pieces of the next tile between
-    // the first 20 MFMAs, the reads of K16 blocks 2 / 3 behind the MFMAs that free their register set
+    // group A (one wave per SIMD): per K step [28 fragment reads][4 x 10 MFMAs], the 6 DMA pieces of tile s + 2 between the
+    // first 20 MFMAs, the reads of K16 blocks 2 / 3 behind the MFMAs that free their register set
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const unsigned ba = tls + (s & 1) * TSTAGE + fa, bb = tls + (s & 1) * TSTAGE + fb;
-      tn_ldfrag<0>(af[0], bfr[0], ba, bb);
-      tn_ldfrag<1>(af[1], bfr[1], ba, bb);
+      tn_ldfrag<0>(af[0], bfr[0], fa, fb);
+      tn_ldfrag<1>(af[1], bfr[1], fa, fb);
       TN_WAIT(14, 0);
-      stage_b((s + 1) & 1);
+      stage_1(wr);
       mma(0);
-      tn_pin<TNJ>();
-      tn_ldfrag<2>(af[0], bfr[0], ba, bb);
+      tn_pin<3>();
+      tn_ldfrag<2>(af[0], bfr[0], fa, fb);
       TN_WAIT(14, 1);
-      stage_a((s + 1) & 1);
+      stage_2(wr);
       mma(1);
-      tn_pin<4>();
-      tn_ldfrag<3>(af[1], bfr[1], ba, bb);
+      tn_pin<3>();
+      tn_ldfrag<3>(af[1], bfr[1], fa, fb);
       TN_WAIT(14, 0);
       mma(0);
       TN_WAIT(0, 1);
       mma(1);
+      next_stage();
     }
   } else {
     // group B (the second wave of every SIMD) runs half a K step behind: it issues the second half of the previous tile's
     // MFMAs while group A reads its fragments, and reads the current tile after A
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
-      const unsigned ba = tls + fa, bb = tls + fb;
-      tn_ldfrag<0>(af[0], bfr[0], ba, bb);
-      tn_ldfrag<1>(af[1], bfr[1], ba, bb);
-      TN_WAIT(14, 0);
-      stage_b(1);
-      mma(0);
-      tn_pin<TNJ>();
-      tn_ldfrag<2>(af[0], bfr[0], ba, bb);
-      TN_WAIT(14, 1);
-      stage_a(1);
-      mma(1);
-      tn_pin<4>();
-      tn_ldfrag<3>(af[1], bfr[1], ba, bb);
-    }
+    tn_ldfrag<0>(af[0], bfr[0], fa, fb);
+    tn_ldfrag<1>(af[1], bfr[1], fa, fb);
+    TN_WAIT(14, 0);
+    stage_1(wr);
+    mma(0);
+    tn_pin<3>();
+    tn_ldfrag<2>(af[0], bfr[0], fa, fb);
+    TN_WAIT(14, 1);
+    stage_2(wr);
+    mma(1);
+    tn_pin<3>();
+    tn_ldfrag<3>(af[1], bfr[1], fa, fb);
+    next_stage();
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const unsigned ba = tls + (s & 1) * TSTAGE + fa, bb = tls + (s & 1) * TSTAGE + fb;
       TN_WAIT(14, 0);
-      stage_b((s + 1) & 1);
+      stage_1(wr);
       mma(0);                 // previous tile, K16 block 2
-      tn_pin<TNJ>();
+      tn_pin<3>();
       TN_WAIT(0, 1);
-      stage_a((s + 1) & 1);
+      stage_2(wr);
       mma(1);                 // previous tile, K16 block 3
-      tn_pin<4>();
-      tn_ldfrag<0>(af[0], bfr[0], ba, bb);
-      tn_ldfrag<1>(af[1], bfr[1], ba, bb);
+      tn_pin<3>();
+      tn_ldfrag<0>(af[0], bfr[0], fa, fb);
+      tn_ldfrag<1>(af[1], bfr[1], fa, fb);
       TN_WAIT(14, 0);
       mma(0);
-      tn_ldfrag<2>(af[0], bfr[0], ba, bb);
+      tn_ldfrag<2>(af[0], bfr[0], fa, fb);
       TN_WAIT(14, 1);
       mma(1);
-      tn_ldfrag<3>(af[1], bfr[1], ba, bb);
+      tn_ldfrag<3>(af[1], bfr[1], fa, fb);
+      next_stage();
     }
     TN_WAIT(14, 0);
     mma(0);
@@ -268,10 +291,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     mma(1);
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus prefetches must have landed before the LDS allocation goes away
   // ---- epilogue: fp32 accumulators [CA][25][CB]; every element belongs to exactly one workgroup (plain read-modify-write)
   const int frow = lane & 31, fhalf = lane >> 5;
   const long ldc = 25L * p.CB;
-  float* cb = p.C + (long)tap * p.CB + n0 + wn * 32 + frow;
+  const long tstep = p.flip ? -(long)p.CB : (long)p.CB;       // residue shift j -> tap 5 z0 + j, or 24 - (5 z0 + j)
+  float* cb = p.C + (long)(p.flip ? 24 - 5 * z0 : 5 * z0) * p.CB + n0 + wn * 32 + frow;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -280,9 +305,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
       float* row = cb + m * ldc;
       float cv[TNJ];
 #pragma unroll
-      for (int j = 0; j < TNJ; ++j) cv[j] = p.accumulate ? row[j * 64] : 0.f;
+      for (int j = 0; j < TNJ; ++j) cv[j] = p.accumulate ? row[j * tstep] : 0.f;
 #pragma unroll
-      for (int j = 0; j < TNJ; ++j) row[j * 64] = acc[i][j][e] + cv[j];
+      for (int j = 0; j < TNJ; ++j) row[j * tstep] = acc[i][j][e] + cv[j];
     }
   }
 }
@@ -291,10 +316,10 @@ extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float
                                    int32_t Fp, int32_t Wp, int32_t N, int32_t f0, int32_t nf, int32_t flip,
                                    int32_t accumulate, void* stream) {
   if (!a_grid || !b_grid || !dwg) return DFOLD_EINVAL;
-  if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBN) || W <= 0 || N <= 0 || (N % TBK) || N + 4 > Wp) return DFOLD_EINVAL;
+  if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBC) || W <= 0 || N <= 0 || (N % TBK) || N + 4 > Wp) return DFOLD_EINVAL;
   if (f0 < 0 || nf <= 0 || f0 + nf + 4 > Fp) return DFOLD_EINVAL;
   if (((uintptr_t)a_grid | (uintptr_t)b_grid) & 15) return DFOLD_EINVAL;
-  if ((long)TBK * CA * 2 + 1024 >= (1L << 31) || (long)TBK * CB * 2 + 1024 >= (1L << 31)) return DFOLD_EINVAL;
+  if ((long)(TBK + 8) * CA * 2 >= (1L << 31) || (long)(TBK + 8) * CB * 2 >= (1L << 31)) return DFOLD_EINVAL;   // 32-bit lane offsets
   WgradTnParams p;
   p.A = (const char*)a_grid + (((long)(2 + f0) * Wp + 2) * CA) * 2;
   p.B = (const char*)b_grid + ((long)f0 * Wp * CB) * 2;
@@ -304,8 +329,8 @@ extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float
   p.winA = (long)Fp * p.rowA; p.winB = (long)Fp * p.rowB;
   p.nchunk = N / TBK; p.nF = nf; p.nW = W;
   p.flip = flip ? 1 : 0; p.accumulate = accumulate ? 1 : 0;
-  const unsigned nwg = (unsigned)((CA / TBM) * 25 * (CB / TBN));
-  DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel, 2 * TSTAGE);
-  DFOLD_LAUNCH(conv_wgrad_tn_kernel, dim3(nwg), dim3(512), (size_t)(2 * TSTAGE), (hipStream_t)stream, p);
+  const unsigned nwg = (unsigned)((CA / TBM) * 5 * (CB / TBC));
+  DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel, TNSTAGE * TSTAGE);
+  DFOLD_LAUNCH(conv_wgrad_tn_kernel, dim3(nwg), dim3(512), (size_t)(TNSTAGE * TSTAGE), (hipStream_t)stream, p);
   return dfold_check_launch();
 }

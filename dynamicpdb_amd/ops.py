@@ -300,8 +300,8 @@ _WGRAD_TN = os.environ.get("DFOLD_WGRAD_TN", "1") != "0"
 
 def wgrad_tn_ok(g, CI, CO):
     """shapes the direct (transpose-read) weight-gradient kernel covers: frame rows of whole 64-cell K chunks, the wider
-    channel count a multiple of its 256-row tile, the narrower of its 320-column tile"""
-    return g.N % 64 == 0 and max(CI, CO) % 256 == 0 and min(CI, CO) % 320 == 0
+    channel count a multiple of the 256-row tile, the narrower of the 64-channel column tile"""
+    return g.N % 64 == 0 and max(CI, CO) % 256 == 0 and min(CI, CO) % 64 == 0
 
 
 def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=None):

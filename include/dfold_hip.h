@@ -117,7 +117,7 @@ int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, in
      tap = 5 z0 + z1, or 24 - (5 z0 + z1) when flip != 0
    A bf16 [W][Fp][Wp][CA], B bf16 [W][Fp][Wp][CB], dWg fp32 [CA][25][CB] (overwritten unless accumulate != 0).
    With A = dL/dy (CA = CO), B = x: dWg = dW in the [CO][25][CI] layout of dfold_conv_wgrad_unpack; with A = x, B = dL/dy and
-   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 320 == 0, N % 64 == 0, grids 16-byte aligned. */
+   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 64 == 0, N % 64 == 0, grids 16-byte aligned. */
 int dfold_conv_wgrad_tn(const void* A, const void* B, float* dWg, int32_t CA, int32_t CB, int32_t W, int32_t Fp, int32_t Wp,
                         int32_t N, int32_t f0, int32_t nf, int32_t flip, int32_t accumulate, void* stream);
 /* out[c] += sum_r X[r*ld + c]   (X bf16, out fp32, atomics) */

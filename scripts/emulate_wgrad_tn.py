@@ -4,9 +4,9 @@ plain definition of the 5x5 conv weight gradient.  Index arithmetic only -- the 
 kernel; run it after touching the kernel's addressing:   python scripts/emulate_wgrad_tn.py"""
 import numpy as np
 
-TBK, TBM, TBN, TNJ = 64, 256, 320, 5
-TA_PITCH, TB_PITCH = TBM * 2, TBN * 2
-TA_BYTES, TB_BYTES = TBK * TA_PITCH, TBK * TB_PITCH
+TBK, TBM, TBC, TNJ = 64, 256, 64, 5
+TA_PITCH, TB_PITCH = TBM * 2, TBC * 2
+TA_BYTES, TB_ROWS, TB_BYTES = TBK * TA_PITCH, 68, 9 * 1024
 
 
 def tr_read(lds16, addr):
@@ -22,7 +22,7 @@ def tr_read(lds16, addr):
     return out
 
 
-def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wgs=6):
+def run(CA=512, CB=128, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wgs=6):
     rng = np.random.default_rng(seed)
     Fp, Wp = F + 4, N + 4
     nf = F - f0 if nf is None else nf
@@ -47,7 +47,7 @@ def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wg
     nchunk, nF, nW = N // TBK, nf, Wn
     out = np.zeros((CA, 25, CB), dtype=np.int64)
     tiles_m = CA // TBM
-    nwg = tiles_m * 25 * (CB // TBN)
+    nwg = tiles_m * 5 * (CB // TBC)
     wgs = rng.choice(nwg, size=min(check_wgs, nwg), replace=False)
     done = []
     for lid in wgs:
@@ -55,12 +55,9 @@ def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wg
         m0 = (r % tiles_m) * TBM
         r //= tiles_m
         z0 = r % 5
-        r //= 5
-        z1 = r % 5
-        n0 = (r // 5) * TBN
-        tap = 24 - (z0 * 5 + z1) if flip else z0 * 5 + z1
+        n0 = (r // 5) * TBC
         pa = pA + m0 * 2
-        pb = pB + z0 * rowB + (z1 * CB + n0) * 2
+        pb = pB + z0 * rowB + n0 * 2
         acc = np.zeros((8, 2, TNJ, 64, 16), dtype=np.int64)     # [wave][i][j][lane][e]
         lane = np.arange(64)
         for wi in range(nW):
@@ -68,23 +65,24 @@ def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wg
                 for ci in range(nchunk):
                     sa = pa + wi * winA + fi * rowA + ci * TBK * pitchA
                     sb = pb + wi * winB + fi * rowB + ci * TBK * pitchB
-                    lds = np.zeros((TA_BYTES + TB_BYTES) // 2, dtype=np.int64)
+                    lds = np.full((TA_BYTES + TB_BYTES) // 2, 10 ** 6, dtype=np.int64)   # poison: unwritten LDS must not be read
                     for w in range(8):                         # the DMA image
                         cell = 2 * w + (lane >> 5)
                         lc = (lane & 31) ^ ((cell & 3) << 2)
                         aoff0 = cell * pitchA + lc * 16
+                        cb = 8 * w + (lane >> 3)
+                        boff0 = cb * pitchB + (((lane & 7) ^ (((cb >> 1) & 1) << 2)) << 4)
+                        ch = 64 + (lane >> 3)
+                        chs = np.minimum(ch, TB_ROWS - 1)
+                        boff8 = chs * pitchB + (((lane & 7) ^ (((ch >> 1) & 1) << 2)) << 4)
                         for t in range(4):
                             src = sa + t * 16 * pitchA + aoff0
                             dst = (t * 8 + w) * 1024 + lane * 16
                             for l in range(64):
                                 lds[dst[l] // 2:dst[l] // 2 + 8] = Ab[src[l] // 2:src[l] // 2 + 8]
-                        for t in range(TNJ):
-                            b = (t * 8 + w) * 1024 + lane * 16
-                            cell = b // TB_PITCH
-                            pc = (b - cell * TB_PITCH) >> 4
-                            lc = pc ^ (((cell >> 1) & 1) << 2)
-                            src = sb + cell * pitchB + lc * 16
-                            dst = TA_BYTES + b
+                        for (off, piece) in ((boff0, w), (boff8, 8)):
+                            src = sb + off
+                            dst = TA_BYTES + piece * 1024 + lane * 16
                             for l in range(64):
                                 lds[dst[l] // 2:dst[l] // 2 + 8] = Bb[src[l] // 2:src[l] // 2 + 8]
                     for w in range(8):
@@ -93,14 +91,17 @@ def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wg
                         cell_l = (g >> 1) * 8 + (p16 >> 2)
                         c0 = (g & 1) * 2 + ((p16 >> 1) & 1)
                         fa = cell_l * TA_PITCH + (((wm * 4 + c0) ^ ((p16 >> 2) << 2)) << 4) + (p16 & 1) * 8
-                        fb = TA_BYTES + cell_l * TB_PITCH + (((wn * 4 + c0) ^ (((p16 >> 3) & 1) << 2)) << 4) + (p16 & 1) * 8
+                        fb = []
+                        for j in range(TNJ):
+                            cell = cell_l + j
+                            fb.append(TA_BYTES + cell * TB_PITCH + (((wn * 4 + c0) ^ (((cell >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8)
                         for kb in range(4):
                             af, bf = [], []
                             for i in range(2):
                                 a = fa + i * 256 + kb * 16 * TA_PITCH
                                 af.append(np.concatenate([tr_read(lds, a), tr_read(lds, a + 4 * TA_PITCH)], 1))
                             for j in range(TNJ):
-                                a = fb + j * 128 + kb * 16 * TB_PITCH
+                                a = fb[j] + kb * 16 * TB_PITCH
                                 bf.append(np.concatenate([tr_read(lds, a), tr_read(lds, a + 4 * TB_PITCH)], 1))
                             for i in range(2):
                                 for j in range(TNJ):
@@ -119,16 +120,18 @@ def run(CA=512, CB=640, Wn=2, F=3, N=64, flip=0, f0=0, nf=None, seed=0, check_wg
             wm, wn = w >> 1, w & 1
             for i in range(2):
                 for j in range(TNJ):
+                    tap = 24 - (z0 * 5 + j) if flip else z0 * 5 + j
                     for l in range(64):
                         frow, fhalf = l & 31, l >> 5
                         for e in range(16):
                             m = m0 + wm * 32 + i * 128 + (e & 3) + 8 * (e >> 2) + 4 * fhalf
-                            n = n0 + wn * 32 + frow + j * 64
+                            n = n0 + wn * 32 + frow
                             out[m, tap, n] += acc[w, i, j, l, e]
-        done.append((m0, tap, n0))
+        done.append((m0, z0, n0))
     bad = 0
-    for (m0, tap, n0) in done:
-        bad += int(np.abs(out[m0:m0 + TBM, tap, n0:n0 + TBN] - ref[m0:m0 + TBM, tap, n0:n0 + TBN]).max() != 0)
+    for (m0, z0, n0) in done:
+        taps = [24 - (z0 * 5 + j) if flip else z0 * 5 + j for j in range(5)]
+        bad += int(np.abs(out[m0:m0 + TBM, taps, n0:n0 + TBC] - ref[m0:m0 + TBM, taps, n0:n0 + TBC]).max() != 0)
     return bad, len(done)
 
 

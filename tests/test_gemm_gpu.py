@@ -347,7 +347,7 @@ def test_convnet_vs_oracle_golden(dev):
     assert rel_l2(g.interior(h4)[0].cpu(), cout) < 1e-2     # bf16 operands, fp32 accumulate (tolerance: DESIGN.md)
 
 
-@pytest.mark.parametrize("CI,CO", [(512, 320), (320, 512), (640, 768)])
+@pytest.mark.parametrize("CI,CO", [(512, 320), (320, 512), (640, 768), (256, 64)])
 def test_conv_wgrad_direct_matches_copy_form(dev, CI, CO):
     """conv_wgrad_tn_kernel (channels-last grids read as they lie, ds_read_b64_tr_b16 fragments) against the copy form of
     the same weight gradient and against fp64: both operand orders (wider channel count on the row side, flipped taps for
