@@ -83,6 +83,12 @@ def _linear_backward(x2d, weight, g2d, need_dx=True):
         wt = CACHE.wt(weight)                       # [K][N8]
         dx = torch.empty((M, K), dtype=BF16, device=x2d.device)
         gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
+    if ops.gemm_tn_ok(N8, K, M) and g8.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
+        # both operands have the reduction index (the rows) as their slow axis: csrc/tn_gemm.hip reads them as they lie
+        dW = ops.weight_grad_tn(g8, x2d, M, N8, K)
+        db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)
+        ops.colsum_bf16(g8, db, M, N8, N8)
+        return dx, dW[:N], db[:N]
     M8 = (M + 7) // 8 * 8
     if M8 == M:
         gT = ops.transpose_bf16(g8, M, N8)          # [N8][M]
@@ -450,6 +456,13 @@ class IpaCoreFn(Function):
              sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C), alpha=alpha)
         # dk = alpha dS^T q ; dv = P^T do
         dkv = torch.empty_like(kv)
+        if ops.gemm_tn_ok(N, C, N):
+            # the reduction runs over the query index, the slow axis of dS / P and of q / do: no transposed copies
+            ops.gemm_tn(dSb, q, dkv, N, C, N, N, HC, 2 * HC, nbatch=nb, nb1=H, sa=(H * NN, NN), sb=(N * HC, C),
+                        sc=(N * 2 * HC, 2 * C), alpha=alpha)
+            ops.gemm_tn(Pb, do, dkv, N, C, N, N, HC, 2 * HC, nbatch=nb, nb1=H, sa=(H * NN, NN), sb=(N * HC, C),
+                        sc=(N * 2 * HC, 2 * C), c_off=C)
+            return IpaCoreFn._backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw)
         dSbT = ops.transpose_bf16(dSb, N, N, nbatch=nb, nb1=1, bs_src=(NN, 0))
         qT = ops.transpose_bf16(q, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
         gemm(dSbT, qT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
@@ -460,7 +473,14 @@ class IpaCoreFn(Function):
         gemm(PbT, doT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
              sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * 2 * HC, 2 * C), c_off=C)
         del PbT, doT
-        # pair-side gradients
+        return IpaCoreFn._backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw)
+
+    @staticmethod
+    def _backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw):
+        """gradients of the pair-side inputs (z, linear_b, down_z) from dS and the bf16 probabilities"""
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        B, F, N, H, C, CZ, PZ = ctx.dims
+        NN, dev = N * N, q.device
         FH = F * H
         PbT2 = ops.transpose_bf16(Pb, FH, N, ld_src=NN, nbatch=B * N, nb1=N, bs_src=(FH * NN, N))       # [B,N(i),N(j),FH]
         dop = do_pair.view(B, F, N, H, PZ).permute(0, 2, 1, 3, 4).contiguous()                          # [B,N,F,H,PZ]

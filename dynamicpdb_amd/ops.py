@@ -103,6 +103,36 @@ def gemm_reduce_rows(AT, BT, M, N, K, out=None):
                 sa=(ks, 0), sb=(ks, 0), sc=(0, 0), flags=GEMM_ATOMIC)
 
 
+def gemm_tn(A, B, C, M, N, K, lda, ldb, ldc, *, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), splitk=1, flags=0, alpha=1.0,
+            a_off=0, b_off=0, c_off=0):
+    """C (+)= alpha A^T B with both operands reduction-major (dfold_gemm_tn_bf16, include/dfold_hip.h)."""
+    assert A.dtype == BF16 and B.dtype == BF16
+    if C.dtype == BF16:
+        flags |= GEMM_OUT_BF16
+    check(_lib.lib().dfold_gemm_tn_bf16(_p(A, a_off), _p(B, b_off), _p(C, c_off), c_int32(M), c_int32(N), c_int64(K), c_int64(lda),
+                                        c_int64(ldb), c_int64(ldc), c_int32(nbatch), c_int32(nb1), c_int64(sa[0]), c_int64(sa[1]),
+                                        c_int64(sb[0]), c_int64(sb[1]), c_int64(sc[0]), c_int64(sc[1]), c_int32(splitk),
+                                        c_int32(flags), ctypes.c_float(alpha), stream()), "dfold_gemm_tn_bf16")
+    return C
+
+
+def gemm_tn_ok(M, N, K):
+    """shapes the reduction-major product covers (256 x 256 output tiles, 64-row K steps)"""
+    return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and os.environ.get("DFOLD_GEMM_TN", "1") != "0"
+
+
+def weight_grad_tn(g2d, x2d, M, N, K, out=None):
+    """dW fp32 [N, K] (+)= g2d^T x2d for g2d bf16 [M, N], x2d bf16 [M, K]: the long row axis M is cut into split-K parts so
+    that the few 256 x 256 output tiles still fill the chip."""
+    tiles = (N // 256) * (K // 256)
+    S = max(1, min(64, 512 // tiles))
+    while S > 1 and (M % (S * 64)):
+        S -= 1
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=g2d.device)
+    return gemm_tn(g2d, x2d, out, N, K, M, N, K, K, splitk=S, flags=GEMM_ATOMIC)
+
+
 def cast_bf16(x):
     """fp32 -> bf16 copy (HIP kernel)."""
     x = x.contiguous()

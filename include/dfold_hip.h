@@ -111,6 +111,18 @@ int dfold_conv_wgrad_unpack(const float* dWg, float* G, int32_t CO, int32_t CI, 
    gradient, fused) */
 int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, int32_t Wp, int32_t C, int32_t N, int32_t NP,
                                int32_t d0, int32_t nd, int32_t f0, int32_t nf, float* colsum, void* stream);
+/* "TN" product on the bf16 MFMA engine, both operands with the reduction index as the slow axis (csrc/tn_gemm.hip; no
+   transposed copies -- ds_read_b64_tr_b16 fragments):
+     C[z][m][n] (+)= alpha * sum_{k < K} A[z][k][m] * B[z][k][n]      A bf16 rows of lda, B bf16 rows of ldb elements
+   = the weight gradient of a dense layer (dW = dY^T X, torch.nn.Linear autograd) and the transposed attention products of
+   the IPA backward (dK = dS^T Q, dV = P^T dO; src/model/ipa_pytorch_dynamic.py:396-469).  Batch z -> (z / nb1, z % nb1)
+   with element strides (sa0, sa1) / (sb0, sb1) / (sc0, sc1).  flags: DFOLD_GEMM_OUT_BF16 (C bf16, stored), DFOLD_GEMM_ACCUM
+   (C fp32 += ), DFOLD_GEMM_ATOMIC (C fp32, atomics: required when splitk > 1 -- the K range is cut into splitk parts, C must
+   hold the running sum / zeros), else C fp32 stored.  M, N multiples of 256; K a multiple of 64 * splitk; lda, ldb, ldc and
+   the A / B strides multiples of 8, A / B 16-byte aligned. */
+int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
+                       int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
+                       int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags, float alpha, void* stream);
 /* 5x5 conv weight gradient straight from the zero-padded channels-last grids (the autograd of nn.Conv2d,
    src/model/ipa_pytorch_dynamic.py:669-690), no operand copies (csrc/conv_wgrad_tn.hip, ds_read_b64_tr_b16 fragments):
      dWg[a][tap][b] (+)= sum_{w < W, f0 <= f < f0+nf, n < N}  A[w][2+f][2+n][a] * B[w][f+z0][n+z1][b],   z0, z1 = 0..4,

@@ -385,3 +385,39 @@ def test_conv_wgrad_direct_matches_copy_form(dev, CI, CO):
             got = outs[1][0][:, tap, :] if CI <= CO else outs[1][0][:, tap, :].t()
             assert rel_l2(got, ref) < 1e-5, (f_lo, nf, df, dn, rel_l2(got, ref))
         assert rel_l2(outs[1][1], 2 * gyi.sum(0)) < 1e-5
+
+
+def test_gemm_tn_reduction_major_operands(dev):
+    """dfold_gemm_tn_bf16 (both operands with the reduction index as the slow axis, ds_read_b64_tr_b16 fragments) against fp64:
+    a split-K weight gradient with atomics, plain store / accumulate, and a strided two-level batch with bf16 output and a
+    scale (the dK / dV products of the IPA backward).  Asymmetric random operands (a transposed result cannot pass)."""
+    from dynamicpdb_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    # (a) dW[N, K] = g^T x, rows cut into 4 K parts
+    R, N, K = 4096, 512, 256
+    g = torch.randn(R, N + 8, generator=gen).to(dev).to(torch.bfloat16)[:, :N]          # row pitch N + 8
+    x = torch.randn(R, K, generator=gen).to(dev).to(torch.bfloat16)
+    ref = g.double().t() @ x.double()
+    dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    ops.gemm_tn(g, x, dW, N, K, R, N + 8, K, K, splitk=4, flags=ops.GEMM_ATOMIC)
+    assert rel_l2(dW, ref) < 1e-5
+    out = torch.full((N, K), 3.0, dtype=torch.float32, device=dev)
+    ops.gemm_tn(g, x, out, N, K, R, N + 8, K, K)
+    assert rel_l2(out, ref) < 1e-5
+    ops.gemm_tn(g, x, out, N, K, R, N + 8, K, K, flags=ops.GEMM_ACCUM, alpha=0.5)
+    assert rel_l2(out, 1.5 * ref) < 1e-5
+    assert rel_l2(ops.weight_grad_tn(g.contiguous(), x, R, N, K), ref) < 1e-5
+    # (b) batched: dkv[b, j, h, c] = alpha sum_i dS[b, h, i, j] q[b, i, h, c] into the k half of a [b, j, h, 2C] tensor
+    Bn, H, Nr, C = 2, 3, 256, 256
+    dS = (torch.randn(Bn, H, Nr, Nr, generator=gen) * 0.1).to(dev).to(torch.bfloat16)
+    q = torch.randn(Bn, Nr, H, C, generator=gen).to(dev).to(torch.bfloat16)
+    dkv = torch.zeros(Bn, Nr, H, 2 * C, dtype=torch.bfloat16, device=dev)
+    ops.gemm_tn(dS, q, dkv, Nr, C, Nr, Nr, H * C, 2 * H * C, nbatch=Bn * H, nb1=H, sa=(H * Nr * Nr, Nr * Nr), sb=(Nr * H * C, C),
+                sc=(Nr * 2 * H * C, 2 * C), alpha=0.25)
+    ops.gemm_tn(dS, q, dkv, Nr, C, Nr, Nr, H * C, 2 * H * C, nbatch=Bn * H, nb1=H, sa=(H * Nr * Nr, Nr * Nr), sb=(Nr * H * C, C),
+                sc=(Nr * 2 * H * C, 2 * C), c_off=C)
+    refk = torch.einsum("bhij,bihc->bjhc", dS.double(), q.double())
+    assert rel_l2(dkv[..., :C], 0.25 * refk) < 4e-3        # bf16 output rounding
+    assert rel_l2(dkv[..., C:], refk) < 4e-3
+    with pytest.raises(ValueError):
+        ops.gemm_tn(g, x, dW, N, K, R, N + 8, K, K, splitk=4)              # split-K without atomics
