@@ -67,7 +67,8 @@ extern "C" int dfold_cast_bf16_f32(const void* src, float* dst, int64_t n, void*
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wf,
                                                                bf16_t* __restrict__ Wd, int CO, int CI) {
-  __shared__ bf16_t t[32][32][26];
+  // rows of 32 x 26 + 2 elements: 417 dwords apart, so that the Wd phase (lanes along co) hits 32 different banks
+  __shared__ bf16_t t[32][32 * 26 + 2];
   const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
   // load: for each co row, 32 ci x 25 taps = 800 contiguous floats
   for (int r = 0; r < 32; ++r) {
@@ -75,18 +76,18 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* __re
     if (co >= CO) break;
     const float* src = W + ((long)co * CI + ci0) * 25;
     const int lim = min(32, CI - ci0) * 25;
-    for (int e = threadIdx.x; e < lim; e += 256) t[r][e / 25][e % 25] = f2bf(src[e]);
+    for (int e = threadIdx.x; e < lim; e += 256) t[r][(e / 25) * 26 + e % 25] = f2bf(src[e]);
   }
   __syncthreads();
   // Wf rows (co, tap): 32 contiguous ci
   for (int e = threadIdx.x; e < 32 * 25 * 32; e += 256) {
     const int ci = e & 31, tap = (e >> 5) % 25, r = e / (32 * 25);
-    if (co0 + r < CO && ci0 + ci < CI) Wf[((long)(co0 + r) * 25 + tap) * CI + ci0 + ci] = t[r][ci][tap];
+    if (co0 + r < CO && ci0 + ci < CI) Wf[((long)(co0 + r) * 25 + tap) * CI + ci0 + ci] = t[r][ci * 26 + tap];
   }
   // Wd rows (ci, tap'): 32 contiguous co
   for (int e = threadIdx.x; e < 32 * 25 * 32; e += 256) {
     const int r = e & 31, tap = (e >> 5) % 25, ci = e / (32 * 25);
-    if (co0 + r < CO && ci0 + ci < CI) Wd[((long)(ci0 + ci) * 25 + tap) * CO + co0 + r] = t[r][ci][24 - tap];
+    if (co0 + r < CO && ci0 + ci < CI) Wd[((long)(ci0 + ci) * 25 + tap) * CO + co0 + r] = t[r][ci * 26 + 24 - tap];
   }
 }
 

@@ -419,6 +419,7 @@ class IpaCoreFn(Function):
         del P            # the backward reads the bf16 probabilities (what the forward products consumed)
         ctx.save_for_backward(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, Pb, pz)
         ctx.dims = (B, F, N, H, C, CZ, PZ)
+        ctx.ctr = ctr if _ipa_fused_ok(N, C, q_pts, v_pts) else None      # the backward's point terms use the same centre
         return o, o_pt, o_pair
 
     @staticmethod
@@ -442,7 +443,7 @@ class IpaCoreFn(Function):
         dv_pts = torch.empty_like(v_pts)
         dhw = torch.zeros(H, dtype=torch.float32, device=dev)
         check(L.dfold_ipa_softmax_bwd(_p(Pb), _p(dP), _p(q_pts), _p(k_pts), _p(v_pts), _p(do_pt), _p(hw), _p(dP), _p(dSb),
-                                      _p(dq_pts), _p(dhw), _p(_ipa_centre(k_pts)), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                      _p(dq_pts), _p(dhw), _p(ctx.ctr if ctx.ctr is not None else _ipa_centre(k_pts)), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
                                       stream()),
               "dfold_ipa_softmax_bwd")
         dS = dP
