@@ -44,6 +44,16 @@ def main():
         ev.append((key, e0, e1))
         return r
     ops.gemm = timed
+    orig_tn = ops.gemm_tn
+
+    def timed_tn(A, B, C, M, N, K, *a_, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_tn(A, B, C, M, N, K, *a_, **kw)
+        e1.record()
+        ev.append(((M, N, K, kw.get("nbatch", 1), str(C.dtype).replace("torch.", ""), "tn", kw.get("flags", 0)), e0, e1))
+        return r
+    ops.gemm_tn = timed_tn
     import dynamicpdb_amd.model.functional as F_
     import dynamicpdb_amd.model.triangle as T_
     for mod in (F_, T_):

@@ -34,6 +34,17 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     d = _lib.GemmDesc()
     assert L.dfold_gemm_bf16(byref(d), c_void_p(0)) == -1
     assert L.dfold_gemm_bf16(None, c_void_p(0)) == -1
+    from ctypes import c_float, c_int32, c_int64
+    one = c_void_p(16)           # a non-null, 16-byte aligned token: validation must fail before anything dereferences it
+    # direct conv weight gradient: channel counts off its tiles (256 / 64), ragged N_res, frame range outside the grid
+    for (ca, cb, n, f0, nf) in ((100, 64, 64, 0, 2), (256, 40, 64, 0, 2), (256, 64, 60, 0, 2), (256, 64, 64, 3, 2)):
+        assert L.dfold_conv_wgrad_tn(one, one, one, c_int32(ca), c_int32(cb), c_int32(1), c_int32(8), c_int32(68), c_int32(n),
+                                     c_int32(f0), c_int32(nf), c_int32(0), c_int32(0), c_void_p(0)) == -1
+    # reduction-major GEMM: M off the 256 tile, K not a multiple of 64 * splitk, split-K without atomics
+    z = c_int64(0)
+    for (m, k, sk, fl) in ((200, 64, 1, 0), (256, 96, 1, 0), (256, 128, 2, 0)):
+        assert L.dfold_gemm_tn_bf16(one, one, one, c_int32(m), c_int32(256), c_int64(k), c_int64(256), c_int64(256), c_int64(256),
+                                    c_int32(1), c_int32(1), z, z, z, z, z, z, c_int32(sk), c_int32(fl), c_float(1.0), c_void_p(0)) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):
@@ -391,3 +402,16 @@ def test_conv_tower_grid_pool_is_bounded():
         assert float(a.float().abs().sum()) == 0.0
     finally:
         ops.ConvTower.POOL_CAP_BYTES = cap
+
+
+def test_transpose_read_kernels_addressing_emulation():
+    """The data movement of the two ds_read_b64_tr_b16 kernels (csrc/conv_wgrad_tn.hip, csrc/tn_gemm.hip) -- LDS-DMA image, XOR
+    keys, transpose-read gather, MFMA operand / accumulator layouts, epilogue addressing -- replayed on the host on integer
+    operands against the plain definition of the products (scripts/emulate_*.py: the formulas are transcribed from the kernels;
+    this guards the transcription and the layout conventions, the GPU tests guard the kernels)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import emulate_tn_gemm
+    import emulate_wgrad_tn
+    assert emulate_wgrad_tn.run(CA=256, CB=64, Wn=1, F=2, N=64, check_wgs=2) == (0, 2)
+    assert emulate_wgrad_tn.run(CA=256, CB=128, Wn=1, F=1, N=64, flip=1, seed=4, check_wgs=1) == (0, 1)
+    assert emulate_tn_gemm.run(lda=256, ldb=256, seed=2) == (0, 0)
