@@ -97,11 +97,14 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         return r
 
     ops.gemm = timed_gemm
+    ops._wgrad_tn_events = wg_events = []
     try:
         trainer.update_fn(batch, step_optimizer=False)
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+        ops._wgrad_tn_events = None
+    wg_ms = [e0.elapsed_time(e1) for e0, e1 in wg_events]
     ms = [e0.elapsed_time(e1) for e0, e1 in events]
     avg_s = sum(ms) / len(ms) * 1e-3
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
@@ -112,10 +115,20 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         with open(pmc) as fh:
             c = json.load(fh)
         traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
+    second = None
+    if wg_ms:      # the second-largest kernel of the step: the conv weight gradient (same algorithmic FLOPs per launch)
+        wavg = sum(wg_ms) / len(wg_ms) * 1e-3
+        wt = None
+        if traffic is not None and "wgrad_tn" in c:
+            wt = int((2.0 * c["wgrad_tn"]["FETCH_SIZE_kb"] + c["wgrad_tn"]["WRITE_SIZE_kb"]) * 1024)
+        second = {"kernel": "conv_wgrad_tn_kernel (5x5 conv weight gradient straight from the channels-last grids)", "bound": "mfma",
+                  "achieved": round(flops / wavg / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(flops / wavg / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": wt, "launches": len(wg_ms),
+                  "avg_launch_ms": round(wavg * 1e3, 4), "flop_per_launch": flops}
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "kernel": "dfold_mfma_gemm320_kernel<1, 5, true> (5x5 conv implicit GEMM, halo form, forward + dgrad launches)", "launches": len(ms),
-            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops,
+            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
             "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "
                     "binary on all-zero operands runs 1.85 PFLOP/s = 0.74 of the peak (scripts/exp_conv_dvfs.py), hipBLASLt "
                     "on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s (scripts/bench_conv.py library); "
