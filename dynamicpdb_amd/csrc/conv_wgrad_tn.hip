@@ -7,7 +7,7 @@
 // fast one ([window][frame + 4][residue + 4][C] grids), whereas v_mfma_f32_32x32x16_bf16 wants 8 consecutive k values of
 // one row / column per lane.  The engine of gemm_bf16.hip therefore runs this product on transposed, column-shifted COPIES
 // of the grids (dfold_grid_transpose_shift: 6 copies per weight gradient).  This kernel needs no copies: K tiles of
-// 64 cells x 256 / 320 channels go HBM -> LDS as they lie (LDS-DMA, 16-byte chunks, rows stay channel-contiguous) and the
+// 64 cells of the grids (all channels of the tile per cell) go HBM -> LDS as they lie (LDS-DMA, 16-byte chunks, rows stay channel-contiguous) and the
 // MFMA fragments are read with ds_read_b64_tr_b16, the LDS transpose read of gfx950: a 16-lane group fetches a
 // [4 cells][16 channels] block and every lane receives the 4 cells of ITS channel.  Two such reads make one 8-deep
 // fragment.  Which 8 cells of a K16 block a lane holds is a free choice as long as the A and the B fragment agree (a
@@ -44,7 +44,6 @@
 #define TSTAGE (TA_BYTES + TB_BYTES)  // 41 KiB
 #define TNSTAGE 3
 #define TNJ 5
-#define TN_DMA_PER_STEP 6
 
 typedef __attribute__((address_space(3))) void* tn_lds_ptr_t;
 typedef __attribute__((address_space(3))) char tn_lchar;   // LDS byte pointer: 32-bit address arithmetic
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     // group A (one wave per SIMD): per K step [28 fragment reads][4 x 10 MFMAs], the 6 DMA pieces of tile s + 2 between the
     // first 20 MFMAs, the reads of K16 blocks 2 / 3 behind the MFMAs that free their register set
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 6 = DMA pieces per wave and K step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       tn_ldfrag<0>(af[0], bfr[0], fa, fb);
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
   } else {
     // group B (the second wave of every SIMD) runs half a K step behind: it issues the second half of the previous tile's
     // MFMAs while group A reads its fragments, and reads the current tile after A
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 6 = DMA pieces per wave and K step
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     tn_ldfrag<0>(af[0], bfr[0], fa, fb);
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     tn_ldfrag<3>(af[1], bfr[1], fa, fb);
     next_stage();
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 6 = DMA pieces per wave and K step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       TN_WAIT(14, 0);
