@@ -97,13 +97,27 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         return r
 
     ops.gemm = timed_gemm
-    ops._wgrad_tn_events = wg_events = []
+    # the direct weight-gradient launches: the library entry point itself is wrapped (an instance attribute on the CDLL
+    # object shadows the exported function for the duration of this one step)
+    from dynamicpdb_amd import _lib
+    L = _lib.lib()
+    wg_orig, wg_events = L.dfold_conv_wgrad_tn, []
+
+    def timed_wgrad(*a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = wg_orig(*a)
+        e1.record()
+        wg_events.append((e0, e1))
+        return rc
+
+    L.dfold_conv_wgrad_tn = timed_wgrad
     try:
         trainer.update_fn(batch, step_optimizer=False)
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
-        ops._wgrad_tn_events = None
+        del L.dfold_conv_wgrad_tn        # the exported function is visible again
     wg_ms = [e0.elapsed_time(e1) for e0, e1 in wg_events]
     ms = [e0.elapsed_time(e1) for e0, e1 in events]
     avg_s = sum(ms) / len(ms) * 1e-3

@@ -328,9 +328,6 @@ def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):
 _WGRAD_TN = os.environ.get("DFOLD_WGRAD_TN", "1") != "0"
 
 
-_wgrad_tn_events = None     # bench.py: a list here collects (start, end) HIP events around every direct weight-gradient launch
-
-
 def wgrad_tn_ok(g, CI, CO):
     """shapes the direct (transpose-read) weight-gradient kernel covers: frame rows of whole 64-cell K chunks, the wider
     channel count a multiple of the 256-row tile, the narrower of the 64-channel column tile"""
@@ -354,16 +351,9 @@ def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=
         F = min(g.F, f_lo + F + 2) - lo
         f_lo = lo
         a, b, flip = x, gy, 1
-    ev = _wgrad_tn_events
-    if ev is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     check(_lib.lib().dfold_conv_wgrad_tn(_p(a), _p(b), _p(dwg), c_int32(a.shape[-1]), c_int32(b.shape[-1]), c_int32(g.Wn),
                                          c_int32(g.Fp), c_int32(g.Wp), c_int32(g.N), c_int32(f_lo), c_int32(F), c_int32(flip),
                                          c_int32(1 if accumulate else 0), stream()), "dfold_conv_wgrad_tn")
-    if ev is not None:
-        e1.record()
-        ev.append((e0, e1))
     return dwg
 
 
