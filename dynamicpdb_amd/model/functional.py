@@ -304,6 +304,7 @@ def _zT(z2d):
 
 
 _IPA_FUSED = os.environ.get("DFOLD_IPA_FUSED", "1") != "0"     # A/B switch: "0" = the unfused round-2 chain
+_IPA_BWD_FUSED = os.environ.get("DFOLD_IPA_BWD_FUSED", "1") != "0"   # "0": the product / VALU row pass chain instead of csrc/ipa_fused_bwd.hip
 _IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
 _IPA_WS = {}
 
@@ -430,6 +431,8 @@ class IpaCoreFn(Function):
         HC, NN, dev = H * C, N * N, q.device
         alpha = math.sqrt(1.0 / (3 * C))
         do, do_pair, do_pt = do.contiguous(), do_pair.contiguous(), do_pt.contiguous()
+        if _IPA_BWD_FUSED and _ipa_fused_ok(N, C, q_pts, v_pts):
+            return IpaCoreFn._backward_fused(ctx, L, do, do_pt, do_pair)
         # dP = do v^T + do_pair pz^T
         dP = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
         gemm(do, kv, dP, N, N, C, a_rows=rows_plain(HC), c_rows=rows_plain(N), ldb=2 * HC, nbatch=B * F * H, nb1=H,
@@ -455,7 +458,17 @@ class IpaCoreFn(Function):
         dq = torch.empty_like(q)
         gemm(dSb, kT, dq, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(HC), ldb=N, nbatch=nb, nb1=H,
              sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * HC, C), alpha=alpha)
-        # dk = alpha dS^T q ; dv = P^T do
+        dkv = IpaCoreFn._backward_dkv(ctx, dSb, do)
+        return IpaCoreFn._backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw)
+
+    @staticmethod
+    def _backward_dkv(ctx, dSb, do):
+        """dk = alpha dS^T q ; dv = P^T do  into one [B,F,N,H*2C] tensor"""
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        B, F, N, H, C, CZ, PZ = ctx.dims
+        HC, NN = H * C, N * N
+        alpha = math.sqrt(1.0 / (3 * C))
+        nb = B * F * H
         dkv = torch.empty_like(kv)
         if ops.gemm_tn_ok(N, C, N):
             # the reduction runs over the query index, the slow axis of dS / P and of q / do: no transposed copies
@@ -463,7 +476,7 @@ class IpaCoreFn(Function):
                         sc=(N * 2 * HC, 2 * C), alpha=alpha)
             ops.gemm_tn(Pb, do, dkv, N, C, N, N, HC, 2 * HC, nbatch=nb, nb1=H, sa=(H * NN, NN), sb=(N * HC, C),
                         sc=(N * 2 * HC, 2 * C), c_off=C)
-            return IpaCoreFn._backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw)
+            return dkv
         dSbT = ops.transpose_bf16(dSb, N, N, nbatch=nb, nb1=1, bs_src=(NN, 0))
         qT = ops.transpose_bf16(q, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
         gemm(dSbT, qT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
@@ -473,7 +486,44 @@ class IpaCoreFn(Function):
         doT = ops.transpose_bf16(do, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
         gemm(PbT, doT, dkv, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(2 * HC), ldb=N, nbatch=nb, nb1=H,
              sa=(H * NN, NN), sb=(H * C * N, C * N), sc=(N * 2 * HC, 2 * C), c_off=C)
-        del PbT, doT
+        return dkv
+
+    @staticmethod
+    def _backward_fused(ctx, L, do, do_pt, do_pair):
+        """row pass in one launch (csrc/ipa_fused_bwd.hip): no fp32 dP, no transposed copy of k for dq; the pair-value term of dP
+        leaves its product once as bf16"""
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        B, F, N, H, C, CZ, PZ = ctx.dims
+        HC, NN, dev = H * C, N * N, q.device
+        alpha = math.sqrt(1.0 / (3 * C))
+        nb = B * F * H
+        ws = _ipa_workspace(dev)
+        NPv = (N + 63) // 64 * 64
+        ctr = ctx.ctr if ctx.ctr is not None else _ipa_centre(k_pts)
+        dPp = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
+        gemm(do_pair, pz, dPp, F * H, N, PZ, a_rows=rows_grid(PZ, H, F, F, N * H), c_rows=rows_plain(NN), ldb=PZ,
+             nbatch=B * N, nb1=N, sa=(F * N * H * PZ, H * PZ), sb=(NN * PZ, N * PZ), sc=(F * H * NN, N))
+        DOP = ws.get("DOP/%d" % N, (B * F, H, N, 224))
+        VP = ws.get("VP/%d" % N, (B * F, H, N, 224))
+        KT = ws.get("KT/%d" % N, (B * F, H, 352, NPv))       # zero-filled once: pad rows / columns are never written
+        check(L.dfold_ipa_bwd_prep(_p(do_pt), _p(v_pts), _p(k_pts), _p(ctr), _p(DOP), _p(VP), _p(KT), c_int32(B), c_int32(F),
+                                   c_int32(N), c_int32(H), c_int32(NPv), stream()), "dfold_ipa_bwd_prep")
+        ops.transpose_bf16(kv, N, C, ld_src=2 * HC, out=KT, nbatch=nb, nb1=H, bs_src=(N * 2 * HC, 2 * C),
+                           bs_dst=(H * 352 * NPv, 352 * NPv), ld_dst=NPv)                          # rows 0..255 = k^T
+        dS = torch.empty((B, F, H, N, N), dtype=torch.float32, device=dev)
+        dSb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
+        dq = torch.empty_like(q)
+        dq_pts = torch.empty_like(q_pts)
+        dhw = torch.zeros(H, dtype=torch.float32, device=dev)
+        check(L.dfold_ipa_fused_bwd(_p(do), _p(kv), _p(DOP), _p(VP), _p(KT), _p(Pb), _p(dPp), _p(q_pts), _p(hw), _p(ctr), _p(dS),
+                                    _p(dSb), _p(dq), _p(dq_pts), _p(dhw), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                    c_int32(NPv), ctypes_float(alpha), stream()), "dfold_ipa_fused_bwd")
+        del dPp
+        dk_pts = torch.empty_like(k_pts)
+        dv_pts = torch.empty_like(v_pts)
+        check(L.dfold_ipa_col_bwd(_p(Pb), _p(dS), _p(q_pts), _p(k_pts), _p(do_pt), _p(hw), _p(dk_pts), _p(dv_pts),
+                                  c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()), "dfold_ipa_col_bwd")
+        dkv = IpaCoreFn._backward_dkv(ctx, dSb, do)
         return IpaCoreFn._backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw)
 
     @staticmethod

@@ -184,6 +184,19 @@ int dfold_ipa_opt_fwd(const float* P, const float* v_pts, float* o_pt, int32_t B
 int dfold_ipa_softmax_bwd(const void* P_bf16, const float* dP, const float* q_pts, const float* k_pts, const float* v_pts,
                           const float* do_pt, const float* hw, float* dS, void* dS_bf16, float* dq_pts, float* dhw,
                           const float* ctr, int32_t B, int32_t F, int32_t N, int32_t H, void* stream);
+/* Fused row pass of the backward (csrc/ipa_fused_bwd.hip; N % 8 == 0, N <= 512, 256 channels per head, 8 / 12 points): one launch
+ * for  g = do v^T + do_pt (v_pts - ctr)^T + dP_pair,  dS = P (g - <g>_P)  (fp32 and bf16),  dq = alpha dS k (bf16),
+ * dq_pts = hw dS (k_pts - ctr),  dhw (atomics: zero it first) -- the point terms ride on the matrix cores as bf16-split columns.
+ * dfold_ipa_bwd_prep writes the augmented operands: DOP, VP bf16 [B*F,H,N,224] (do_pt / v_pts - ctr as three bf16 pieces, six
+ * product blocks of 36) and rows 256..351 of KT bf16 [B*F,H,352,NP] (k_pts - ctr and |k_pts - ctr|^2, three pieces x 32 rows,
+ * key-contiguous; rows 0..255 = k^T of the head are the caller's: dfold_transpose_bf16; NP = N rounded up to 64, pad columns and
+ * rows 25..31 of each piece zero).  dP_pair_bf16 [B,F,H,N,N] or NULL: the pair-value term of dP. */
+int dfold_ipa_bwd_prep(const float* do_pt, const float* v_pts, const float* k_pts, const float* ctr, void* DOP_bf16, void* VP_bf16,
+                       void* KT_bf16, int32_t B, int32_t F, int32_t N, int32_t H, int32_t NP, void* stream);
+int dfold_ipa_fused_bwd(const void* do_bf16, const void* kv_bf16, const void* DOP_bf16, const void* VP_bf16, const void* KT_bf16,
+                        const void* P_bf16, const void* dP_pair_bf16, const float* q_pts, const float* hw, const float* ctr,
+                        float* dS, void* dS_bf16, void* dq_bf16, float* dq_pts, float* dhw, int32_t B, int32_t F, int32_t N,
+                        int32_t H, int32_t NP, float alpha, void* stream);
 /* column pass of the backward: dk_pts, dv_pts (P_bf16 as above) */
 int dfold_ipa_col_bwd(const void* P_bf16, const float* dS, const float* q_pts, const float* k_pts, const float* do_pt,
                       const float* hw, float* dk_pts, float* dv_pts, int32_t B, int32_t F, int32_t N, int32_t H,

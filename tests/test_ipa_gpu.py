@@ -49,9 +49,13 @@ def test_ipa_opt_fwd_direct(N):
     assert (out.double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("bwd_fused", [False, True])
 @pytest.mark.parametrize("B,F,N", [(2, 3, 24), (1, 2, 72), (1, 1, 328)])
-def test_ipa_core_fwd_bwd(B, F, N):
+def test_ipa_core_fwd_bwd(B, F, N, bwd_fused, monkeypatch):
+    """bwd_fused: the row pass of the backward as one launch (csrc/ipa_fused_bwd.hip) instead of the product / accumulate /
+    VALU row pass / product chain -- same fp64 reference, same tolerances"""
     from dynamicpdb_amd.model import functional as Fm
+    monkeypatch.setattr(Fm, "_IPA_BWD_FUSED", bwd_fused)
     dev = torch.device("cuda:0")
     H, C, CZ, PZ = 8, 256, 128, 32
     gen = torch.Generator(device="cpu").manual_seed(5)
@@ -348,3 +352,41 @@ def test_ipa_fused_forward_protein_scale_coordinates(B, F, N):
     assert rel_l2(o, ro) < 6e-3 and rel_l2(o_pair, ropair) < 1e-2
     assert e_pt < (2e-3 if N <= 256 else 5e-3), e_pt       # logit rounding ~ eps * hw * R^2 grows with the chain radius R
     assert torch.isfinite(o.float()).all() and torch.isfinite(o_pt).all()
+
+
+@pytest.mark.parametrize("B,F,N", [(1, 2, 256), (2, 1, 40), (1, 1, 512)])
+def test_ipa_fused_backward_protein_scale_coordinates(B, F, N, monkeypatch):
+    """The fused row pass of the backward (csrc/ipa_fused_bwd.hip) with points of protein scale (global-frame coordinates of tens
+    of Angstrom, off-centre) against the chain it replaces (fp32 VALU point terms, csrc/ipa_attn.hip): every gradient of the
+    attention core, both workgroup shapes, masked keys / queries.  The bf16-split point columns must carry fp32-grade accuracy:
+    dq_pts leans on the rows of dS summing to zero."""
+    from dynamicpdb_amd.model import functional as Fm
+    dev = torch.device("cuda:0")
+    H, C, CZ, PZ = 8, 256, 128, 32
+    gen = torch.Generator(device="cpu").manual_seed(300 + N)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=gen) * scale).to(dev)
+    steps = torch.randn(B, F, N, 3, generator=gen)
+    steps = 3.8 * steps / steps.norm(dim=-1, keepdim=True)
+    chain = (torch.cumsum(steps, 2) + torch.tensor([40.0, -25.0, 10.0])).to(dev)[:, :, :, None, None, :]
+    vals = dict(q=rn(B, F, N, H * C).to(torch.bfloat16), kv=rn(B, F, N, 2 * H * C).to(torch.bfloat16),
+                q_pts=chain + rn(B, F, N, H, 8, 3, scale=2.0), k_pts=chain + rn(B, F, N, H, 8, 3, scale=2.0),
+                v_pts=chain + rn(B, F, N, H, 12, 3, scale=2.0), z=rn(B, N, N, CZ).to(torch.bfloat16), w_b=rn(H, CZ, scale=0.1),
+                w_dz=rn(PZ, CZ, scale=0.1), b_dz=rn(PZ, scale=0.1), hw=(0.05 + 0.02 * torch.rand(H, generator=gen)).to(dev))
+    mask = torch.ones(B, F, N, device=dev)
+    mask[0, 0, N - 5:] = 0
+    mask[0, 0, 3] = 0
+    go, gpt, gpair = rn(B, F, N, H * C).to(torch.bfloat16), rn(B, F, N, H, 12, 3, scale=0.3), rn(B, F, N, H * PZ).to(torch.bfloat16)
+    names = ["q", "kv", "q_pts", "k_pts", "v_pts", "z", "w_b", "w_dz", "b_dz", "hw"]
+    grads = {}
+    for fused in (False, True):
+        monkeypatch.setattr(Fm, "_IPA_BWD_FUSED", fused)
+        leaves = [vals[n].clone().requires_grad_(True) for n in names]
+        o, o_pt, o_pair = Fm.IpaCoreFn.apply(*leaves[:9], mask, leaves[9])
+        torch.autograd.backward([o, o_pt, o_pair], [go, gpt, gpair])
+        grads[fused] = [t.grad.double() for t in leaves]
+    tol = dict(q=1e-2, kv=1e-2, q_pts=3e-3, k_pts=3e-3, v_pts=3e-3, z=1.5e-2, w_b=1e-2, w_dz=1e-2, b_dz=1e-2, hw=1e-2)
+    errs = {n: rel_l2(a, b) for n, a, b in zip(names, grads[True], grads[False])}
+    print(f"[fused IPA backward N={N}] " + ", ".join(f"{n} {e:.1e}" for n, e in errs.items()))
+    for n in names:
+        assert errs[n] < tol[n], (n, errs[n])
+        assert torch.isfinite(grads[True][names.index(n)]).all(), n
