@@ -40,6 +40,12 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     for (ca, cb, n, f0, nf) in ((100, 64, 64, 0, 2), (256, 40, 64, 0, 2), (256, 64, 60, 0, 2), (256, 64, 64, 3, 2)):
         assert L.dfold_conv_wgrad_tn(one, one, one, c_int32(ca), c_int32(cb), c_int32(1), c_int32(8), c_int32(68), c_int32(n),
                                      c_int32(f0), c_int32(nf), c_int32(0), c_int32(0), c_void_p(0)) == -1
+    # fused IPA backward: N_res not a multiple of 8 / above 512, key pitch not a multiple of 64
+    for (n, npad) in ((20, 64), (520, 576), (64, 72)):
+        assert L.dfold_ipa_fused_bwd(one, one, one, one, one, one, None, one, one, one, one, one, one, one, one, c_int32(1), c_int32(1),
+                                     c_int32(n), c_int32(8), c_int32(npad), c_float(0.1), c_void_p(0)) == -1
+    assert L.dfold_ipa_bwd_prep(one, one, one, one, one, one, one, c_int32(1), c_int32(1), c_int32(64), c_int32(8), c_int32(72),
+                                c_void_p(0)) == -1
     # reduction-major GEMM: M off the 256 tile, K not a multiple of 64 * splitk, split-K without atomics
     z = c_int64(0)
     for (m, k, sk, fl) in ((200, 64, 1, 0), (256, 96, 1, 0), (256, 128, 2, 0)):
