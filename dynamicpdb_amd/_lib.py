@@ -40,6 +40,11 @@ def header_symbols():
     return sorted(set(re.findall(r"^\s*int\s+(dfold_\w+)\s*\(", txt, flags=re.M)))
 
 
+def header_abi_version():
+    with open(HEADER) as fh:
+        return int(re.search(r"^#define\s+DFOLD_ABI_VERSION\s+(\d+)", fh.read(), flags=re.M).group(1))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -55,8 +60,10 @@ def lib():
         for name in header_symbols():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = c_int32
-        if L.dfold_abi_version() != 1:
-            raise RuntimeError("libdfold_hip.so ABI version mismatch")
+        want = header_abi_version()
+        if L.dfold_abi_version() != want:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {L.dfold_abi_version()}, include/dfold_hip.h declares {want} "
+                               "(stale or variant library: rebuild with `python -m dynamicpdb_amd.build_ext --force`)")
         _lib = L
     return _lib
 

@@ -32,23 +32,36 @@ def write_checkpoint(ckpt_path, model, conf, optimizer, epoch, step, logger=None
 
 
 def read_checkpoint(ckpt_path, allow_pickle=None):
-    """Loads with torch's restricted unpickler first (tensors, containers, numbers -- everything this module writes when
-    `conf` is a plain dict / None).  A reference checkpoint carries an OmegaConf object under 'conf'
-    (src/data/utils.py:353-362), which needs the unrestricted pickle loader: that executes code from the file, so it is
-    only used when allowed -- `allow_pickle=True`, or the environment variable DFOLD_TRUSTED_CHECKPOINTS=1 (default: on,
-    matching the reference's own torch.load; set it to 0 to refuse such files)."""
+    """Loads with torch's restricted unpickler (tensors, containers, numbers -- everything this module writes when `conf`
+    is a plain dict / None).  A reference checkpoint carries an OmegaConf object under 'conf' (src/data/utils.py:353-362):
+    the OmegaConf container classes are allow-listed for the restricted loader when omegaconf is importable, so such
+    files load without executing anything from them.  The unrestricted pickle loader (arbitrary code execution from the
+    file) is used only on request -- `allow_pickle=True`, or DFOLD_TRUSTED_CHECKPOINTS=1 in the environment (default: off)
+    -- and says so with a warning that names the file."""
     import pickle
     import warnings
+    safe = []
+    try:                                   # OmegaConf's own containers (no user code): what a reference 'conf' is made of
+        import omegaconf
+        from omegaconf import base, dictconfig, listconfig, nodes
+        safe = [dictconfig.DictConfig, listconfig.ListConfig, base.ContainerMetadata, base.Metadata, nodes.AnyNode,
+                nodes.StringNode, nodes.IntegerNode, nodes.FloatNode, nodes.BooleanNode]
+    except Exception:
+        pass
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", UserWarning)       # "pickle protocol 4" note of the restricted unpickler
+            if safe and hasattr(torch.serialization, "safe_globals"):
+                with torch.serialization.safe_globals(safe):
+                    return torch.load(ckpt_path, map_location='cpu', weights_only=True)
             return torch.load(ckpt_path, map_location='cpu', weights_only=True)
     except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError) as e:
         if allow_pickle is None:
-            allow_pickle = os.environ.get("DFOLD_TRUSTED_CHECKPOINTS", "1") != "0"
+            allow_pickle = os.environ.get("DFOLD_TRUSTED_CHECKPOINTS", "0") == "1"
         if not allow_pickle:
-            raise RuntimeError(f"{ckpt_path} needs the unrestricted pickle loader (it holds non-tensor objects, e.g. an "
-                               "OmegaConf 'conf'); pass allow_pickle=True for files you trust") from e
+            raise RuntimeError(f"{ckpt_path} needs the unrestricted pickle loader (it holds objects outside the allow-list: "
+                               f"{e}); pass allow_pickle=True or set DFOLD_TRUSTED_CHECKPOINTS=1 for files you trust") from e
+        warnings.warn(f"{ckpt_path}: falling back to the UNRESTRICTED pickle loader (code in the file is executed)")
         return torch.load(ckpt_path, map_location='cpu', weights_only=False)
 
 

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     tn_ldfrag<3>(af[1], bfr[1], fa, fb);
     next_stage();
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 6 = DMA pieces per wave and K step
+      // the previous tile's fragment reads still in flight (tn_ldfrag<2>, <3>) read the stage that group A's LDS-DMA of
+      // this step overwrites: they must have left the LDS before the barrier (ordered by a wait, not by latency)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // 6 = DMA pieces per wave and K step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       TN_WAIT(14, 0);

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
     tg_pin<4>();
     tg_ldfrag<3>(af[1], bfr[1], fa0, fb00, fb10);
     for (int s = 1; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the fragment reads of the previous tile still in flight (tg_ldfrag<3>) must have left the LDS before this barrier:
+      // behind it the leading waves' LDS-DMA overwrites exactly that stage (ordered by a wait, not by latency)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const unsigned so = (s & 1) * G_STAGE;

@@ -16,8 +16,12 @@ such as the conv tower reports) and in what order they complete; rank 0's observ
 cuts identical buckets.
 
 A step whose graph differs from the discovered one (a parameter used more often, or one that had no gradient in the
-discovery step) is still reduced exactly -- `finish()` agrees on it across ranks with one small flag collective, reduces
-the affected buckets again / the stray gradients separately -- and the next step re-discovers.
+discovery step) is still reduced exactly -- `finish()` agrees on it across ranks with one small flag collective and reduces
+the late / stray gradients on their own -- and the next step re-discovers.  A bucket in flight is never written: the
+moment a bucket's all-reduce is launched its parameters' `.grad` are detached from the flat buffer (set to None), so a
+late accumulation lands in a fresh tensor of its own (autograd / ConvTower.finalize_layer allocate one) instead of racing
+with the collective on the RCCL stream or being overwritten by the host-staged copy-back; `finish()` averages those late
+tensors separately, adds them to the reduced views and re-attaches the views.
 
 `broadcast_parameters` is DDP's start-up broadcast (train_DFOLD_dynamics.py:615: rank 0's 737.7 MB of parameters, and the
 optimizer state on a resume) -- the reference seeds every rank differently (:419), so without it N ranks would train N
@@ -88,7 +92,7 @@ class GradReducer:
         self._views = {}             # id(param) -> its view into self.flat
         self._fired, self._order = {}, {}
         self._remaining, self._works, self._launched = [], [], []
-        self._redo, self._stray = set(), set()
+        self._late, self._stray = set(), set()
         self._hooks = []
         self._towers = []
         self.rediscoveries = 0
@@ -137,7 +141,7 @@ class GradReducer:
                 p.grad = None
             return
         self._bind_towers()
-        self._redo, self._stray = set(), set()
+        self._late, self._stray = set(), set()
         if self._pending_rebuild:            # last step's graph differed from the discovered one: discover again
             self._pending_rebuild = False
             self.rebuild()
@@ -179,9 +183,9 @@ class GradReducer:
             self._stray.add(self._index[k])
             return
         if self._launched[b]:
-            # more accumulations than discovered: the bucket already holds avg(earlier) + this rank's late part; reducing
-            # it once more in finish() gives avg(earlier) + avg(late) exactly (the first term is equal on all ranks)
-            self._redo.add(b)
+            # more accumulations than discovered: the bucket is in flight (or done) and p.grad was detached from it at
+            # launch, so this accumulation went into a fresh tensor; finish() averages it on its own and adds it to the view
+            self._late.add(self._index[k])
             return
         self._remaining[b] -= 1
         if self._remaining[b] == 0:
@@ -218,6 +222,10 @@ class GradReducer:
         s, e = self.buckets[b]
         self._works[b] = self._reduce_async(self.flat[s:e])
         self._launched[b] = True
+        # nothing may write the bucket while its collective is in flight (RCCL stream / gloo thread + host copy-back): a late
+        # accumulation must find no .grad and allocate its own tensor (re-attached in finish())
+        for p in self._bucket_params[b]:
+            p.grad = None
 
     def finish(self):
         """call after backward: reduce whatever has not been launched yet, wait for every bucket, average; then agree
@@ -242,16 +250,27 @@ class GradReducer:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             self._ev = (ev0, ev1)
-        self._reconcile(dev)
+        # re-attach the views; whatever sits in .grad now is a late accumulation (its own tensor, see _launch)
+        late = {}
+        for p in self.params:
+            v = self._views.get(id(p))
+            if v is None:
+                continue
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                late[self._index[id(p)]] = p.grad
+                self._late.add(self._index[id(p)])
+            p.grad = v
+        self._reconcile(dev, late)
 
-    def _reconcile(self, dev):
-        """one small collective per step: flags [redo bucket b ...| stray parameter i ...], MAX over ranks"""
-        nb = len(self.buckets)
-        flags = torch.zeros(nb + len(self.params), dtype=torch.int32)
-        for b in self._redo:
-            flags[b] = 1
+    def _reconcile(self, dev, late):
+        """one small collective per step: flags [late parameter i ...| stray parameter i ...], MAX over ranks.  late: this
+        rank's late accumulations {parameter index: tensor}"""
+        n = len(self.params)
+        flags = torch.zeros(2 * n, dtype=torch.int32)
+        for i in self._late:
+            flags[i] = 1
         for i in self._stray:
-            flags[nb + i] = 1
+            flags[n + i] = 1
         if self.world > 1:
             stage = self._stage_host or dev.type != "cuda"
             f = flags if stage else flags.to(dev)
@@ -259,10 +278,15 @@ class GradReducer:
             flags = f.cpu()
         if not bool(flags.any()):
             return
-        for b in torch.nonzero(flags[:nb]).flatten().tolist():
-            s, e = self.buckets[b]
-            self._reduce_async(self.flat[s:e])()
-        for i in torch.nonzero(flags[nb:]).flatten().tolist():
+        for i in torch.nonzero(flags[:n]).flatten().tolist():
+            p = self.params[i]
+            g = late.get(i)
+            if g is None:                         # another rank's late accumulation: this rank contributes zeros
+                g = torch.zeros_like(p)
+            g = g.contiguous()
+            self._reduce_async(g.view(-1))()
+            p.grad.add_(g)                        # view = avg(in time) + avg(late)
+        for i in torch.nonzero(flags[n:]).flatten().tolist():
             p = self.params[i]
             if p.grad is None:                    # another rank's stray: this rank contributes zeros
                 p.grad = torch.zeros_like(p)

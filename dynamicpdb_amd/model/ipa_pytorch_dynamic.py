@@ -103,11 +103,7 @@ class BackboneUpdate(nn.Module):
         return F_.linear(s.to(BF16), self.linear.weight, self.linear.bias, out_fp32=True)
 
 
-def _relu(x):
-    y = torch.relu(x)
-    if ops.RELU_MASK_LOG is not None:
-        ops.RELU_MASK_LOG.append((y > 0).float().cpu())
-    return y
+_relu = torch.relu
 
 
 class AngleResnetBlock(nn.Module):
@@ -135,8 +131,6 @@ class AngleResnet(nn.Module):
             F_.linear(_relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
         for l in self.layers:
             h = F_.linear(_relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
-            if ops.RELU_MASK_LOG is not None:
-                ops.RELU_MASK_LOG.append((h > 0).float().cpu())
             a = a + F_.linear(h, l.linear_2.weight, l.linear_2.bias)
         out = F_.linear(_relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
         out = out.view(out.shape[:-1] + (-1, 2))

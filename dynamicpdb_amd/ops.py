@@ -11,10 +11,6 @@ from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU,
                    RowMap, check, stream)
 
 BF16 = torch.bfloat16
-# Debug hook for the gradient-parity tests: when set to a list, every ReLU site of the path appends its 0/1 mask (the
-# one the backward will use) in execution order -- conv tower (inner / outer activation of each residual pair, as
-# [windows, C, F, N]) and the dense ReLUs of AngleResnet.  None (always, outside those tests) = nothing recorded.
-RELU_MASK_LOG = None
 _zero_pages = {}
 _seg_tables = {}
 
@@ -609,8 +605,6 @@ class ConvTower:
                         f_lo=l2, nf=n2, ws=ws)
             if save:
                 saved += [u, v, hn]
-            if RELU_MASK_LOG is not None:
-                RELU_MASK_LOG.extend([(g.interior(t) > 0).permute(0, 3, 1, 2).float().cpu() for t in (u, v)])
             h = hn
         return h, saved
 

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define DFOLD_ABI_VERSION 1
+/* Bumped whenever a signature, a pointer's element type or a struct layout changes (2: round-3 changes of
+ * dfold_ipa_softmax_bwd / dfold_ipa_col_bwd (bf16 probabilities, `ctr`) and dfold_ipa_bias_grad (`nh_pitch`); the
+ * round-4 additions).  The Python binding reads the number from THIS header and refuses a library that reports
+ * another one (dynamicpdb_amd/_lib.py), so a stale or variant .so cannot be called with shifted arguments. */
+#define DFOLD_ABI_VERSION 2
 int dfold_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

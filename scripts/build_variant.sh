@@ -12,7 +12,14 @@ objs=""
 for f in $R/dynamicpdb_amd/csrc/*.hip; do  # the diagnostic switches live in scripts/variants/<src>_lab.hip (the production sources carry none)
   b=$(basename $f .hip)
   if [ "$b" = "${SRC:-gemm_bf16}" ]; then
+    # lab forks are GENERATED from the production source (scripts/make_<kernel>_lab.py) and never tracked; a source without a
+    # generator is built as it is (the -D flags then only reach switches the production source itself carries: none)
     lab=$R/scripts/variants/${b}_lab.hip
+    case $b in
+      ipa_fused) python $R/scripts/make_ipa_lab.py ;;
+      triatt_fused) python $R/scripts/make_triatt_lab.py ;;
+      conv_wgrad_tn) python $R/scripts/make_wgrad_lab.py ;;
+    esac
     [ -f $lab ] && f=$lab
     /opt/rocm/bin/hipcc $FLAGS "$@" -I $R/include -I $R/dynamicpdb_amd/csrc -c $f -o $out/obj_$name/$b.o
     objs="$objs $out/obj_$name/$b.o"

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import canon_quat, compact_window, golden_window, load_golden, max_abs, rel_l2
+from util import canon_quat, compact_window, golden_window, load_golden, max_abs, record_relu_masks, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -234,12 +234,8 @@ def test_gradients_mask_aligned_oracle(gname):
     F, N, seed_w = [int(v) for v in g["meta"][:3]]
     model, _ = _build(F, seed_w, dev)
     w = {k: v.to(dev) for k, v in golden_window(g)[0].items()}   # BASELINE-sized captures: inputs from the seed
-    ops.RELU_MASK_LOG = []
-    try:
+    with record_relu_masks() as masks:
         out = model({k: v.clone() for k, v in w.items()})
-        masks = ops.RELU_MASK_LOG
-    finally:
-        ops.RELU_MASK_LOG = None
     assert len(masks) == 4 * 8 + 7, len(masks)       # 4 tower applications x 8 ReLUs + AngleResnet's 7
     batch = {k: v[None] for k, v in w.items()}
     batch["t"] = w["t"].reshape(1)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import canon_quat, load_golden, max_abs, rel_l2
+from util import canon_quat, load_golden, max_abs, record_relu_masks, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -282,12 +282,8 @@ def test_angle_resnet_module_vs_oracle_fwd_bwd():
     ga = torch.tensor(rng.standard_normal((2, 5, 33, 7, 2), dtype=np.float32))
     m.to(dev)
     sd_, s0d = s.to(dev).requires_grad_(True), s0.to(dev).requires_grad_(True)
-    ops.RELU_MASK_LOG = []
-    try:
+    with record_relu_masks() as masks:
         u, a = m(sd_, s0d)
-        masks = ops.RELU_MASK_LOG
-    finally:
-        ops.RELU_MASK_LOG = None
     assert len(masks) == 7
     ((u * gu.to(dev)).sum() + (a * ga.to(dev)).sum()).backward()
     P = {"ar." + k: v.clone() for k, v in sd.items()}

@@ -67,3 +67,42 @@ def golden_window(g):
     F, N, seed_w = meta[:3]
     stride = meta[4] if len(meta) > 4 else 9973
     return window_from_golden(g), (F, N, seed_w, stride)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def record_relu_masks():
+    """Test-side taps on every ReLU site of the path, in execution order -- the conv tower (inner / outer activation of
+    each residual pair, as [windows, C, F, N]) and the dense ReLUs of AngleResnet: the 0/1 masks the engine's backward
+    will use, fed back to the oracle (oracle.RELU_MASK_FEED) by the gradient-parity tests.  The product carries no hook
+    for this: the tower's saved activations and the outputs of the patched functions are read from outside."""
+    from dynamicpdb_amd import ops
+    from dynamicpdb_amd.model import functional as F_
+    from dynamicpdb_amd.model import ipa_pytorch_dynamic as ipa_mod
+    log = []
+    tower_fwd, relu, linear = ops.ConvTower.forward, ipa_mod._relu, F_.linear
+
+    def tower_forward(self, g, h0, save=True, last_frame_only=False, slot=None):
+        h, saved = tower_fwd(self, g, h0, True, last_frame_only, slot)
+        for i in range(4):
+            log.extend((g.interior(t) > 0).permute(0, 3, 1, 2).float().cpu() for t in (saved[1 + 3 * i], saved[2 + 3 * i]))
+        return h, (saved if save else None)
+
+    def relu_logged(x):
+        y = relu(x)
+        log.append((y > 0).float().cpu())
+        return y
+
+    def linear_logged(*a, **k):
+        y = linear(*a, **k)
+        if k.get("relu"):
+            log.append((y > 0).float().cpu())
+        return y
+
+    ops.ConvTower.forward, ipa_mod._relu, F_.linear = tower_forward, relu_logged, linear_logged
+    try:
+        yield log
+    finally:
+        ops.ConvTower.forward, ipa_mod._relu, F_.linear = tower_fwd, relu, linear
