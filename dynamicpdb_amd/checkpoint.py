@@ -31,36 +31,64 @@ def write_checkpoint(ckpt_path, model, conf, optimizer, epoch, step, logger=None
     os.replace(tmp, ckpt_path)
 
 
+class _AllowListedPickle:
+    """`pickle_module` for torch.load: the standard unpickler (every protocol -- the reference writes protocol 4, which
+    torch's own weights_only unpickler does not read) with `find_class` restricted to what a checkpoint of this path is
+    made of: tensors and their storages, plain containers, numpy scalars, OmegaConf's container / node classes (the
+    reference's 'conf', src/data/utils.py:353-362).  Anything else raises instead of being imported and called."""
+    import pickle as _pickle
+
+    ALLOWED = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "set"), ("builtins", "frozenset"),
+        ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"),
+        ("builtins", "str"), ("builtins", "bool"), ("builtins", "complex"), ("builtins", "bytes"), ("builtins", "slice"),
+        ("typing", "Any"), ("typing", "Union"), ("typing", "Optional"), ("typing", "Dict"), ("typing", "List"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_tensor"),
+        ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+        ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "dtype"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+    }
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            ok = ((module, name) in _AllowListedPickle.ALLOWED
+                  or (module == "torch" and (name.endswith("Storage") or name in _AllowListedPickle._torch_dtypes()))
+                  or (module.split(".")[0] == "omegaconf" and name[:1].isupper()))
+            if not ok:
+                raise _AllowListedPickle._pickle.UnpicklingError(
+                    f"global {module}.{name} is not on the checkpoint allow-list (dynamicpdb_amd/checkpoint.py)")
+            return super().find_class(module, name)
+
+    @staticmethod
+    def _torch_dtypes():
+        return {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
+
+    @classmethod
+    def load(cls, f, **kw):
+        return cls.Unpickler(f, **kw).load()
+
+    Pickler = _pickle.Pickler
+    dump, dumps = _pickle.dump, _pickle.dumps
+    __name__ = "dynamicpdb_amd.checkpoint._AllowListedPickle"
+
+
 def read_checkpoint(ckpt_path, allow_pickle=None):
-    """Loads with torch's restricted unpickler (tensors, containers, numbers -- everything this module writes when `conf`
-    is a plain dict / None).  A reference checkpoint carries an OmegaConf object under 'conf' (src/data/utils.py:353-362):
-    the OmegaConf container classes are allow-listed for the restricted loader when omegaconf is importable, so such
-    files load without executing anything from them.  The unrestricted pickle loader (arbitrary code execution from the
-    file) is used only on request -- `allow_pickle=True`, or DFOLD_TRUSTED_CHECKPOINTS=1 in the environment (default: off)
-    -- and says so with a warning that names the file."""
+    """Loads a checkpoint WITHOUT executing anything from the file: an allow-listed unpickler (`_AllowListedPickle`:
+    tensors, containers, numbers, OmegaConf nodes; every pickle protocol -- the reference and `write_checkpoint` use
+    protocol 4).  The unrestricted pickle loader (arbitrary code execution from the file) is used only on request --
+    `allow_pickle=True`, or DFOLD_TRUSTED_CHECKPOINTS=1 in the environment (default: off) -- and says so with a warning
+    that names the file."""
     import pickle
     import warnings
-    safe = []
-    try:                                   # OmegaConf's own containers (no user code): what a reference 'conf' is made of
-        import omegaconf
-        from omegaconf import base, dictconfig, listconfig, nodes
-        safe = [dictconfig.DictConfig, listconfig.ListConfig, base.ContainerMetadata, base.Metadata, nodes.AnyNode,
-                nodes.StringNode, nodes.IntegerNode, nodes.FloatNode, nodes.BooleanNode]
-    except Exception:
-        pass
     try:
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", UserWarning)       # "pickle protocol 4" note of the restricted unpickler
-            if safe and hasattr(torch.serialization, "safe_globals"):
-                with torch.serialization.safe_globals(safe):
-                    return torch.load(ckpt_path, map_location='cpu', weights_only=True)
-            return torch.load(ckpt_path, map_location='cpu', weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError) as e:
+        return torch.load(ckpt_path, map_location='cpu', weights_only=False, pickle_module=_AllowListedPickle)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, TypeError, ImportError) as e:
         if allow_pickle is None:
             allow_pickle = os.environ.get("DFOLD_TRUSTED_CHECKPOINTS", "0") == "1"
         if not allow_pickle:
-            raise RuntimeError(f"{ckpt_path} needs the unrestricted pickle loader (it holds objects outside the allow-list: "
-                               f"{e}); pass allow_pickle=True or set DFOLD_TRUSTED_CHECKPOINTS=1 for files you trust") from e
+            raise RuntimeError(f"{ckpt_path} needs the unrestricted pickle loader ({e}); pass allow_pickle=True or set "
+                               "DFOLD_TRUSTED_CHECKPOINTS=1 for files you trust") from e
         warnings.warn(f"{ckpt_path}: falling back to the UNRESTRICTED pickle loader (code in the file is executed)")
         return torch.load(ckpt_path, map_location='cpu', weights_only=False)
 

@@ -68,8 +68,9 @@ class FullScoreNetwork(nn.Module):
         angles_pred = self._apply_mask(model_out['angles'], gt_angles, fm)
         unorm_angles = self._apply_mask(model_out['unorm_angles'], gt_angles, fm)
         rigids = model_out['final_rigids']
-        with torch.no_grad():   # atoms do not enter the live loss terms (train_DFOLD_dynamics.py:1367-1373)
-            atom14, atom37 = G.frames_to_atoms_hip(rigids, angles_pred, feats['aatype'])
+        # inside autograd like the reference (:532-538): the live loss terms do not read the atoms (train_DFOLD_dynamics.py:
+        # 1367-1373), so the node's backward normally never runs; re-enabling bb_atom / dist_mat terms just works
+        atom14, atom37 = G.frames_to_atoms_hip(rigids, angles_pred, feats['aatype'])
         pred_out = {'angles': angles_pred, 'unorm_angles': unorm_angles, 'rot_score': model_out['rot_score'],
                     'trans_score': model_out['trans_score'], 'rigids': rigids, 'atom37': atom37, 'atom14': atom14,
                     'rigid_update': model_out['rigid_update']}

@@ -74,20 +74,64 @@ def residue_tables(device):
     return t
 
 
-def frames_to_atoms_hip(t7, angles, aatype):
-    """device path of frames_to_atoms: one HIP launch (csrc/atoms.hip); no gradient (the live loss does not use atoms)."""
+def _atoms_launch(t7c, ang, aa, P):
     from ctypes import c_int64
     from .. import _lib
     from ..ops import _p
-    T = residue_tables(t7.device)
-    lead = t7.shape[:-1]
-    P = t7.numel() // 7
-    t7c, ang = t7.detach().reshape(P, 7).float().contiguous(), angles.detach().reshape(P, 14).float().contiguous()
-    aa = aatype.reshape(P).long().contiguous()
-    a14 = torch.empty((P, 14, 3), dtype=torch.float32, device=t7.device)
-    a37 = torch.empty((P, 37, 3), dtype=torch.float32, device=t7.device)
+    T = residue_tables(t7c.device)
+    a14 = torch.empty((P, 14, 3), dtype=torch.float32, device=t7c.device)
+    a37 = torch.empty((P, 37, 3), dtype=torch.float32, device=t7c.device)
     _lib.check(_lib.lib().dfold_frames_to_atoms(_p(t7c), _p(ang), _p(aa), _p(T["default_frames"]), _p(T["atom14_group"]),
                                                 _p(T["atom14_mask"]), _p(T["atom14_pos"]), _p(T["atom37_to_atom14"]),
                                                 _p(T["atom37_mask"]), _p(a14), _p(a37), c_int64(P), _lib.stream()),
                "dfold_frames_to_atoms")
+    return a14, a37
+
+
+class FramesToAtomsFn(torch.autograd.Function):
+    """frames + torsions -> (atom14, atom37) as an autograd node: the reference builds the atoms inside the graph
+    (src/model/Dfold_network_dynamic.py:532-538), so its bb-atom / dist-mat loss terms (train_DFOLD_dynamics.py:1317-1364,
+    weights `bb_atom_loss_weight` / `dist_mat_loss_weight`) reach the frames and the torsions through them.  One HIP launch
+    each way (csrc/atoms.hip)."""
+
+    @staticmethod
+    def forward(ctx, t7, angles, aatype):
+        lead = t7.shape[:-1]
+        P = t7.numel() // 7
+        t7c, ang = t7.detach().reshape(P, 7).float().contiguous(), angles.detach().reshape(P, 14).float().contiguous()
+        aa = aatype.reshape(P).long().contiguous()
+        a14, a37 = _atoms_launch(t7c, ang, aa, P)
+        ctx.save_for_backward(t7c, ang, aa)
+        ctx.shapes = (t7.shape, angles.shape, t7.dtype, angles.dtype)
+        return a14.view(lead + (14, 3)), a37.view(lead + (37, 3))
+
+    @staticmethod
+    def backward(ctx, g14, g37):
+        from ctypes import c_int64
+        from .. import _lib
+        from ..ops import _p
+        t7c, ang, aa = ctx.saved_tensors
+        P = t7c.shape[0]
+        T = residue_tables(t7c.device)
+        g14 = None if g14 is None else g14.reshape(P, 14, 3).float().contiguous()
+        g37 = None if g37 is None else g37.reshape(P, 37, 3).float().contiguous()
+        dt7 = torch.empty((P, 7), dtype=torch.float32, device=t7c.device)
+        dang = torch.empty((P, 14), dtype=torch.float32, device=t7c.device)
+        _lib.check(_lib.lib().dfold_frames_to_atoms_bwd(_p(t7c), _p(ang), _p(aa), _p(T["default_frames"]), _p(T["atom14_group"]),
+                                                        _p(T["atom14_mask"]), _p(T["atom14_pos"]), _p(T["atom37_to_atom14"]),
+                                                        _p(T["atom37_mask"]), _p(g14), _p(g37), _p(dt7), _p(dang), c_int64(P),
+                                                        _lib.stream()), "dfold_frames_to_atoms_bwd")
+        s7, sa, d7, da = ctx.shapes
+        return dt7.view(s7).to(d7), dang.view(sa).to(da), None
+
+
+def frames_to_atoms_hip(t7, angles, aatype):
+    """device path of frames_to_atoms: one HIP launch (csrc/atoms.hip).  Inside autograd when the frames or the torsions
+    carry a graph (like the reference); a plain launch otherwise."""
+    if torch.is_grad_enabled() and (t7.requires_grad or angles.requires_grad):
+        return FramesToAtomsFn.apply(t7, angles, aatype)
+    lead = t7.shape[:-1]
+    P = t7.numel() // 7
+    t7c, ang = t7.detach().reshape(P, 7).float().contiguous(), angles.detach().reshape(P, 14).float().contiguous()
+    a14, a37 = _atoms_launch(t7c, ang, aatype.reshape(P).long().contiguous(), P)
     return a14.view(lead + (14, 3)), a37.view(lead + (37, 3))

@@ -323,6 +323,14 @@ int dfold_frames_to_atoms(const float* t7, const float* angles, const int64_t* a
                           const int64_t* atom14_group, const float* atom14_mask, const float* atom14_pos,
                           const int64_t* atom37_to_atom14, const float* atom37_mask, float* atom14, float* atom37, int64_t P,
                           void* stream);
+/* its backward (round 4): the reference builds the atoms inside autograd (src/model/Dfold_network_dynamic.py:532-538; the
+ * bb-atom / dist-mat loss terms read them, train_DFOLD_dynamics.py:1317-1364).  g_atom14 [P][14][3] and / or g_atom37
+ * [P][37][3] (either may be NULL) -> d_t7 [P][7] (quaternion of the un-normalised quadratic form, translation),
+ * d_angles [P][7][2]. */
+int dfold_frames_to_atoms_bwd(const float* t7, const float* angles, const int64_t* aatype, const float* default_frames,
+                              const int64_t* atom14_group, const float* atom14_mask, const float* atom14_pos,
+                              const int64_t* atom37_to_atom14, const float* atom37_mask, const float* g_atom14,
+                              const float* g_atom37, float* d_t7, float* d_angles, int64_t P, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * IGSO(3) score series (SO3Diffuser.torch_score src/data/so3_diffuser.py:274-305, igso3_expansion :9-49,

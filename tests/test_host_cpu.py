@@ -385,6 +385,34 @@ def test_checkpoint_format_warm_start_and_true_resume(tmp_path):
         experiment.loss_fn = experiment_loss
 
 
+def test_checkpoint_loader_executes_nothing_from_the_file(tmp_path, monkeypatch):
+    """read_checkpoint reads the reference's format (torch zip + pickle protocol 4, which torch's own weights_only
+    unpickler refuses) through an allow-listed unpickler: tensors / containers load, a global outside the list -- here a
+    __reduce__ that would call os.system -- raises instead of running; the unrestricted loader is opt-in only."""
+    from dynamicpdb_amd import checkpoint
+    monkeypatch.delenv("DFOLD_TRUSTED_CHECKPOINTS", raising=False)
+    good = tmp_path / "good.pth"
+    torch.save({"model": {"module.w": torch.arange(3.0)}, "conf": {"a": {"b": 1}}, "epoch": 1, "step": 2,
+                "optimizer": {"state": {0: {"step": torch.tensor(1.0), "exp_avg": torch.zeros(3)}},
+                              "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999), "amsgrad": True, "params": [0]}]}},
+               good, pickle_protocol=4)
+    ck = checkpoint.read_checkpoint(str(good))
+    assert torch.equal(ck["model"]["module.w"], torch.arange(3.0)) and ck["conf"]["a"]["b"] == 1 and ck["step"] == 2
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    bad = tmp_path / "bad.pth"
+    torch.save({"model": {"w": torch.ones(1)}, "conf": Evil()}, bad, pickle_protocol=4)
+    with pytest.raises(RuntimeError, match="allow-list"):
+        checkpoint.read_checkpoint(str(bad))
+    assert not marker.exists()
+    with pytest.warns(UserWarning, match="UNRESTRICTED"):
+        checkpoint.read_checkpoint(str(bad), allow_pickle=True)          # explicit opt-in: now it does run
+    assert marker.exists()
+
+
 def test_geoformer_dropins_keep_the_reference_parameter_layout():
     """Node2Edge / GeometricAttention expose exactly the parameter names and shapes of OmegaFold's modules (the names in
     the reference-minted golden file are the reference's own named_parameters()), load such a state_dict strictly, and

@@ -188,6 +188,41 @@ def test_frames_to_atoms_kernel_vs_reference_formulas():
     assert torch.equal(a37 == 0, r37 == 0) and torch.equal(a14 == 0, r14 == 0)
 
 
+def test_frames_to_atoms_backward_vs_oracle_autograd():
+    """the atoms sit inside autograd like the reference's (src/model/Dfold_network_dynamic.py:532-538): gradients of a
+    read-out of atom14 AND atom37 w.r.t. the frames (un-normalised quaternion form + translation) and the torsions, vs fp64
+    autograd of the oracle's op-by-op restatement; either output alone; the no-graph call stays a plain launch"""
+    from dynamicpdb_amd.model import geometry as G
+    from oracle import dfold_oracle as O
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(19)
+    B, F, N = 2, 2, 57
+    t7 = torch.randn(B, F, N, 7, generator=gen)
+    t7[..., :4] = t7[..., :4] / t7[..., :4].norm(dim=-1, keepdim=True) * (1 + 0.05 * torch.randn(B, F, N, 1, generator=gen))
+    t7[..., 4:] *= 10
+    ang = torch.randn(B, F, N, 7, 2, generator=gen)
+    ang = ang / ang.norm(dim=-1, keepdim=True) * (1 + 0.05 * torch.randn(B, F, N, 7, 1, generator=gen))
+    aa = torch.randint(0, 21, (B, F, N), generator=gen)
+    w14, w37 = torch.randn(B, F, N, 14, 3, generator=gen), torch.randn(B, F, N, 37, 3, generator=gen)
+    for use14, use37 in ((True, True), (True, False), (False, True)):
+        a, g = t7.to(dev).requires_grad_(True), ang.to(dev).requires_grad_(True)
+        a14, a37 = G.frames_to_atoms_hip(a, g, aa.to(dev))
+        assert a14.requires_grad and a37.requires_grad
+        loss = (a14 * w14.to(dev)).sum() * float(use14) + (a37 * w37.to(dev)).sum() * float(use37)
+        if use14 and use37:
+            loss.backward()
+        else:                          # only one output carries a gradient: the other arrives as None / zeros
+            (a14 * w14.to(dev)).sum().backward() if use14 else (a37 * w37.to(dev)).sum().backward()
+        ar, gr = t7.double().requires_grad_(True), ang.double().requires_grad_(True)
+        r14, r37 = O.frames_to_atoms(ar, gr, aa)
+        ((r14 * w14.double()).sum() * float(use14) + (r37 * w37.double()).sum() * float(use37)).backward()
+        assert rel_l2(a.grad, ar.grad) < 1e-5, (use14, use37, rel_l2(a.grad, ar.grad))
+        assert rel_l2(g.grad, gr.grad) < 1e-5, (use14, use37, rel_l2(g.grad, gr.grad))
+    with torch.no_grad():
+        n14, _ = G.frames_to_atoms_hip(t7.to(dev), ang.to(dev), aa.to(dev))
+    assert not n14.requires_grad and torch.equal(n14, a14.detach())
+
+
 def test_ipa_geometry_nodes_fwd_bwd():
     """points -> global frame and attended points -> output features, forward and backward (incl. the gradient w.r.t.
     the rigid frames), vs fp64 autograd of the reference formulas (ipa_pytorch_dynamic.py:363-390, :470-488)."""
@@ -357,8 +392,8 @@ def test_ipa_fused_forward_protein_scale_coordinates(B, F, N):
 @pytest.mark.parametrize("B,F,N", [(1, 2, 256), (2, 1, 40), (1, 1, 512)])
 def test_ipa_fused_backward_protein_scale_coordinates(B, F, N, monkeypatch):
     """The fused row pass of the backward (csrc/ipa_fused_bwd.hip) with points of protein scale (global-frame coordinates of tens
-    of Angstrom, off-centre) against the chain it replaces (fp32 VALU point terms, csrc/ipa_attn.hip): every gradient of the
-    attention core, both workgroup shapes, masked keys / queries.  The bf16-split point columns must carry fp32-grade accuracy:
+    of Angstrom, off-centre) against fp64 autograd of the reference formulas AND against the chain it replaces (fp32 VALU point
+    terms, csrc/ipa_attn.hip): every gradient of the attention core, both workgroup shapes, masked keys / queries.  The bf16-split point columns must carry fp32-grade accuracy:
     dq_pts leans on the rows of dS summing to zero."""
     from dynamicpdb_amd.model import functional as Fm
     dev = torch.device("cuda:0")
@@ -384,6 +419,20 @@ def test_ipa_fused_backward_protein_scale_coordinates(B, F, N, monkeypatch):
         o, o_pt, o_pair = Fm.IpaCoreFn.apply(*leaves[:9], mask, leaves[9])
         torch.autograd.backward([o, o_pt, o_pair], [go, gpt, gpair])
         grads[fused] = [t.grad.double() for t in leaves]
+    # fp64 anchor (round 4): autograd of the formulas of src/model/ipa_pytorch_dynamic.py:396-469 on the same bf16-rounded
+    # operands and the same off-centre 3.8 A chain -- the oracle for BOTH forms, not the one for the other
+    ref_leaves = [vals[n].detach().double().requires_grad_(True) for n in names]
+    rq, rkv, rqp, rkp, rvp, rz, rwb, rwdz, rbdz, rhw = ref_leaves
+    rwb_q = rwb.detach().to(torch.bfloat16).double() + (rwb - rwb.detach())            # engine casts weights to bf16
+    rwdz_q = rwdz.detach().to(torch.bfloat16).double() + (rwdz - rwdz.detach())
+    ro, ropt, ropair = _ref_core(rq, rkv, rqp, rkp, rvp, rz, rwb_q, rwdz_q, rbdz, mask.double(), rhw, H, C)
+    torch.autograd.backward([ro, ropt, ropair], [go.double(), gpt.double(), gpair.double()])
+    ref = [t.grad for t in ref_leaves]
+    e64 = {f: {n: rel_l2(a, r) for n, a, r in zip(names, grads[f], ref)} for f in (True, False)}
+    print(f"[fused IPA backward N={N} vs fp64] " + ", ".join(f"{n} {e64[True][n]:.1e} (chain {e64[False][n]:.1e})" for n in names))
+    tol64 = dict(q=2e-2, kv=2e-2, q_pts=1e-2, k_pts=1e-2, v_pts=1e-2, z=2e-2, w_b=2e-2, w_dz=2e-2, b_dz=2e-2, hw=2e-2)
+    for n in names:
+        assert e64[True][n] < tol64[n], (n, e64[True][n], e64[False][n])
     tol = dict(q=1e-2, kv=1e-2, q_pts=3e-3, k_pts=3e-3, v_pts=3e-3, z=1.5e-2, w_b=1e-2, w_dz=1e-2, b_dz=1e-2, hw=1e-2)
     errs = {n: rel_l2(a, b) for n, a, b in zip(names, grads[True], grads[False])}
     print(f"[fused IPA backward N={N}] " + ", ".join(f"{n} {e:.1e}" for n, e in errs.items()))
