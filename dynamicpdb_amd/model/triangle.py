@@ -414,7 +414,6 @@ class TriangleAttentionFn(Function):
         R, BI = B * NN, B * N
         ld = 4 * HC
         dob = ops.cast_bf16(dout.reshape(R, cin).contiguous().float())
-        dw_o, db_o = _linear_grads(ogb, dob)
         dog = torch.empty((R, HC), dtype=torch.float32, device=dev)
         gemm(dob, CACHE.wt(w_o), dog, R, HC, cin, a_rows=rows_plain(cin), c_rows=rows_plain(HC), ldb=cin)
         dproj = torch.empty((R, ld), dtype=BF16, device=dev)
@@ -446,25 +445,88 @@ class TriangleAttentionFn(Function):
         doT = ops.transpose_bf16(do, N, C, ld_src=HC, nbatch=nb, nb1=H, bs_src=(N * HC, C))
         gemm(PbT, doT, dproj, N, C, N, a_rows=rows_plain(N), c_rows=rows_plain(ld), ldb=N, nbatch=nb, nb1=H,
              sa=(H * N * N, N * N), sb=(H * C * N, C * N), sc=(N * ld, C), c_off=2 * HC)
-        dwcat, dbcat = _linear_grads(xn, dproj)
-        # dxn = dproj Wcat + dtri^T w_tri
-        wcatT = ops.transpose_bf16(_cat_w([w_q, w_k, w_v, w_g]), ld, cin)
-        dxn32 = torch.empty((R, cin), dtype=torch.float32, device=dev)
-        gemm(dproj, wcatT, dxn32, R, cin, ld, a_rows=rows_plain(ld), c_rows=rows_plain(cin), ldb=ld)
-        dtri_b = ops.cast_bf16(dtri)                                                   # [B][H][NN]
-        H8 = (H + 7) // 8 * 8
-        dtriT = torch.zeros((R, H8), dtype=BF16, device=dev)
-        ops.transpose_bf16(dtri_b, H, NN, out=dtriT, nbatch=B, nb1=1, bs_src=(H * NN, 0), ld_dst=H8, bs_dst=(NN * H8, 0))
-        gemm(dtriT, CACHE.wt(w_tri), dxn32, R, cin, H8, a_rows=rows_plain(H8), c_rows=rows_plain(cin), ldb=H8,
-             flags=ops.GEMM_ACCUM)
-        xnT = ops.transpose_bf16(xn, NN, cin, nbatch=B, nb1=1, bs_src=(NN * cin, 0)) if B > 1 else ops.transpose_bf16(xn, NN, cin)
-        dw_tri = torch.zeros((H, cin), dtype=torch.float32, device=dev)
-        for b in range(B):
-            ops.gemm_reduce_rows(dtri_b[b], xnT[b] if B > 1 else xnT, H, cin, NN, out=dw_tri)
-        dxn = ops.cast_bf16(dxn32)
-        dx, dg_ln, db_ln = _row_ln_bwd(xf, st, g_ln.detach(), dxn, dx_bf16=False)
-        return (dx.view(xshape), None, None, None, dg_ln, db_ln, dw_tri, dwcat[:HC], dwcat[HC:2 * HC], dwcat[2 * HC:3 * HC],
-                dwcat[3 * HC:], dbcat[3 * HC:], dw_o, db_o)
+        return _triatt_bwd_tail(xf, xn, st, dproj, dtri, ogb, dob, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o, B, N, cin, H, C, xshape)
+
+
+def _triatt_bwd_tail(xf, xn, st, dproj, dtri, ogb, dob, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o, B, N, cin, H, C, xshape):
+    """Pair-sized rest of the triangle-attention backward, shared by the intermediate-keeping chain and the streaming
+    form: parameter gradients of the five Linear layers (reductions over the cells), dxn = dproj W_cat + dtri^T w_tri,
+    LayerNorm backward.  Returns the gradient tuple of TriangleAttentionFn.forward's arguments."""
+    NN, HC, dev = N * N, H * C, xf.device
+    R, ld = B * NN, 4 * H * C
+    dw_o, db_o = _linear_grads(ogb, dob)
+    dwcat, dbcat = _linear_grads(xn, dproj)
+    # dxn = dproj Wcat + dtri^T w_tri
+    wcatT = ops.transpose_bf16(_cat_w([w_q, w_k, w_v, w_g]), ld, cin)
+    dxn32 = torch.empty((R, cin), dtype=torch.float32, device=dev)
+    gemm(dproj, wcatT, dxn32, R, cin, ld, a_rows=rows_plain(ld), c_rows=rows_plain(cin), ldb=ld)
+    dtri_b = ops.cast_bf16(dtri)                                                   # [B][H][NN]
+    H8 = (H + 7) // 8 * 8
+    dtriT = torch.zeros((R, H8), dtype=BF16, device=dev)
+    ops.transpose_bf16(dtri_b, H, NN, out=dtriT, nbatch=B, nb1=1, bs_src=(H * NN, 0), ld_dst=H8, bs_dst=(NN * H8, 0))
+    gemm(dtriT, CACHE.wt(w_tri), dxn32, R, cin, H8, a_rows=rows_plain(H8), c_rows=rows_plain(cin), ldb=H8,
+         flags=ops.GEMM_ACCUM)
+    xnT = ops.transpose_bf16(xn, NN, cin, nbatch=B, nb1=1, bs_src=(NN * cin, 0)) if B > 1 else ops.transpose_bf16(xn, NN, cin)
+    dw_tri = torch.zeros((H, cin), dtype=torch.float32, device=dev)
+    for b in range(B):
+        ops.gemm_reduce_rows(dtri_b[b], xnT[b] if B > 1 else xnT, H, cin, NN, out=dw_tri)
+    dxn = ops.cast_bf16(dxn32)
+    dx, dg_ln, db_ln = _row_ln_bwd(xf, st, g_ln.detach(), dxn, dx_bf16=False)
+    return (dx.view(xshape), None, None, None, dg_ln, db_ln, dw_tri, dwcat[:HC], dwcat[HC:2 * HC], dwcat[2 * HC:3 * HC],
+            dwcat[3 * HC:], dbcat[3 * HC:], dw_o, db_o)
+
+
+def _use_stream_bwd():
+    """backward of the fused triangle attention: "1" (default) the streaming form (csrc/triatt_bwd.hip: logits recomputed
+    per row on chip), "0" the intermediate-keeping chain (fp32 [B N, H, N, N] logits in HBM; A/B runs, N_res > 512)"""
+    return os.environ.get("DFOLD_TRIATT_STREAM_BWD", "1") != "0"
+
+
+def _triatt_stream_backward(x, mask, dout, inf, params):
+    """Streaming backward of triangle attention in the operator's coordinates (x [B,N,N,128], N % 8 == 0, N <= 512; the
+    ending node passes x^T).  Recomputes LayerNorm, the q|k|v|g projections and the triangle bias (pair-sized), then two
+    launches of csrc/triatt_bwd.hip do everything quadratic in N per pair-tensor row on the matrix cores -- no
+    [B N, H, N, N] tensor exists --, then the pair-sized tail shared with the chain.  Returns the gradients of
+    (x, g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o)."""
+    g_ln, b_ln, w_tri, w_q, w_k, w_v, w_g, b_g, w_o, b_o = params
+    L = _lib.lib()
+    B, N, cin = x.shape[0], x.shape[1], x.shape[-1]
+    H, HC = 4, w_q.shape[0]
+    C = HC // H
+    NN, dev = N * N, x.device
+    R = B * NN
+    xf = x.reshape(R, cin).contiguous()
+    if xf.dtype not in (torch.float32, BF16):
+        xf = xf.float()
+    maskf = mask.reshape(R).contiguous().float()
+    xn, st = _row_ln_fwd(xf, g_ln.detach().float().contiguous(), b_ln.detach().float().contiguous())
+    wcat = _cat_w([w_q, w_k, w_v, w_g])
+    bcat = torch.cat([torch.zeros(3 * HC, device=dev), b_g.detach().float()]).contiguous()
+    proj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)                        # q | k | v | g (pre-activation)
+    gemm(xn, wcat, proj, R, 4 * HC, cin, a_rows=rows_plain(cin), c_rows=rows_plain(4 * HC), ldb=cin, bias=bcat)
+    tri = torch.empty((B, H, NN), dtype=torch.float32, device=dev)
+    gemm(CACHE.w(w_tri), xn, tri, H, NN, cin, a_rows=rows_plain(cin), c_rows=rows_plain(NN), ldb=cin, nbatch=B, nb1=1,
+         sb=(NN * cin, 0), sc=(H * NN, 0))
+    dob = dout.reshape(R, cin)
+    dob = dob.contiguous() if dob.dtype == BF16 else ops.cast_bf16(dob.float())
+    KB = (N + 127) // 128
+    IC = max(1, min(16, N, 512 // (B * H * KB)))
+    dproj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)
+    ogb = torch.empty((R, HC), dtype=BF16, device=dev)
+    dos = torch.empty((R, HC), dtype=BF16, device=dev)
+    stats = torch.empty((B * N, H, 3, N), dtype=torch.float32, device=dev)
+    dtri_part = torch.empty((IC, B, H, NN), dtype=torch.float32, device=dev)
+    check(L.dfold_triatt_bwd_core(_p(proj), _p(tri), _p(maskf), _p(dob), _p(CACHE.wt(w_o)), _p(dproj), _p(ogb), _p(dos), _p(stats),
+                                  _p(dtri_part), c_int32(B), c_int32(N), c_int32(IC), ctypes_float(inf),
+                                  ctypes_float(1.0 / math.sqrt(C)), stream()), "dfold_triatt_bwd_core")
+    if IC > 1:
+        dtri = torch.empty((B, H, NN), dtype=torch.float32, device=dev)
+        check(L.dfold_sum_leading(_p(dtri_part), _p(dtri), c_int32(IC), c_int64(B * H * NN), c_int64(B * H * NN), stream()),
+              "dfold_sum_leading")
+    else:
+        dtri = dtri_part[0]
+    g = _triatt_bwd_tail(xf, xn, st, dproj, dtri, ogb, dob, g_ln, w_tri, w_q, w_k, w_v, w_g, w_o, B, N, cin, H, C, x.shape)
+    return (g[0],) + tuple(g[4:])
 
 
 def _triatt_fused(x, mask, starting, inf, pack, ws=None):
@@ -524,8 +586,26 @@ class TriAttFusedFn(Function):
     @staticmethod
     def backward(ctx, dout):
         xc, maskf, *params = ctx.saved_tensors
-        g = _recompute_grads(TriangleAttentionFn, xc, maskf, dout, (4, ctx.inf), params, transpose=not ctx.starting)
-        return (g[0].to(xc.dtype), None, None, None, None, None, *g[1:])
+        N = xc.shape[1]
+        N8 = (N + 7) // 8 * 8
+        if not (_use_stream_bwd() and N8 <= 512):
+            g = _recompute_grads(TriangleAttentionFn, xc, maskf, dout, (4, ctx.inf), params, transpose=not ctx.starting)
+            return (g[0].to(xc.dtype), None, None, None, None, None, *g[1:])
+        import torch.nn.functional as Fn_
+        # the operator's coordinates: the ending node attends along columns = rows of x^T; N_res zero-padded (masked, zero
+        # output gradient) to the 16-byte rows of the bf16 tensors
+        xb, mb, db = xc, maskf, dout.reshape(xc.shape)
+        if not ctx.starting:
+            xb, mb, db = xb.transpose(1, 2), mb.transpose(1, 2), db.transpose(1, 2)
+        if N8 != N:
+            xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
+            mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
+            db = Fn_.pad(db, (0, 0, 0, N8 - N, 0, N8 - N))
+        g = _triatt_stream_backward(xb.contiguous(), mb.contiguous(), db.contiguous(), ctx.inf, [p.detach() for p in params])
+        dx = g[0][:, :N, :N]
+        if not ctx.starting:
+            dx = dx.transpose(1, 2)
+        return (dx.to(xc.dtype), None, None, None, None, None, *g[1:])
 
 
 class _Attention(nn.Module):

@@ -240,9 +240,13 @@ def test_fused_equals_unfused_chain_fwd_bwd(name, monkeypatch):
         y.backward(gy.to(dev))
         res[fused] = (y.detach(), zz.grad, {k: p.grad for k, p in m.named_parameters()})
     assert rel_l2(res["1"][0], res["0"][0]) < 1e-2, rel_l2(res["1"][0], res["0"][0])
-    assert rel_l2(res["1"][1], res["0"][1]) < 1e-5                              # same backward chain on the same inputs
+    # triangle multiplication: the same backward chain on the same inputs.  Triangle attention (round 4): the fused path's
+    # backward is the streaming form (csrc/triatt_bwd.hip: logits recomputed per row on chip), the unfused one keeps its
+    # fp32 logits -- two different bf16-class evaluations of the same gradient
+    tol = 1e-5 if name.startswith("tri_mul") else 1e-2
+    assert rel_l2(res["1"][1], res["0"][1]) < tol, rel_l2(res["1"][1], res["0"][1])
     for k in res["0"][2]:
-        assert rel_l2(res["1"][2][k], res["0"][2][k]) < 1e-5, k
+        assert rel_l2(res["1"][2][k], res["0"][2][k]) < tol, (k, rel_l2(res["1"][2][k], res["0"][2][k]))
 
 
 @pytest.mark.parametrize("name", ["tri_mul_out", "tri_att_end"])
