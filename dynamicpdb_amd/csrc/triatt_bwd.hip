@@ -35,6 +35,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned tbu32x2;
 
 struct TriAttBwdParams {
   const bf16_t* proj;   // [B N N][512] bf16: q | k | v | g (pre-activation) of every cell, head h at columns h*32 of each block
+  const bf16_t* projT;  // [512][B N N] the same, channel-major (the projection GEMM run with swapped operands): K^T, V^T, Q^T tiles
   const float* tri;     // [B][4][N][N] triangle bias (unscaled)
   const float* mask;    // [B][N][N]
   const bf16_t* dob;    // [B N N][128] dL/dout
@@ -42,6 +43,8 @@ struct TriAttBwdParams {
   bf16_t* dproj;        // [B N N][512] dq | dk | dv | dg
   bf16_t* og;           // [B N N][128] o * sigmoid(g) (operand of dW_o)
   bf16_t* dos;          // [B N N][128] scratch: do
+  bf16_t* dosT;         // [128][B N N] scratch: do, channel-major
+  long R;               // B N N
   float* stats;         // [B N][4][3][N]: row max (log2 domain), 1 / sum, D
   float* dtri_part;     // [IC][B][4][N][N]
   int B, N, IC, rpc, KB;
@@ -59,20 +62,29 @@ __device__ __forceinline__ float tb_xsum(float v) {
 }
 __device__ __forceinline__ float tb_sigm(float y) { return 1.f / (1.f + __expf(-y)); }
 
-// [rows][32] bf16 head slice (row stride `ld` elements) -> LDS in both orientations: row-major 64-byte rows (16-byte chunks
-// XOR-swizzled like the forward kernels' K tile) and channel-major [32][NMAX * 2 + 16 bytes]; rows >= nvalid are zero.
+// [rows][32] bf16 head slice (row stride `ld` elements) -> LDS, row-major 64-byte rows (16-byte chunks XOR-swizzled like the
+// forward kernels' K tile); rows >= nvalid are zero.
 template <int NMAX>
-__device__ __forceinline__ void tb_load_tile(const bf16_t* __restrict__ src, long ld, int nvalid, char* ldsR, char* ldsT, int tid) {
-  constexpr int TP = NMAX * 2 + 16;
+__device__ __forceinline__ void tb_load_rows(const bf16_t* __restrict__ src, long ld, int nvalid, char* ldsR, int tid) {
 #pragma unroll
-  for (int it = 0; it < NMAX * 4 / 512; ++it) {
-    const int id = it * 512 + tid, row = id >> 2, c = id & 3;
+  for (int it = 0; it < NMAX * 4 / 256; ++it) {
+    const int id = it * 256 + tid, row = id >> 2, c = id & 3;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (row < nvalid) v = *(const uint4*)(src + (long)row * ld + c * 8);
     *(uint4*)(ldsR + tb_k_off(row, c)) = v;
-    const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+  }
+}
+// the same head slice from the channel-major copy (32 rows of `nvalid` consecutive cells, row stride ldT) -> LDS
+// [32][NMAX * 2 + 16 bytes]; cells >= nvalid are zero (nvalid % 8 == 0)
+template <int NMAX>
+__device__ __forceinline__ void tb_load_planes(const bf16_t* __restrict__ srcT, long ldT, int nvalid, char* ldsT, int tid) {
+  constexpr int TP = NMAX * 2 + 16, CPR = NMAX / 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *(bf16_t*)(ldsT + (c * 8 + e) * TP + row * 2) = (bf16_t)(wv[e >> 1] >> ((e & 1) * 16));
+  for (int it = 0; it < NMAX * 4 / 256; ++it) {
+    const int id = it * 256 + tid, c = id / CPR, cell0 = (id - c * CPR) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (cell0 < nvalid) v = *(const uint4*)(srcT + (long)c * ldT + cell0);
+    *(uint4*)(ldsT + c * TP + cell0 * 2) = v;
   }
 }
 
@@ -88,7 +100,7 @@ __device__ __forceinline__ bf16x8 tb_pack8(const f32x4& a, const f32x4& b) {
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(512) void triatt_bwd_q_kernel(const TriAttBwdParams p) {
+__global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(const TriAttBwdParams p) {
   constexpr int NKT = NMAX / 16, ROWT = NMAX * 64, TP = NMAX * 2 + 16, TRT = 32 * TP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsK = smem;
@@ -103,9 +115,11 @@ __global__ __launch_bounds__(512) void triatt_bwd_q_kernel(const TriAttBwdParams
   const long bi = blockIdx.x >> 2;                    // b * N + i
   const int b = (int)(bi / N);
   const long row0 = bi * N;                           // first cell of the row
-  tb_load_tile<NMAX>(p.proj + row0 * 512 + 128 + h * 32, 512, N, ldsK, ldsKT, tid);
-  tb_load_tile<NMAX>(p.proj + row0 * 512 + 256 + h * 32, 512, N, ldsV, ldsVT, tid);
-  for (int t = tid; t < NMAX; t += 512) ldsMB[t] = t < N ? p.inf * (p.mask[row0 + t] - 1.f) * TB_L2E : -INFINITY;
+  tb_load_rows<NMAX>(p.proj + row0 * 512 + 128 + h * 32, 512, N, ldsK, tid);
+  tb_load_rows<NMAX>(p.proj + row0 * 512 + 256 + h * 32, 512, N, ldsV, tid);
+  tb_load_planes<NMAX>(p.projT + (long)(128 + h * 32) * p.R + row0, p.R, N, ldsKT, tid);
+  tb_load_planes<NMAX>(p.projT + (long)(256 + h * 32) * p.R + row0, p.R, N, ldsVT, tid);
+  for (int t = tid; t < NMAX; t += 256) ldsMB[t] = t < N ? p.inf * (p.mask[row0 + t] - 1.f) * TB_L2E : -INFINITY;
   __syncthreads();
 
   const float sl2 = p.scale * TB_L2E;
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(512) void triatt_bwd_q_kernel(const TriAttBwdParams
   const int nqt = (N + 15) >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int qt = w; qt < nqt; qt += 8) {
+  for (int qt = w; qt < nqt; qt += 4) {
     asm volatile("" ::: "memory");      // the K / V tiles are loop-invariant: without this every fragment of the row is hoisted out
                                         // of the loop and parked in scratch
     const int q = qt * 16 + l15;
@@ -191,6 +205,8 @@ __global__ __launch_bounds__(512) void triatt_bwd_q_kernel(const TriAttBwdParams
         *(uint2*)(p.og + cell * 128 + col) = make_uint2(pack2bf_hw(ogv[0], ogv[1]), pack2bf_hw(ogv[2], ogv[3]));
         *(uint2*)(p.dos + cell * 128 + col) = make_uint2(pack2bf_hw(dov[cb][0], dov[cb][1]), pack2bf_hw(dov[cb][2], dov[cb][3]));
         *(uint2*)(p.dproj + cell * 512 + 384 + col) = make_uint2(pack2bf_hw(dgv[0], dgv[1]), pack2bf_hw(dgv[2], dgv[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.dosT[(long)(col + r) * p.R + cell] = f2bf_hw(dov[cb][r]);      // channel-major copy (kernel K's do^T tile)
       }
     }
     const float D = tb_xsum(Dp);
@@ -229,15 +245,42 @@ __global__ __launch_bounds__(512) void triatt_bwd_q_kernel(const TriAttBwdParams
   }
 }
 
+// Kernel K: 8 waves = KT key tiles x QS query ranges (QS = NMAX / 128: every wave owns 16 keys and 128 queries, so that its
+// slice of the triangle bias and of the bias gradient -- 2 x 32 registers -- stays in registers for the whole chunk of rows;
+// the dk / dv partial sums of the QS waves of a key tile meet in LDS once per row).
+template <int NMAX, int NT>
+__device__ __forceinline__ void tb_load_rows_nt(const bf16_t* __restrict__ src, long ld, int nvalid, char* ldsR, int tid) {
+#pragma unroll
+  for (int it = 0; it < NMAX * 4 / NT; ++it) {
+    const int id = it * NT + tid, row = id >> 2, c = id & 3;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < nvalid) v = *(const uint4*)(src + (long)row * ld + c * 8);
+    *(uint4*)(ldsR + tb_k_off(row, c)) = v;
+  }
+}
+template <int NMAX, int NT>
+__device__ __forceinline__ void tb_load_planes_nt(const bf16_t* __restrict__ srcT, long ldT, int nvalid, char* ldsT, int tid) {
+  constexpr int TP = NMAX * 2 + 16, CPR = NMAX / 8;
+#pragma unroll
+  for (int it = 0; it < NMAX * 4 / NT; ++it) {
+    const int id = it * NT + tid, c = id / CPR, cell0 = (id - c * CPR) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (cell0 < nvalid) v = *(const uint4*)(srcT + (long)c * ldT + cell0);
+    *(uint4*)(ldsT + c * TP + cell0 * 2) = v;
+  }
+}
+
 template <int NMAX>
 __global__ __launch_bounds__(512) void triatt_bwd_k_kernel(const TriAttBwdParams p) {
-  constexpr int NQT = NMAX / 16, ROWT = NMAX * 64, TP = NMAX * 2 + 16, TRT = 32 * TP;
+  constexpr int QS = NMAX / 128, KT = 8 / QS, NQW = 8;            // query tiles per wave (128 queries)
+  constexpr int ROWT = NMAX * 64, TP = NMAX * 2 + 16, TRT = 32 * TP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsQ = smem;
   char* const ldsDO = smem + ROWT;
   char* const ldsQT = smem + 2 * ROWT;
   char* const ldsDOT = smem + 2 * ROWT + TRT;
   float* const ldsST = (float*)(smem + 2 * ROWT + 2 * TRT);      // [3][NMAX]: max, 1 / sum, D of the row's queries
+  float* const ldsRED = ldsST + 3 * NMAX;                        // [KT][QS - 1][16][64]: dk / dv partial sums
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int N = p.N, B = p.B;
@@ -248,25 +291,45 @@ __global__ __launch_bounds__(512) void triatt_bwd_k_kernel(const TriAttBwdParams
   bid >>= 2;
   const int b = (int)(bid % (unsigned)B), ic = (int)(bid / (unsigned)B);
   const int i0 = ic * p.rpc, i1 = min(N, i0 + p.rpc);
-  const int kt = kblk * 8 + w;
+  const int ktl = w % KT, qs = w / KT;                            // key tile of the block, query range
+  const int kt = kblk * KT + ktl;
   const int key = kt * 16 + l15;
-  const bool kok = key < N, wave_on = kt * 16 < N;
+  const int qt0 = qs * NQW;                                       // first query tile of the wave
+  const bool kok = key < N, wave_on = kt * 16 < N && qt0 * 16 < N;
   const int kc = kok ? key : N - 1;
   const float sl2 = p.scale * TB_L2E;
   const int kswz = (-(l15 >> 2)) & 3;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 dt[NQT];
+  // the wave's slice of the triangle bias (x log2 e) -- the same for every row -- and of its gradient, in registers for the
+  // whole chunk of rows: [query tile][r] <-> tri[h][(qt0 + t)*16 + l4*4 + r][key]
+  f32x4 trv[NQW], dt[NQW];
+  {
+    const float* tbase = p.tri + ((long)b * 4 + h) * N * N + kc;
 #pragma unroll
-  for (int qt = 0; qt < NQT; ++qt) dt[qt] = zero4;
-  const float* tbase = p.tri + ((long)b * 4 + h) * N * N + kc;
+    for (int t = 0; t < NQW; ++t) {
+      dt[t] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = (qt0 + t) * 16 + l4 * 4 + r;
+        trv[t][r] = tbase[(long)min(qq, N - 1) * N] * TB_L2E;
+      }
+    }
+  }
+  const char* const aq = ldsQ + (qt0 * 16 + l15) * 64 + ((l4 ^ kswz) << 4);       // A fragments: + t * 1024
+  const char* const ad = aq + ROWT;
+  const float* const stq = ldsST + qt0 * 16 + l4 * 4;                                // statistics: + t * 16 floats
+  const char* const tq = ldsQT + l15 * TP + qt0 * 32 + l4 * 8;                       // permuted A fragments: + cb * 16 TP + tp * 64
+  const char* const td = tq + TRT;
 
 #pragma unroll 1
   for (int i = i0; i < i1; ++i) {
     const long bi = (long)b * N + i;
     const long row0 = bi * N;
-    __syncthreads();            // the previous row's readers are done with the tiles
-    tb_load_tile<NMAX>(p.proj + row0 * 512 + h * 32, 512, N, ldsQ, ldsQT, tid);
-    tb_load_tile<NMAX>(p.dos + row0 * 128 + h * 32, 128, N, ldsDO, ldsDOT, tid);
+    __syncthreads();            // the previous row's readers are done with the tiles and the reduction buffer
+    tb_load_rows_nt<NMAX, 512>(p.proj + row0 * 512 + h * 32, 512, N, ldsQ, tid);
+    tb_load_rows_nt<NMAX, 512>(p.dos + row0 * 128 + h * 32, 128, N, ldsDO, tid);
+    tb_load_planes_nt<NMAX, 512>(p.projT + (long)(h * 32) * p.R + row0, p.R, N, ldsQT, tid);
+    tb_load_planes_nt<NMAX, 512>(p.dosT + (long)(h * 32) * p.R + row0, p.R, N, ldsDOT, tid);
     {
       const float* st = p.stats + ((bi * 4 + h) * 3) * N;
       for (int t = tid; t < 3 * NMAX; t += 512) {
@@ -275,42 +338,63 @@ __global__ __launch_bounds__(512) void triatt_bwd_k_kernel(const TriAttBwdParams
       }
     }
     __syncthreads();
+    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
     if (wave_on) {
       const bf16x8 kf = *(const bf16x8*)(p.proj + (row0 + kc) * 512 + 128 + h * 32 + l4 * 8);
       const bf16x8 vf = *(const bf16x8*)(p.proj + (row0 + kc) * 512 + 256 + h * 32 + l4 * 8);
       const float mbk = kok ? p.inf * (p.mask[row0 + key] - 1.f) * TB_L2E : -INFINITY;
-      f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
 #pragma unroll
-      for (int qp = 0; qp < NQT / 2; ++qp) {
+      for (int tp = 0; tp < NQW / 2; ++tp) {
         f32x4 pr[2], ds[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int qt = 2 * qp + u;
-          const int off = (qt * 16 + l15) * 64 + ((l4 ^ kswz) << 4);
-          const f32x4 sa = TB_MFMA(*(const bf16x8*)(ldsQ + off), kf, zero4);       // rows = queries qt*16 + l4*4 + r, column = key
-          const f32x4 dp = TB_MFMA(*(const bf16x8*)(ldsDO + off), vf, zero4);
-          const int q0 = qt * 16 + l4 * 4;
-          const f32x4 m4 = *(const f32x4*)(ldsST + q0), il4 = *(const f32x4*)(ldsST + NMAX + q0), D4 = *(const f32x4*)(ldsST + 2 * NMAX + q0);
+          const int t = 2 * tp + u;
+          const f32x4 sa = TB_MFMA(*(const bf16x8*)(aq + t * 1024), kf, zero4);       // rows = queries (qt0+t)*16 + l4*4 + r, column = key
+          const f32x4 dp = TB_MFMA(*(const bf16x8*)(ad + t * 1024), vf, zero4);
+          const f32x4 m4 = *(const f32x4*)(stq + t * 16), il4 = *(const f32x4*)(stq + NMAX + t * 16), D4 = *(const f32x4*)(stq + 2 * NMAX + t * 16);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qq = q0 + r;
-            float pv = 0.f, dsv = 0.f;
-            if (qq < N) {
-              const float tv = tbase[(long)qq * N];
-              pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], sl2, __builtin_fmaf(tv, TB_L2E, mbk)) - m4[r]) * il4[r];
-              dsv = pv * (dp[r] - D4[r]);
-            }
+            // (queries >= N: Q / do rows, the statistics and so 1 / sum are zero; the clamp keeps an overflowing exp2 from
+            // meeting that zero -- for real queries the argument is <= 0 by construction)
+            const float e = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(sa[r], sl2, trv[t][r] + mbk) - m4[r], 64.f));
+            const float pv = e * il4[r];
+            const float dsv = pv * (dp[r] - D4[r]);
             pr[u][r] = pv;
             ds[u][r] = dsv;
-            dt[qt][r] += dsv;
+            dt[t][r] += dsv;
           }
         }
         const bf16x8 pb = tb_pack8(pr[0], pr[1]), dsb = tb_pack8(ds[0], ds[1]);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          dk[cb] = TB_MFMA(tb_frag_perm(ldsQT + (cb * 16 + l15) * TP + qp * 64 + l4 * 8), dsb, dk[cb]);
-          dv[cb] = TB_MFMA(tb_frag_perm(ldsDOT + (cb * 16 + l15) * TP + qp * 64 + l4 * 8), pb, dv[cb]);
+          dk[cb] = TB_MFMA(tb_frag_perm(tq + cb * 16 * TP + tp * 64), dsb, dk[cb]);
+          dv[cb] = TB_MFMA(tb_frag_perm(td + cb * 16 * TP + tp * 64), pb, dv[cb]);
         }
+      }
+    }
+    // dk / dv of the key tile: the QS - 1 upper query ranges hand their partial sums to the wave of range 0
+    if (qs > 0) {
+      float* red = ldsRED + ((ktl * (QS - 1) + qs - 1) * 16) * 64 + lane;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[(cb * 8 + r) * 64] = dk[cb][r];
+          red[(cb * 8 + 4 + r) * 64] = dv[cb][r];
+        }
+    }
+    __syncthreads();
+    if (qs == 0 && kt * 16 < N) {
+#pragma unroll
+      for (int o = 0; o < QS - 1; ++o) {
+        const float* red = ldsRED + ((ktl * (QS - 1) + o) * 16) * 64 + lane;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dk[cb][r] += red[(cb * 8 + r) * 64];
+            dv[cb][r] += red[(cb * 8 + 4 + r) * 64];
+          }
       }
       if (kok) {
 #pragma unroll
@@ -326,38 +410,41 @@ __global__ __launch_bounds__(512) void triatt_bwd_k_kernel(const TriAttBwdParams
   if (wave_on && kok) {
     float* dst = p.dtri_part + ((((long)ic * B + b) * 4 + h) * N) * N + key;
 #pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
+    for (int t = 0; t < NQW; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qq = qt * 16 + l4 * 4 + r;
-        if (qq < N) dst[(long)qq * N] = dt[qt][r];
+        const int qq = (qt0 + t) * 16 + l4 * 4 + r;
+        if (qq < N) dst[(long)qq * N] = dt[t][r];
       }
   }
 }
 
-extern "C" int dfold_triatt_bwd_core(const void* proj_bf16, const float* tri, const float* mask, const void* dout_bf16,
-                                     const void* w_o_t_bf16, void* dproj_bf16, void* og_bf16, void* do_scratch_bf16, float* stats,
-                                     float* dtri_part, int32_t B, int32_t N, int32_t n_chunks, float inf, float scale, void* stream) {
-  if (!proj_bf16 || !tri || !mask || !dout_bf16 || !w_o_t_bf16 || !dproj_bf16 || !og_bf16 || !do_scratch_bf16 || !stats || !dtri_part)
+extern "C" int dfold_triatt_bwd_core(const void* proj_bf16, const void* proj_t_bf16, const float* tri, const float* mask,
+                                     const void* dout_bf16, const void* w_o_t_bf16, void* dproj_bf16, void* og_bf16,
+                                     void* do_scratch_bf16, void* do_t_scratch_bf16, float* stats, float* dtri_part, int32_t B,
+                                     int32_t N, int32_t n_chunks, float inf, float scale, void* stream) {
+  if (!proj_bf16 || !proj_t_bf16 || !tri || !mask || !dout_bf16 || !w_o_t_bf16 || !dproj_bf16 || !og_bf16 || !do_scratch_bf16 ||
+      !do_t_scratch_bf16 || !stats || !dtri_part)
     return DFOLD_EINVAL;
   if (B <= 0 || N <= 0 || N > 512 || (N & 7) || n_chunks <= 0 || n_chunks > N || (long)B * N * 4 > 0x3fffffffL) return DFOLD_EINVAL;
   TriAttBwdParams p;
-  p.proj = (const bf16_t*)proj_bf16; p.tri = tri; p.mask = mask; p.dob = (const bf16_t*)dout_bf16; p.WoT = (const bf16_t*)w_o_t_bf16;
-  p.dproj = (bf16_t*)dproj_bf16; p.og = (bf16_t*)og_bf16; p.dos = (bf16_t*)do_scratch_bf16; p.stats = stats; p.dtri_part = dtri_part;
-  p.B = B; p.N = N; p.IC = n_chunks; p.rpc = (N + n_chunks - 1) / n_chunks; p.KB = (N + 127) / 128; p.inf = inf; p.scale = scale;
+  p.proj = (const bf16_t*)proj_bf16; p.projT = (const bf16_t*)proj_t_bf16; p.tri = tri; p.mask = mask; p.dob = (const bf16_t*)dout_bf16;
+  p.WoT = (const bf16_t*)w_o_t_bf16; p.dproj = (bf16_t*)dproj_bf16; p.og = (bf16_t*)og_bf16; p.dos = (bf16_t*)do_scratch_bf16;
+  p.dosT = (bf16_t*)do_t_scratch_bf16; p.stats = stats; p.dtri_part = dtri_part; p.R = (long)B * N * N;
+  p.B = B; p.N = N; p.IC = n_chunks; p.rpc = (N + n_chunks - 1) / n_chunks; p.KB = N <= 256 ? (N + 63) / 64 : (N + 31) / 32;      /* key tiles per block of kernel K: 8 waves / (NMAX / 128) */ p.inf = inf; p.scale = scale;
   const unsigned gq = (unsigned)((long)B * N * 4), gk = (unsigned)((long)n_chunks * B * 4 * p.KB);
   if (N <= 256) {
-    constexpr int LDS = 2 * 256 * 64 + 2 * 32 * (256 * 2 + 16) + 3 * 256 * 4;
+    constexpr int LDS = 2 * 256 * 64 + 2 * 32 * (256 * 2 + 16) + 3 * 256 * 4, LDSK = LDS + 4 * 1 * 16 * 64 * 4;
     DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<256>), LDS);
-    DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<256>), LDS);
-    DFOLD_LAUNCH(triatt_bwd_q_kernel<256>, dim3(gq), dim3(512), LDS, (hipStream_t)stream, p);
-    DFOLD_LAUNCH(triatt_bwd_k_kernel<256>, dim3(gk), dim3(512), LDS, (hipStream_t)stream, p);
+    DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<256>), LDSK);
+    DFOLD_LAUNCH(triatt_bwd_q_kernel<256>, dim3(gq), dim3(256), LDS, (hipStream_t)stream, p);
+    DFOLD_LAUNCH(triatt_bwd_k_kernel<256>, dim3(gk), dim3(512), LDSK, (hipStream_t)stream, p);
   } else {
-    constexpr int LDS = 2 * 512 * 64 + 2 * 32 * (512 * 2 + 16) + 3 * 512 * 4;
+    constexpr int LDS = 2 * 512 * 64 + 2 * 32 * (512 * 2 + 16) + 3 * 512 * 4, LDSK = LDS + 2 * 3 * 16 * 64 * 4;
     DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<512>), LDS);
-    DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<512>), LDS);
-    DFOLD_LAUNCH(triatt_bwd_q_kernel<512>, dim3(gq), dim3(512), LDS, (hipStream_t)stream, p);
-    DFOLD_LAUNCH(triatt_bwd_k_kernel<512>, dim3(gk), dim3(512), LDS, (hipStream_t)stream, p);
+    DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<512>), LDSK);
+    DFOLD_LAUNCH(triatt_bwd_q_kernel<512>, dim3(gq), dim3(256), LDS, (hipStream_t)stream, p);
+    DFOLD_LAUNCH(triatt_bwd_k_kernel<512>, dim3(gk), dim3(512), LDSK, (hipStream_t)stream, p);
   }
   return dfold_check_launch();
 }

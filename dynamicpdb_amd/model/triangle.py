@@ -509,15 +509,19 @@ def _triatt_stream_backward(x, mask, dout, inf, params):
          sb=(NN * cin, 0), sc=(H * NN, 0))
     dob = dout.reshape(R, cin)
     dob = dob.contiguous() if dob.dtype == BF16 else ops.cast_bf16(dob.float())
-    KB = (N + 127) // 128
+    # the same projections channel-major ([512][R]: the GEMM with swapped operands) -- the K^T / V^T / Q^T tiles of the kernels
+    projT = torch.empty((4 * HC, R), dtype=BF16, device=dev)
+    gemm(wcat, xn, projT, 4 * HC, R, cin, a_rows=rows_plain(cin), c_rows=rows_plain(R), ldb=cin)
+    KB = (N + 63) // 64 if N <= 256 else (N + 31) // 32         # key blocks of the second kernel (csrc/triatt_bwd.hip)
     IC = max(1, min(16, N, 512 // (B * H * KB)))
     dproj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)
     ogb = torch.empty((R, HC), dtype=BF16, device=dev)
     dos = torch.empty((R, HC), dtype=BF16, device=dev)
+    dosT = torch.empty((HC, R), dtype=BF16, device=dev)
     stats = torch.empty((B * N, H, 3, N), dtype=torch.float32, device=dev)
     dtri_part = torch.empty((IC, B, H, NN), dtype=torch.float32, device=dev)
-    check(L.dfold_triatt_bwd_core(_p(proj), _p(tri), _p(maskf), _p(dob), _p(CACHE.wt(w_o)), _p(dproj), _p(ogb), _p(dos), _p(stats),
-                                  _p(dtri_part), c_int32(B), c_int32(N), c_int32(IC), ctypes_float(inf),
+    check(L.dfold_triatt_bwd_core(_p(proj), _p(projT), _p(tri), _p(maskf), _p(dob), _p(CACHE.wt(w_o)), _p(dproj), _p(ogb), _p(dos),
+                                  _p(dosT), _p(stats), _p(dtri_part), c_int32(B), c_int32(N), c_int32(IC), ctypes_float(inf),
                                   ctypes_float(1.0 / math.sqrt(C)), stream()), "dfold_triatt_bwd_core")
     if IC > 1:
         dtri = torch.empty((B, H, NN), dtype=torch.float32, device=dev)

@@ -259,15 +259,18 @@ int dfold_sum_leading(const float* x, float* out, int32_t I, int64_t n, int64_t 
  * openfold/model/triangular_attention.py:78-139 / primitives.py:219-243,377-448 for 4 heads x 32 channels, in the operator's
  * own coordinates (the ending node passes transposed tensors), N % 8 == 0, N <= 512.  Logits, probabilities and their
  * gradients are recomputed per pair-tensor row on the matrix cores and never reach HBM.
- *   proj bf16 [B N N][512]: q | k | v | g (gate PRE-activation) of every cell (the recomputed projections);
+ *   proj bf16 [B N N][512]: q | k | v | g (gate PRE-activation) of every cell (the recomputed projections) and proj_t
+ *   bf16 [512][B N N], the same values channel-major (the projection GEMM with swapped operands: the K^T / V^T / Q^T tiles);
  *   tri fp32 [B][4][N][N] triangle bias; mask fp32 [B][N][N]; dout bf16 [B N N][128]; w_o_t bf16 [128][128] = W_o^T;
  * -> dproj bf16 [B N N][512]: dq | dk | dv | dg;  og bf16 [B N N][128] = o * sigmoid(g) (operand of dW_o);
  *    dtri_part fp32 [n_chunks][B][4][N][N]: the triangle-bias gradient summed over the rows of each chunk (add the chunks
- *    with dfold_sum_leading);  workspace: do_scratch bf16 [B N N][128], stats fp32 [B N][4][3][N].
+ *    with dfold_sum_leading);  workspace: do_scratch bf16 [B N N][128], do_t_scratch bf16 [128][B N N], stats fp32
+ *    [B N][4][3][N].
  * inf: mask bias = inf * (mask - 1); scale = 1 / sqrt(32). */
-int dfold_triatt_bwd_core(const void* proj_bf16, const float* tri, const float* mask, const void* dout_bf16,
-                          const void* w_o_t_bf16, void* dproj_bf16, void* og_bf16, void* do_scratch_bf16, float* stats,
-                          float* dtri_part, int32_t B, int32_t N, int32_t n_chunks, float inf, float scale, void* stream);
+int dfold_triatt_bwd_core(const void* proj_bf16, const void* proj_t_bf16, const float* tri, const float* mask,
+                          const void* dout_bf16, const void* w_o_t_bf16, void* dproj_bf16, void* og_bf16, void* do_scratch_bf16,
+                          void* do_t_scratch_bf16, float* stats, float* dtri_part, int32_t B, int32_t N, int32_t n_chunks, float inf,
+                          float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused forward of the triangle operators for c_z = c_hidden = 128 / c_in = 128, 4 heads x 32 (csrc/pair_fused.hip).

@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--cpu", action="store_true", help="time the CPU oracle too (N <= 256)")
     ap.add_argument("--unfused", action="store_true", help="time the unfused round-1 chain too")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="time forward + backward through autograd too: the streaming backward "
+                    "(triangle attention: csrc/triatt_bwd.hip) next to the intermediate-keeping chain, with peak device memory")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -191,6 +193,24 @@ def main():
                     tu = _time(lambda: m(z.float(), mask=mask), max(3, a.reps // 4))
                     os.environ["DFOLD_TRI_FUSED"] = "1"
                     row["unfused_chain_ms"] = round(tu * 1e3, 4)
+            if a.backward:
+                gy = torch.randn(B, N, N, 128, device=dev).to(dt)
+
+                def fb():
+                    zz = z.detach().requires_grad_(True)
+                    m.zero_grad(set_to_none=True)
+                    m(zz, mask=mask).backward(gy)
+                for tag, env in (("stream", "1"), ("chain", "0")):
+                    os.environ["DFOLD_TRIATT_STREAM_BWD"] = env
+                    os.environ["DFOLD_TRIMUL_STREAM_BWD"] = env
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    torch.cuda.reset_peak_memory_stats()
+                    base = torch.cuda.memory_allocated()
+                    tb = _time(fb, max(3, a.reps // 4), warm=2)
+                    row[f"fwd_bwd_{tag}_ms"] = round(tb * 1e3, 4)
+                    row[f"fwd_bwd_{tag}_peak_MB"] = round((torch.cuda.max_memory_allocated() - base) / 2 ** 20, 1)
+                os.environ["DFOLD_TRIATT_STREAM_BWD"] = os.environ["DFOLD_TRIMUL_STREAM_BWD"] = "1"
             if a.cpu and N <= 256:
                 from oracle import dfold_oracle as O
                 P = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}

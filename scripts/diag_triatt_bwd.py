@@ -31,14 +31,16 @@ def run(B, N, seed=0, chunks=None):
     wo = (torch.randn(128, 128, generator=g) / math.sqrt(128)).to(torch.bfloat16).to(dev)      # [n][hc]
     woT = wo.t().contiguous()
     inf, scale = 1e9, 1.0 / math.sqrt(C)
-    KB = (N + 127) // 128
+    KB = (N + 63) // 64 if N <= 256 else (N + 31) // 32
+    projT = proj.t().contiguous()
+    dosT = torch.empty((128, R), dtype=torch.bfloat16, device=dev)
     IC = chunks or max(1, min(16, N, 512 // (B * H * KB)))
     dproj = torch.full((R, 512), float("nan"), dtype=torch.bfloat16, device=dev)
     og = torch.full((R, 128), float("nan"), dtype=torch.bfloat16, device=dev)
     dos = torch.empty((R, 128), dtype=torch.bfloat16, device=dev)
     stats = torch.empty((B * N, H, 3, N), dtype=torch.float32, device=dev)
     dtp = torch.full((IC, B, H, N, N), float("nan"), dtype=torch.float32, device=dev)
-    rc = _lib.lib().dfold_triatt_bwd_core(_p(proj), _p(tri), _p(mask), _p(dob), _p(woT), _p(dproj), _p(og), _p(dos), _p(stats), _p(dtp),
+    rc = _lib.lib().dfold_triatt_bwd_core(_p(proj), _p(projT), _p(tri), _p(mask), _p(dob), _p(woT), _p(dproj), _p(og), _p(dos), _p(dosT), _p(stats), _p(dtp),
                                           c_int32(B), c_int32(N), c_int32(IC), ctypes_float(inf), ctypes_float(scale), _lib.stream())
     assert rc == 0, rc
     torch.cuda.synchronize()
@@ -71,7 +73,7 @@ def run(B, N, seed=0, chunks=None):
 
 
 if __name__ == "__main__":
-    sizes = [int(a) for a in sys.argv[1:]] or [64, 40, 256, 264]
+    sizes = [int(a) for a in sys.argv[1:]] or [64, 40, 256, 264, 136, 512]
     bad = False
     for n in sizes:
         r = run(2 if n <= 128 else 1, n, seed=n)
