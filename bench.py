@@ -390,12 +390,32 @@ def main():
     # the instrumented extra step contains the gradient all-reduce: EVERY rank runs it (a collective issued by rank 0
     # alone would pair with the other ranks' next step and hang the job at the end); rank 0 reports its own timings
     roof = conv_kernel_roofline(model, trainer, batches[-1], B, F, N) if args.mode == "all_frames" else None
-    waits = None
+    waits, dp_info = None, None
     if world > 1:        # how long each rank's stream sat in finish() waiting for the gradient collectives, per step
         w = torch.tensor([sum(trainer.reducer.wait_ms) / max(1, len(trainer.reducer.wait_ms))], device=dev, dtype=torch.float64)
         allw = [torch.zeros_like(w) for _ in range(world)]
         dist.all_gather(allw, w)
         waits = [round(float(x), 3) for x in allw]
+        # what makes the N > 1 line explain itself: who took part, how early each bucket's collective could start relative
+        # to the end of backward (the time available for overlap), and what one bucket achieves on the wire in isolation
+        me = "rank%d:cuda%d:%s" % (rank, local, getattr(torch.cuda.get_device_properties(dev), "gcnArchName", "?").split(":")[0])
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        red = trainer.reducer
+        lead = list(red.bucket_lead_ms)                 # last timed step (events resolved at the instrumented step's begin)
+        prof = red.profile_buckets(reps=3)              # collective: every rank calls it
+        for row in prof:
+            row["launched_ms_before_backward_end"] = lead[row["bucket"]] if row["bucket"] < len(lead) else None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        gb = sum(r["mb"] for r in prof)
+        dp_info = {"backend": dist.get_backend(), "rccl_version": ver, "ranks_seen": seen, "gradient_mb_per_step": round(gb, 1),
+                   "payload_dtype": "bf16" if red.payload_dtype == torch.bfloat16 else "fp32", "buckets": prof,
+                   "note": "launched_ms_before_backward_end: compute-stream time between a bucket's all-reduce launch and the end "
+                           "of backward (what can overlap; buckets launched in finish() show ~0); isolated_ms / bus_GBps: the same "
+                           "bucket's collective alone, bus bandwidth = 2 (n-1)/n bytes / time (xGMI ring: per-link bound)"}
     # second timed region: the engine's training-step mode (Trainer default).  Loss, gradients and the optimizer update
     # are identical (tests/test_network_gpu.py::test_last_frame_only_training_mode_equals_full); the conv tower only
     # evaluates the dependency cone of the last frame, the one frame the live loss terms and frame updates read.
@@ -440,6 +460,7 @@ def main():
         if waits is not None:
             line["allreduce_wait_ms"] = waits
             line["param_broadcast_mb"] = round(trainer.bytes_broadcast / 1e6, 1)
+            line["dp"] = dp_info
     del batches
     if world == 1 and rank == 0:
         del trainer, model

@@ -74,9 +74,12 @@ def broadcast_parameters(tensors, src=0, group=None):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, force=False):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, force=False, payload_dtype=None):
         """params: the trainable parameters in a fixed order (identical on all ranks).  force: run the collectives even
-        in a single-rank world (test / single-GPU coverage of the multi-GPU code path)."""
+        in a single-rank world (test / single-GPU coverage of the multi-GPU code path).  payload_dtype: torch.bfloat16
+        sends every bucket as bf16 (half the bytes per xGMI link; the bucket is rounded once before and the average once
+        after the collective -- relative error 2^-8 per gradient entry, opt-in; default / None = fp32, exact); the
+        environment variable DFOLD_DP_GRAD_BF16=1 selects it without a code change."""
         self.params = list(params)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
@@ -102,6 +105,13 @@ class GradReducer:
         self._stage_host = None           # gloo without device-tensor support: buckets go through host memory (tests)
         self.timing = False               # record how long the stream waits for the collectives in finish()
         self._ev, self.wait_ms = None, []
+        # timing mode also records, per bucket, how long before the end of backward its collective was launched (the
+        # time available for overlap): events on the compute stream at each launch and at the start of finish()
+        self._launch_ev, self._bwd_end_ev, self.bucket_lead_ms = {}, None, []
+        import os
+        if payload_dtype is None and os.environ.get("DFOLD_DP_GRAD_BF16", "0") == "1":
+            payload_dtype = torch.bfloat16
+        self.payload_dtype = payload_dtype
 
     # ---------------------------------------------------------------- wiring
     def attach(self, model=None):
@@ -136,6 +146,10 @@ class GradReducer:
             b.synchronize()
             self.wait_ms.append(a.elapsed_time(b))
             self._ev = None
+            if self._bwd_end_ev is not None:
+                self.bucket_lead_ms = [round(self._launch_ev[i].elapsed_time(self._bwd_end_ev), 3) if i in self._launch_ev else None
+                                       for i in range(len(self.buckets))]
+        self._launch_ev, self._bwd_end_ev = {}, None
         if not self.active:
             for p in self.params:
                 p.grad = None
@@ -210,6 +224,16 @@ class GradReducer:
                 if not self._avg and self.world > 1:
                     t.div_(self.world)
             return done
+        if self.payload_dtype is not None and t.dtype != self.payload_dtype:
+            pay = t.to(self.payload_dtype)        # rounded once; the collective moves half the bytes
+            w = dist.all_reduce(pay, op=op, group=self.group, async_op=True)
+
+            def done():
+                w.wait()
+                t.copy_(pay)
+                if not self._avg and self.world > 1:
+                    t.div_(self.world)
+            return done
         w = dist.all_reduce(t, op=op, group=self.group, async_op=True)
 
         def done():
@@ -220,6 +244,10 @@ class GradReducer:
 
     def _launch(self, b):
         s, e = self.buckets[b]
+        if self.timing and self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._launch_ev[b] = ev
         self._works[b] = self._reduce_async(self.flat[s:e])
         self._launched[b] = True
         # nothing may write the bucket while its collective is in flight (RCCL stream / gloo thread + host copy-back): a late
@@ -233,6 +261,9 @@ class GradReducer:
         if not self.active:
             return
         dev = None
+        if self.timing and torch.cuda.is_available() and self.params and self.params[0].is_cuda:
+            self._bwd_end_ev = torch.cuda.Event(enable_timing=True)
+            self._bwd_end_ev.record()             # the compute stream has reached the end of backward
         if self.flat is None:
             self._build()
             for b in range(len(self.buckets)):
@@ -295,6 +326,30 @@ class GradReducer:
         # this step's (now exact) gradients stay where they are for the optimizer; the next begin_step forgets the
         # structure and discovers again
         self._pending_rebuild = True
+
+    def profile_buckets(self, reps=3):
+        """Each bucket's collective in isolation (blocking, back to back; call between steps, on every rank): milliseconds
+        and the achieved bus bandwidth 2 (n - 1) / n * bytes / time -- what one link of the xGMI ring sustains for that
+        message size.  Leaves the gradients untouched (works on a scratch copy)."""
+        out = []
+        if not self.active or self.flat is None or not self.flat.is_cuda:
+            return out
+        n = self.world
+        for b, (s, e) in enumerate(self.buckets):
+            scratch = self.flat[s:e].clone()
+            self._reduce_async(scratch)()             # warm-up (communicator set-up, first-touch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                self._reduce_async(scratch)()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            nbytes = (e - s) * (2 if self.payload_dtype == torch.bfloat16 else 4)
+            out.append({"bucket": b, "mb": round(nbytes / 1e6, 2), "isolated_ms": round(ms, 3),
+                        "bus_GBps": round(2.0 * (n - 1) / max(n, 1) * nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        return out
 
     def rebuild(self):
         """forget the discovered structure (the next step is a discovery step again)"""

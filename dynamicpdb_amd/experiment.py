@@ -53,13 +53,14 @@ class Trainer:
     uses DistributedDataParallel, :615).  Adam(amsgrad=True, lr) as train_DFOLD_dynamics.py:412."""
 
     def __init__(self, model, lr=1e-4, loss_kwargs=None, bucket_bytes=32 << 20, last_frame_only=True, force_reduce=False,
-                 sync_params=True):
+                 sync_params=True, grad_payload_dtype=None):
         """last_frame_only: run the model in its training-step mode (the live loss terms of loss_fn and the frame
         updates read the last frame of each window only, so the conv tower evaluates just that frame's dependency
         cone; identical loss and gradients, see DFOLDIpaScore.forward).  False = every frame, as the reference.
         force_reduce: run the gradient collectives even in a single-rank world (coverage of the multi-GPU path on one
         GPU).  sync_params: in a multi-rank world, start from rank 0's parameters and buffers like the reference's
-        DistributedDataParallel wrap does (train_DFOLD_dynamics.py:615; every rank is seeded differently, :419)."""
+        DistributedDataParallel wrap does (train_DFOLD_dynamics.py:615; every rank is seeded differently, :419).
+        grad_payload_dtype: torch.bfloat16 halves the gradient bytes on the wire (dp.GradReducer, opt-in; default fp32)."""
         from .dp import GradReducer, broadcast_parameters
         self.model = model
         self.bytes_broadcast = 0
@@ -73,7 +74,8 @@ class Trainer:
         else:
             self.opt = torch.optim.Adam(self.params, lr=lr, amsgrad=True)
         self.loss_kwargs = loss_kwargs or {}
-        self.reducer = GradReducer(self.params, bucket_bytes=bucket_bytes, force=force_reduce).attach(model)
+        self.reducer = GradReducer(self.params, bucket_bytes=bucket_bytes, force=force_reduce,
+                                   payload_dtype=grad_payload_dtype).attach(model)
         self.world = self.reducer.world
 
     def begin_step(self):
