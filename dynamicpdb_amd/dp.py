@@ -117,13 +117,25 @@ class GradReducer:
     def attach(self, model=None):
         if not self.active:
             return self
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_accumulated))
         if model is not None:
             for m in model.modules():
                 tower_of = getattr(m, "tower", None)
                 if callable(tower_of) and hasattr(m, "_tower"):
                     self._towers.append(m)
+        # A conv tower hands its layers' gradients over itself (ops.ConvTower.finalize_layer -> mark_ready), one layer at a
+        # time while its last backward application is still running.  Its parameters get NO autograd hook: torch fires a
+        # post-accumulate hook even when the node returned no gradient for the parameter (observed with torch 2.10: one
+        # firing per backward pass, AFTER the tower's last application has returned), which the discovery step would count as
+        # a second accumulation event -- every conv bucket (89 % of the gradient bytes) would then wait for it and start its
+        # all-reduce only at the end of the tower's backward instead of layer by layer.
+        managed = set()
+        for m in self._towers:
+            ws, bs = m._params()
+            managed.update(id(p) for p in list(ws) + list(bs))
+        self._tower_managed = managed
+        for p in self.params:
+            if id(p) not in managed:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_accumulated))
         return self
 
     def _bind_towers(self):

@@ -427,6 +427,15 @@ def _dp_real_model_worker(rank, world, port, q):
         for _ in range(3):
             loss, _ = tr.update_fn(shards[rank])
         got = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        # the conv tower's parameters complete ONCE per step (its own layer-by-layer hand-over; no spurious autograd hook
+        # event), in the order in which the last backward application finalises the layers: 7, 6, ..., 0
+        red = tr.reducer
+        names = {id(p): n for n, p in model.named_parameters()}
+        conv_expected = sorted({red._expected[k] for k, n in names.items() if ".conv_0." in n and k in red._expected})
+        conv_order = [names[id(p)].split("conv_0.")[1] for ps in red._bucket_params for p in ps if ".conv_0." in names[id(p)]
+                      and names[id(p)].endswith("weight")]
+        tr.begin_step()                                      # resolves the last step's per-bucket launch events
+        lead = list(red.bucket_lead_ms)
         # the mean of the per-rank gradients, computed locally on the (now common) weights without any reducer
         tr.reducer.detach()
         tr.reducer.active = False
@@ -443,6 +452,7 @@ def _dp_real_model_worker(rank, world, port, q):
         gmax = max(float(v.norm()) for v in want.values())
         worst = max(float((got[n].double() - want[n]).norm()) / max(float(want[n].norm()), 1e-3 * gmax) for n in want)
         q.put((rank, dict(checksum=ck, worst=worst, same_keys=set(got) == set(want), launched=launched,
+                          conv_expected=conv_expected, conv_order=conv_order, lead=lead,
                           n_buckets=len(tr.reducer.buckets), wait_ms=list(tr.reducer.wait_ms),
                           bytes_broadcast=tr.bytes_broadcast, staged=bool(tr.reducer._stage_host))))
     except Exception as e:   # surface the failure in the parent instead of a queue timeout
@@ -479,5 +489,11 @@ def test_data_parallel_real_model_two_ranks_on_one_gpu():
         assert info["worst"] < 2e-3, info["worst"]
         assert info["n_buckets"] >= 8 and len(info["launched"]) == 2 and all(all(l) for l in info["launched"]), info["launched"]
         assert len(info["wait_ms"]) >= 1
+        # one accumulation event per conv parameter and step; buckets cut in the hand-over order of the last backward
+        # application (top layer first), each launched strictly earlier than the next (layer-by-layer overlap with backward)
+        assert info["conv_expected"] == [1], info["conv_expected"]
+        assert info["conv_order"] == ["conv4.2.weight", "conv4.0.weight", "conv3.2.weight", "conv3.0.weight", "conv2.2.weight",
+                                      "conv2.0.weight", "conv1.2.weight", "conv1.0.weight"], info["conv_order"]
     print("2-rank real model on one GPU: worst gradient deviation from the mean of per-rank gradients",
-          max(res[0]["worst"], res[1]["worst"]), "host-staged gloo:", res[0]["staged"], "wait_ms", res[0]["wait_ms"])
+          max(res[0]["worst"], res[1]["worst"]), "host-staged gloo:", res[0]["staged"], "wait_ms", res[0]["wait_ms"],
+          "bucket launch lead before the end of backward (ms):", res[0]["lead"])
