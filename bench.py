@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--nres", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=8)
+    ap.add_argument("--cpu-baseline-frames", type=int, default=32, help="window length of the CPU leg (default: the bench's own 32 "
+                    "frames: one warm-up + 2 timed iterations, about 4 minutes of host time)")
     ap.add_argument("--selftest-dist", action="store_true",
                     help="only rendezvous (nccl with GPUs, gloo without), all-reduce one number, report n_gpus")
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
@@ -232,9 +233,9 @@ def cpu_baseline(F, N, seed_w=0):
                       f"iterations ({timed[0]:.2f} s, {timed[1]:.2f} s) after same-shape warm-up iterations at "
                       + ", ".join(f"{k} threads {v:.2f} s" for k, v in sorted(warm.items())) + f"; {cores} usable hardware threads = "
                       f"{threads} physical cores x SMT{smt}, one torch CPU thread per core (all {cores}: measured 15x slower, "
-                      "profiles/r3_bench_cpu_threads.txt); the bench's windows are 32 frames: the per-frame "
-                      "conv work T(F)/F grows from 4.25 taps (F=8) to 4.81 (F=32), so this 8-frame rate OVERSTATES the CPU's "
-                      "32-frame rate by up to 13 % (conservative for any GPU/CPU ratio)",
+                      "profiles/r3_bench_cpu_threads.txt)" + ("" if F == 32 else "; the bench's windows are 32 frames: the per-frame "
+                      f"conv work T(F)/F grows from {T(F) / F:.2f} taps (F={F}) to 4.81 (F=32), so this rate OVERSTATES the CPU's "
+                      "32-frame rate (conservative for any GPU/CPU ratio)"),
             "reference_probe": {"value": 0.43, "unit": "frames/s", "cores": 8, "shape": "1 window, 2 frames x N_res=256, fwd+bwd",
                                 "source": "the reference's own code (FullScoreNetwork fwd+bwd) timed in the build container, "
                                           "SURVEY.md section 6 [probe]; the reference does not exist on the GPU box"}}

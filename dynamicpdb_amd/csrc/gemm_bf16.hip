@@ -923,7 +923,11 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   // many small batch items whose 256 x 256 tiles would not even fill the chip once (the triangle contraction at
   // N_res = 256: 128 channel planes = 128 tiles for 256 CUs): 256 x 128 tiles instead (19.5 -> 15.2 us there)
   const bool half_tiles = tilesq * d->nbatch < 256 && d->M >= 256 && d->nbatch >= 64 && steps >= 4 && tiles256 * d->nbatch >= 192;
-  if (!half_tiles && variant >= 256 && variant != 2560 && variant != 3201 && role == 0 && (d->N % 256) == 0 && (d->seglen % BK) == 0 && d->M >= 256 &&
+  // (a plain dense product with fp32 output does not take this form: its fp32 epilogue is not staged through LDS, and the
+  // 256 x 128 kernel below ran the step's fp32-output projections 1.4 - 2.4 x faster -- 65536 x 256 x 3072: 235 -> 171 us,
+  // 65536 x 256 x 256: 115 -> 47 us, scripts/bench_gemm_shapes.py, round 4)
+  const bool dense_f32 = d->nbatch == 1 && !(d->flags & DFOLD_GEMM_OUT_BF16);
+  if (!half_tiles && !dense_f32 && variant >= 256 && variant != 2560 && variant != 3201 && role == 0 && (d->N % 256) == 0 && (d->seglen % BK) == 0 && d->M >= 256 &&
       steps >= 2 && tilesq * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
     static bool attrq_done = false;
     const size_t lds = 2 * (A3_BYTES + 256 * BK * 2);
