@@ -124,12 +124,17 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     avg_s = sum(ms) / len(ms) * 1e-3
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r3_pmc_conv.json")     # HBM-side bytes per launch from the committed PMC passes
-    if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
-        with open(pmc) as fh:
-            c = json.load(fh)
-        traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
+    traffic, traffic_source = None, None
+    # HBM-side bytes per launch: NOT measured in this run (rocprofv3 counter passes cannot ride on a timed run) but read
+    # from the newest committed PMC pass of the same kernel at the same shape; `traffic_source` names the file
+    for tag in ("r4", "r3"):
+        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_conv.json")
+        if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
+            with open(pmc) as fh:
+                c = json.load(fh)
+            traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
+            traffic_source = f"profiles/{tag}_pmc_conv.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, scripts/gpu_pmc.sh; not collected in this run)"
+            break
     second = None
     if wg_ms:      # the second-largest kernel of the step: the conv weight gradient (same algorithmic FLOPs per launch)
         wavg = sum(wg_ms) / len(wg_ms) * 1e-3
@@ -141,7 +146,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
                   "frac": round(flops / wavg / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": wt, "launches": len(wg_ms),
                   "avg_launch_ms": round(wavg * 1e3, 4), "flop_per_launch": flops}
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "dfold_mfma_gemm320_kernel<1, 5, true> (5x5 conv implicit GEMM, halo form, forward + dgrad launches)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
             "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "

@@ -12,8 +12,8 @@ run() {
   timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/ipmc_$tag -- \
       python "$R/scripts/bench_ipa.py" 256 --fwdbwd > /tmp/ipmc_$tag.log 2>&1 < /dev/null
   echo "pmc $tag rc=$?"
-  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/ipmc_$tag > "$R/gpurun_out/r3_ipa_pmc_$tag.txt" 2>&1 < /dev/null
-  grep -i "ipa_" "$R/gpurun_out/r3_ipa_pmc_$tag.txt" | cut -c1-420
+  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/ipmc_$tag > "$R/gpurun_out/${PROF_TAG:-r4}_ipa_pmc_$tag.txt" 2>&1 < /dev/null
+  grep -i "ipa_" "$R/gpurun_out/${PROF_TAG:-r4}_ipa_pmc_$tag.txt" | cut -c1-420
 }
 for p in ${PASSES:-sq sq2 fetch write}; do
   case $p in

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 view of the fused triangle kernels (run on the GPU box from the repo root):
 #   gpurun --timeout 500 -- 'bash scripts/gpu_triangle_profile.sh'
-# 1. kernel-trace stats of scripts/bench_triangle.py at N_res 256 and 512  -> gpurun_out/r3_triangle_kernel_stats.csv
+# 1. kernel-trace stats of scripts/bench_triangle.py at N_res 256 and 512  -> gpurun_out/${PROF_TAG:-r4}_triangle_kernel_stats.csv
 # 2. PMC passes (own runs; only --kernel-trace beside --pmc): SQ issue/stall buckets, HBM-side bytes, L2 hit rate
 #    -> gpurun_out/r2_triangle_pmc_{sq,sq2,fetch,write}.txt  (per-kernel averages, scripts/pmc_summary.py)
 set -u
@@ -14,15 +14,15 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tprof -
     python "$R/scripts/bench_triangle.py" $ARGS > /tmp/tb.log 2>&1 < /dev/null
 echo "kernel-trace rc=$?"
 f=$(find /tmp/tprof -name "*kernel_stats.csv" 2>/dev/null | head -n 1)
-if [ -n "$f" ]; then cp "$f" "$R/gpurun_out/r3_triangle_kernel_stats.csv"; head -n 14 "$f" | cut -c1-170; fi
+if [ -n "$f" ]; then cp "$f" "$R/gpurun_out/${PROF_TAG:-r4}_triangle_kernel_stats.csv"; head -n 14 "$f" | cut -c1-170; fi
 run() {  # $1 = tag, rest = counters
   tag=$1; shift
   rm -rf /tmp/tpmc_$tag
   timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/tpmc_$tag -- \
       python "$R/scripts/bench_triangle.py" ${PMC_ARGS:---n 256 --reps 2 --no-stages} > /tmp/tpmc_$tag.log 2>&1 < /dev/null
   echo "pmc $tag rc=$?"
-  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/tpmc_$tag > "$R/gpurun_out/r3_triangle_pmc_$tag.txt" 2>&1 < /dev/null
-  grep -i "pair_proj\|trimul_out\|triatt_core\|gemm" "$R/gpurun_out/r3_triangle_pmc_$tag.txt" | cut -c1-400
+  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/tpmc_$tag > "$R/gpurun_out/${PROF_TAG:-r4}_triangle_pmc_$tag.txt" 2>&1 < /dev/null
+  grep -i "pair_proj\|trimul_out\|triatt_core\|gemm" "$R/gpurun_out/${PROF_TAG:-r4}_triangle_pmc_$tag.txt" | cut -c1-400
 }
 for p in ${PASSES:-sq sq2 fetch write}; do
   case $p in
