@@ -112,11 +112,86 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
     if (c < k) atomicAdd(dW + (long)o * k + c, aw[c]);
 }
 
+// The same with dx for k <= 8 (the rigid embedder: the frames carry a gradient): the row-wise sums over the 256 channels were
+// k wave reductions + an LDS atomic per row and wave (0.39 ms per call at config 3, 4 calls per step).  Here the
+// pre-activation gradients of a 32-row tile are parked in LDS (pitch 257: conflict-free for both phases) and the 32 x 8
+// (row, component) sums run as one thread each over the 256 channels.
+#define EMB_DXR 32
+__global__ __launch_bounds__(256) void embed_in_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              const float* __restrict__ b, const bf16_t* __restrict__ g,
+                                                              float* __restrict__ dW, float* __restrict__ db,
+                                                              float* __restrict__ dx, long P, int k, int D) {
+  __shared__ float xs[EMB_DXR][8];
+  __shared__ float wt[256][8];
+  __shared__ float gps[EMB_DXR][257];
+  const int o = threadIdx.x;
+  float w[8], aw[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    w[c] = c < k ? W[(long)o * k + c] : 0.f;
+    wt[o][c] = w[c];
+    aw[c] = 0.f;
+  }
+  const float bo = b[o];
+  float ab = 0.f;
+  const int pr = threadIdx.x >> 3, pc = threadIdx.x & 7;        // phase 2: (row of the tile, component)
+  for (long r0 = (long)blockIdx.x * EMB_DXR; r0 < P; r0 += (long)gridDim.x * EMB_DXR) {
+    const int rows = (int)min((long)EMB_DXR, P - r0);
+    __syncthreads();                                              // the previous tile's phase 2 is done with gps / xs
+    for (int e = threadIdx.x; e < EMB_DXR * 8; e += 256) {
+      const int r = e >> 3, c = e & 7;
+      xs[r][c] = (r < rows && c < k) ? x[(r0 + r) * k + c] : 0.f;
+    }
+    __syncthreads();
+    for (int rb = 0; rb < EMB_DXR; rb += 8) {
+      float gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gv[u] = rb + u < rows ? bf2f(g[(r0 + rb + u) * D + o]) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u;
+        float pre = bo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pre += xs[r][c] * w[c];
+        const float sg = sigmoid_f(pre);
+        const float gp = gv[u] * sg * (1.f + pre * (1.f - sg));      // rows past the end: gv = 0
+        ab += gp;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aw[c] += gp * xs[r][c];
+        gps[r][o] = gp;
+      }
+    }
+    __syncthreads();
+    if (pr < rows && pc < k) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+      for (int oo = 0; oo < 256; oo += 4) {
+        a0 += gps[pr][oo] * wt[oo][pc];
+        a1 += gps[pr][oo + 1] * wt[oo + 1][pc];
+        a2 += gps[pr][oo + 2] * wt[oo + 2][pc];
+        a3 += gps[pr][oo + 3] * wt[oo + 3][pc];
+      }
+      dx[(r0 + pr) * k + pc] = (a0 + a1) + (a2 + a3);
+    }
+  }
+  atomicAdd(db + o, ab);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < k) atomicAdd(dW + (long)o * k + c, aw[c]);
+}
+
 extern "C" int dfold_embed_in_bwd(const float* x, const float* W, const float* b, const void* g_bf16, float* dW, float* db,
                                   float* dx, int64_t P, int32_t k, int32_t D, void* stream) {
   if (!x || !W || !b || !g_bf16 || !dW || !db || P <= 0 || k <= 0 || k > EMB_MAXK || D != 256) return DFOLD_EINVAL;
   // 512 workgroups (measured: 128 workgroups of 512 rows each ran 2.6x slower -- the row loop, not the closing
   // 256 x (k + 1) fp32 atomics per workgroup, sets the time)
+  if (dx != nullptr && k <= 8) {
+    long nb = (P + EMB_DXR - 1) / EMB_DXR;
+    if (nb > 1024) nb = 1024;
+    DFOLD_LAUNCH(embed_in_bwd_dx_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, W, b, (const bf16_t*)g_bf16, dW, db,
+                 dx, (long)P, k, D);
+    return dfold_check_launch();
+  }
   long blocks = (P + EMB_ROWS - 1) / EMB_ROWS;
   if (blocks > 512) blocks = 512;
   DFOLD_LAUNCH(embed_in_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, W, b, (const bf16_t*)g_bf16,

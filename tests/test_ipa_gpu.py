@@ -152,7 +152,7 @@ def test_embed_in_fwd_bwd():
     from dynamicpdb_amd.model import functional as Fm
     dev = torch.device("cuda:0")
     torch.manual_seed(4)
-    for k, need_dx in ((1, False), (3, False), (7, True), (14, False)):
+    for k, need_dx in ((1, False), (3, False), (3, True), (7, True), (8, True), (14, False), (14, True)):
         x = torch.randn(2, 5, 37, k, device=dev).requires_grad_(need_dx)
         w = torch.randn(256, k, device=dev).requires_grad_(True)
         b = (0.3 * torch.randn(256, device=dev)).requires_grad_(True)
