@@ -5,6 +5,7 @@ ragged sizes, with a batch axis, across key-chunk boundaries (N > 256) and for b
 Tolerances: every stage rounds its outputs to bf16 once (rel-L2 ~ 2^-9 = 2e-3 .. 4e-3); end to end as DESIGN.md
 (1.5e-2 forward, 3e-2 gradients)."""
 import math
+import os
 from ctypes import c_int32, c_void_p
 
 import numpy as np
@@ -305,12 +306,28 @@ def test_fused_bench_sizes_vs_oracle(name, N):
     assert float(d.max()) < 0.15, float(d.max())
 
 
-@pytest.mark.parametrize("name", ["tri_mul_out", "tri_mul_in", "tri_att_start", "tri_att_end"])
-def test_fused_nres256_gradients_vs_oracle(name):
-    """Backward at N_res 256 (one batch item) against the oracle's autograd: input gradient and every parameter
+@pytest.mark.parametrize("B,N,chunks", [(2, 64, None), (2, 40, None), (1, 256, None), (1, 264, None), (1, 136, None), (1, 512, None),
+                                        (1, 48, 5)])
+def test_triatt_stream_backward_stages_vs_fp64(B, N, chunks):
+    """The two launches of the streaming triangle-attention backward (csrc/triatt_bwd.hip) through the C ABI against fp64
+    math on the same bf16 operands: dq | dk | dv | dg, og, the triangle-bias gradient (summed over row chunks in registers),
+    the row statistics -- both template instances (N_res <= 256 / <= 512), ragged tiles, a row-chunk count that does not
+    divide N_res."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from scripts.diag_triatt_bwd import run
+    res = run(B, N, seed=N, chunks=chunks)
+    for k, v in res.items():
+        assert v < (1e-5 if k == "inv_l" else 6e-3), (k, v)
+
+
+@pytest.mark.parametrize("name,N", [("tri_mul_out", 256), ("tri_mul_in", 256), ("tri_att_start", 256), ("tri_att_end", 256),
+                                    ("tri_att_end", 512)])
+def test_fused_nres256_gradients_vs_oracle(name, N):
+    """Backward at N_res 256 (one batch item; triangle attention also at N_res 512, config 5's chain length, through the
+    N_res <= 512 instances of the streaming backward) against the oracle's autograd: input gradient and every parameter
     gradient, bf16 class."""
     dev = torch.device(DEV)
-    N = 256
     m = _rand_module(_names()[name](), 71)
     P = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
     m.to(dev)
