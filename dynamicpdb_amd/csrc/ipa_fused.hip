@@ -159,7 +159,8 @@ struct IpaFusedParams {
   const float* bias;    // [B, H, N, N]
   const float* mask;    // [B*F, N]
   const float* ctr;     // [B*F, 3]
-  bf16_t* o;            // [B*F, N, H*256]
+  bf16_t* o;            // [B*F, N, o_ld]: head h at columns h*256 (o_ld >= H*256: the row of a wider feature matrix)
+  long o_ld;
   float* o_pt;          // [B*F, N, H, 36]
   bf16_t* Pb;           // [B*F, H, N, N]
   float* P;             // optional fp32 copy of the probabilities (null: not written)
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_fwd_kernel(const IpaFusedPa
 
   // ---- epilogue: lane holds query l15, rows (channels / point components) m*16 + l4*4 + r ----
   if (q0 < N)       // (the phase-2 loop ended with a barrier: the LDS buffers are idle)
-    if_store_rows_bf16<16>(smem + w * (16 * (16 * 32 + 16)), oacc, p.o + ((bf * N + q0) * H + h) * (long)IF_C, (long)H * IF_C,
+    if_store_rows_bf16<16>(smem + w * (16 * (16 * 32 + 16)), oacc, p.o + (bf * N + q0) * p.o_ld + h * (long)IF_C, p.o_ld,
                            min(16, N - q0), IF_C, lane);
   if (qok) {
     float* prow = p.o_pt + ((bf * N + myq) * H + h) * 36L;
@@ -446,17 +447,18 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_fwd_kernel(const IpaFusedPa
 
 extern "C" int dfold_ipa_fused_fwd(const void* q_bf16, const void* kv_bf16, const void* QP_bf16, const void* KP_bf16,
                                    const void* VT_bf16, const float* kn, const float* bias, const float* mask, const float* ctr,
-                                   void* o_bf16, float* o_pt, void* P_bf16, float* P_f32, int32_t B, int32_t F, int32_t N,
-                                   int32_t H, int32_t NP, float alpha, float bias_scale, float inf, void* stream) {
+                                   void* o_bf16, int64_t o_ld, float* o_pt, void* P_bf16, float* P_f32, int32_t B, int32_t F,
+                                   int32_t N, int32_t H, int32_t NP, float alpha, float bias_scale, float inf, void* stream) {
   if (!q_bf16 || !kv_bf16 || !QP_bf16 || !KP_bf16 || !VT_bf16 || !kn || !bias || !mask || !ctr || !o_bf16 || !o_pt || !P_bf16)
     return DFOLD_EINVAL;
   if (B <= 0 || F <= 0 || N <= 0 || H <= 0 || (N & 7) || N > 512 || NP < N || (NP % IF_KC)) return DFOLD_EINVAL;
+  if (o_ld < (int64_t)H * IF_C || (o_ld & 7) || ((uintptr_t)o_bf16 & 15)) return DFOLD_EINVAL;
   const int qpw = N <= 256 ? 128 : 64;                   // queries per workgroup (8 resp. 4 waves)
   const long nwg = (long)B * F * H * ((N + qpw - 1) / qpw);
   if (nwg > 0x7fffffffL) return DFOLD_EINVAL;
   IpaFusedParams p;
   p.q = (const bf16_t*)q_bf16; p.kv = (const bf16_t*)kv_bf16; p.QP = (const bf16_t*)QP_bf16; p.KP = (const bf16_t*)KP_bf16;
-  p.VT = (const bf16_t*)VT_bf16; p.kn = kn; p.bias = bias; p.mask = mask; p.ctr = ctr; p.o = (bf16_t*)o_bf16; p.o_pt = o_pt;
+  p.VT = (const bf16_t*)VT_bf16; p.kn = kn; p.bias = bias; p.mask = mask; p.ctr = ctr; p.o = (bf16_t*)o_bf16; p.o_ld = o_ld; p.o_pt = o_pt;
   p.Pb = (bf16_t*)P_bf16; p.P = P_f32; p.BF = B * F; p.F = F; p.N = N; p.H = H; p.NP = NP; p.alpha = alpha;
   p.bias_scale = bias_scale; p.inf = inf;
   hipStream_t st = (hipStream_t)stream;

@@ -146,7 +146,8 @@ extern "C" int dfold_ipa_points_bwd(const float* raw_q, const float* raw_kv, con
 // o_pt_g [P][H][PV][3] (global frame) -> geo_l bf16 [P][4*NOV] = [l_x | l_y | l_z | |l|], geo_g bf16 [P][4*NOV] likewise for g
 //   l = R^T (g - t);  norms sqrt(|.|^2 + eps)
 __global__ __launch_bounds__(128) void ipa_outfeat_fwd_kernel(const float* __restrict__ o_pt, const float* __restrict__ t7,
-                                                              bf16_t* __restrict__ geo_l, bf16_t* __restrict__ geo_g, float eps) {
+                                                              bf16_t* __restrict__ geo_l, bf16_t* __restrict__ geo_g, long ld,
+                                                              float eps) {
   const long p = blockIdx.x;
   const int i = threadIdx.x;
   if (i >= NOV) return;
@@ -158,19 +159,19 @@ __global__ __launch_bounds__(128) void ipa_outfeat_fwd_kernel(const float* __res
   const float l0 = R[0] * u0 + R[3] * u1 + R[6] * u2;
   const float l1 = R[1] * u0 + R[4] * u1 + R[7] * u2;
   const float l2 = R[2] * u0 + R[5] * u1 + R[8] * u2;
-  bf16_t* ol = geo_l + p * 4 * NOV;
-  bf16_t* og = geo_g + p * 4 * NOV;
+  bf16_t* ol = geo_l + p * ld;
+  bf16_t* og = geo_g + p * ld;
   ol[i] = f2bf(l0); ol[NOV + i] = f2bf(l1); ol[2 * NOV + i] = f2bf(l2);
   ol[3 * NOV + i] = f2bf(sqrtf(l0 * l0 + l1 * l1 + l2 * l2 + eps));
   og[i] = f2bf(g0); og[NOV + i] = f2bf(g1); og[2 * NOV + i] = f2bf(g2);
   og[3 * NOV + i] = f2bf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2 + eps));
 }
 
-extern "C" int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t P, float eps,
-                                     void* stream) {
-  if (!o_pt || !t7 || !geo_l || !geo_g || P <= 0) return DFOLD_EINVAL;
+extern "C" int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t ld, int64_t P,
+                                     float eps, void* stream) {
+  if (!o_pt || !t7 || !geo_l || !geo_g || P <= 0 || ld < 4 * NOV) return DFOLD_EINVAL;
   DFOLD_LAUNCH(ipa_outfeat_fwd_kernel, dim3((unsigned)P), dim3(128), 0, (hipStream_t)stream, o_pt, t7, (bf16_t*)geo_l,
-               (bf16_t*)geo_g, eps);
+               (bf16_t*)geo_g, (long)ld, eps);
   return dfold_check_launch();
 }
 

@@ -348,8 +348,12 @@ class IpaCoreFn(Function):
       -> o [B,F,N,H*C] bf16, o_pt [B,F,N,H,12,3] fp32 (global frame), o_pair [B,F,N,H*c_z/4] bf16."""
 
     @staticmethod
-    def forward(ctx, q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw):
+    def forward(ctx, q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw, *rest):
+        """rest = (feat_ld,) -- only from IpaFeatFn, which calls this body directly with ITS context: `o` and `o_pair` are
+        written straight into the concatenated IPA feature matrix [B,F,N,feat_ld] = [o (H*C) | geo_l (384) | o_pair (H*PZ) |
+        geo_g (384)] (:504), returned as a fourth value; the tensors to save are handed back in `ctx._to_save`."""
         L = _lib.lib()
+        feat_ld = int(rest[0]) if rest else 0
         B, F, N, HC = q.shape
         H = hw.shape[0]
         C = HC // H
@@ -373,7 +377,10 @@ class IpaCoreFn(Function):
         pz = torch.empty((B, N, N, PZ), dtype=BF16, device=dev)
         gemm(z, wdz, pz, B * NN, PZ, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(PZ), ldb=CZ)
         Pb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
-        o = torch.empty((B, F, N, HC), dtype=BF16, device=dev)
+        direct = feat_ld >= HC + 768 + H * PZ and feat_ld % PZ == 0 and _ipa_fused_ok(N, C, q_pts, v_pts)
+        feats = torch.empty((B, F, N, feat_ld), dtype=BF16, device=dev) if direct else None
+        o = feats[..., :HC] if direct else torch.empty((B, F, N, HC), dtype=BF16, device=dev)
+        o_ld = feat_ld if direct else HC
         o_pt = torch.empty((B, F, N, H, 12, 3), dtype=torch.float32, device=dev)
         alpha = math.sqrt(1.0 / (3 * C))
         if _ipa_fused_ok(N, C, q_pts, v_pts):
@@ -395,7 +402,7 @@ class IpaCoreFn(Function):
             ops.transpose_bf16(kv, N, C, ld_src=2 * HC, out=VT, nbatch=B * F * H, nb1=H, bs_src=(N * 2 * HC, 2 * C), src_off=C,
                                bs_dst=(H * 400 * NPv, 400 * NPv), ld_dst=NPv)                      # rows 0..255 = v^T
             check(L.dfold_ipa_fused_fwd(_p(q), _p(kv), _p(QP), _p(KP), _p(VT), _p(kn), _p(bias_t), _p(mask), _p(ctr), _p(o),
-                                        _p(o_pt), _p(Pb), _p(P), c_int32(B), c_int32(F), c_int32(N), c_int32(H), c_int32(NPv),
+                                        c_int64(o_ld), _p(o_pt), _p(Pb), _p(P), c_int32(B), c_int32(F), c_int32(N), c_int32(H), c_int32(NPv),
                                         ctypes_float(alpha), ctypes_float(math.sqrt(1.0 / 3)), ctypes_float(1e5), stream()),
                   "dfold_ipa_fused_fwd")
         else:
@@ -413,20 +420,36 @@ class IpaCoreFn(Function):
             check(L.dfold_ipa_opt_fwd(_p(P), _p(v_pts), _p(o_pt), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
                   "dfold_ipa_opt_fwd")
         # o_pair[b,f,i,h,:] = sum_j P[b,f,h,i,j] pz[b,i,j,:] + b_dz   (:498-502): per (b,i) a [F*H, N] x [N, PZ] product
-        o_pair = torch.empty((B, F, N, H * PZ), dtype=BF16, device=dev)
-        gemm(Pb, pzT, o_pair, F * H, PZ, N, a_rows=rows_plain(NN), c_rows=rows_grid(PZ, H, F, F, N * H), ldb=N,
-             bias=b_dz.detach(), nbatch=B * N, nb1=N, sa=(F * H * NN, N), sb=(N * PZ * N, PZ * N),
-             sc=(F * N * H * PZ, H * PZ))
+        if direct:
+            # the same product written into columns [HC + 384, HC + 384 + H PZ) of the feature matrix: row (f, h) of batch
+            # (b, i) lands at ((b F + f) N + i) feat_ld + h PZ -- the grid row map with a "padded width" of N feat_ld / PZ cells
+            o_pair = feats[..., HC + 384:HC + 384 + H * PZ]
+            gemm(Pb, pzT, feats, F * H, PZ, N, a_rows=rows_plain(NN), c_rows=rows_grid(PZ, H, F, F, N * (feat_ld // PZ)), ldb=N,
+                 bias=b_dz.detach(), nbatch=B * N, nb1=N, sa=(F * H * NN, N), sb=(N * PZ * N, PZ * N),
+                 sc=(F * N * feat_ld, feat_ld), c_off=HC + 384)
+        else:
+            o_pair = torch.empty((B, F, N, H * PZ), dtype=BF16, device=dev)
+            gemm(Pb, pzT, o_pair, F * H, PZ, N, a_rows=rows_plain(NN), c_rows=rows_grid(PZ, H, F, F, N * H), ldb=N,
+                 bias=b_dz.detach(), nbatch=B * N, nb1=N, sa=(F * H * NN, N), sb=(N * PZ * N, PZ * N),
+                 sc=(F * N * H * PZ, H * PZ))
         del P            # the backward reads the bf16 probabilities (what the forward products consumed)
-        ctx.save_for_backward(q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, Pb, pz)
         ctx.dims = (B, F, N, H, C, CZ, PZ)
         ctx.ctr = ctr if _ipa_fused_ok(N, C, q_pts, v_pts) else None      # the backward's point terms use the same centre
+        saved = (q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hwc, Pb, pz)
+        if rest:
+            ctx._to_save = saved
+            return o, o_pt, o_pair, feats
+        ctx.save_for_backward(*saved)
         return o, o_pt, o_pair
 
     @staticmethod
     def backward(ctx, do, do_pt, do_pair):
+        return IpaCoreFn._backward(ctx, do, do_pt, do_pair)
+
+    @staticmethod
+    def _backward(ctx, do, do_pt, do_pair):
         L = _lib.lib()
-        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors[:11]
         B, F, N, H, C, CZ, PZ = ctx.dims
         HC, NN, dev = H * C, N * N, q.device
         alpha = math.sqrt(1.0 / (3 * C))
@@ -464,7 +487,7 @@ class IpaCoreFn(Function):
     @staticmethod
     def _backward_dkv(ctx, dSb, do):
         """dk = alpha dS^T q ; dv = P^T do  into one [B,F,N,H*2C] tensor"""
-        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors[:11]
         B, F, N, H, C, CZ, PZ = ctx.dims
         HC, NN = H * C, N * N
         alpha = math.sqrt(1.0 / (3 * C))
@@ -492,7 +515,7 @@ class IpaCoreFn(Function):
     def _backward_fused(ctx, L, do, do_pt, do_pair):
         """row pass in one launch (csrc/ipa_fused_bwd.hip): no fp32 dP, no transposed copy of k for dq; the pair-value term of dP
         leaves its product once as bf16"""
-        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors[:11]
         B, F, N, H, C, CZ, PZ = ctx.dims
         HC, NN, dev = H * C, N * N, q.device
         alpha = math.sqrt(1.0 / (3 * C))
@@ -529,7 +552,7 @@ class IpaCoreFn(Function):
     @staticmethod
     def _backward_pair_side(ctx, L, do_pair, dS, dq, dkv, dq_pts, dk_pts, dv_pts, dhw):
         """gradients of the pair-side inputs (z, linear_b, down_z) from dS and the bf16 probabilities"""
-        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors
+        q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, hw, Pb, pz = ctx.saved_tensors[:11]
         B, F, N, H, C, CZ, PZ = ctx.dims
         NN, dev = N * N, q.device
         FH = F * H
@@ -606,8 +629,8 @@ class IpaOutFeatFn(Function):
         o, t = o_pt.contiguous(), t7.contiguous()
         geo_l = torch.empty(lead + (384,), dtype=BF16, device=t7.device)
         geo_g = torch.empty(lead + (384,), dtype=BF16, device=t7.device)
-        check(_lib.lib().dfold_ipa_outfeat_fwd(_p(o), _p(t), _p(geo_l), _p(geo_g), c_int64(P), ctypes_float(eps), stream()),
-              "dfold_ipa_outfeat_fwd")
+        check(_lib.lib().dfold_ipa_outfeat_fwd(_p(o), _p(t), _p(geo_l), _p(geo_g), c_int64(384), c_int64(P), ctypes_float(eps),
+                                               stream()), "dfold_ipa_outfeat_fwd")
         ctx.save_for_backward(o, t)
         ctx.eps = eps
         return geo_l, geo_g
@@ -615,12 +638,54 @@ class IpaOutFeatFn(Function):
     @staticmethod
     def backward(ctx, dl, dg):
         o, t = ctx.saved_tensors
+        do, dt = IpaOutFeatFn._bwd(o, t, dl, dg, ctx.eps)
+        return do, dt, None
+
+    @staticmethod
+    def _bwd(o, t, dl, dg, eps):
         P = t.numel() // 7
         do, dt = torch.empty_like(o), torch.empty_like(t)
         dl, dg = dl.contiguous(), dg.contiguous()     # (slices of the concatenated feature gradient: real copies)
         check(_lib.lib().dfold_ipa_outfeat_bwd(_p(o), _p(t), _p(dl), _p(dg), _p(do), _p(dt),
-                                               c_int64(P), ctypes_float(ctx.eps), stream()), "dfold_ipa_outfeat_bwd")
-        return do, dt, None
+                                               c_int64(P), ctypes_float(eps), stream()), "dfold_ipa_outfeat_bwd")
+        return do, dt
+
+
+class IpaFeatFn(Function):
+    """Attention core + output features + cat([o, geo_l, o_pair, geo_g], -1) (:396-504) as ONE node whose output is the
+    operand of linear_out: the fused attention kernel, the pair-value product and the output-feature kernel write their
+    column blocks straight into it (no torch.cat: 403 MB read + written per block at config 3).  Same kernels and the same
+    backward as IpaCoreFn + IpaOutFeatFn (their bodies are called with this node's context); only for shapes the fused
+    attention kernel covers (`ipa_feat_direct_ok`)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw, t7, eps):
+        H, PZ = hw.shape[0], w_dz.shape[0]
+        HC = q.shape[-1]
+        ld = HC + 768 + H * PZ
+        o, o_pt, o_pair, feats = IpaCoreFn.forward(ctx, q, kv, q_pts, k_pts, v_pts, z, w_b, w_dz, b_dz, mask, hw, ld)
+        if feats is None:
+            raise RuntimeError("IpaFeatFn: shape not covered by the fused attention kernel (use IpaCoreFn + IpaOutFeatFn)")
+        t = t7.contiguous()
+        P = t.numel() // 7
+        check(_lib.lib().dfold_ipa_outfeat_fwd(_p(o_pt), _p(t), _p(feats, HC), _p(feats, HC + 384 + H * PZ), c_int64(ld), c_int64(P),
+                                               ctypes_float(eps), stream()), "dfold_ipa_outfeat_fwd")
+        ctx.save_for_backward(*ctx._to_save, o_pt, t)
+        ctx._to_save = None
+        ctx.eps, ctx.cols = eps, (HC, H * PZ)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        o_pt, t = ctx.saved_tensors[11:13]
+        HC, HP = ctx.cols
+        do_pt, dt7 = IpaOutFeatFn._bwd(o_pt, t, g[..., HC:HC + 384], g[..., HC + 384 + HP:], ctx.eps)
+        grads = IpaCoreFn._backward(ctx, g[..., :HC], do_pt, g[..., HC + 384:HC + 384 + HP])
+        return tuple(grads) + (dt7, None)
+
+
+def ipa_feat_direct_ok(N, C, q_pts, v_pts):
+    return os.environ.get("DFOLD_IPA_FEAT_DIRECT", "1") != "0" and _ipa_fused_ok(N, C, q_pts, v_pts)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -154,8 +154,10 @@ int dfold_ipa_points_fwd(const float* raw_q, const float* raw_kv, const float* t
                          int64_t P, void* stream);
 int dfold_ipa_points_bwd(const float* raw_q, const float* raw_kv, const float* t7, const float* dq_pts, const float* dk_pts,
                          const float* dv_pts, float* draw_q, float* draw_kv, float* dt7, int64_t P, void* stream);
-/* o_pt [P][8][12][3] global frame -> geo_l / geo_g bf16 [P][384] = [x|y|z|norm] of R^T(o_pt - t) and of o_pt (:470-488,504) */
-int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t P, float eps, void* stream);
+/* o_pt [P][8][12][3] global frame -> geo_l / geo_g bf16 [P][384] = [x|y|z|norm] of R^T(o_pt - t) and of o_pt (:470-488,504);
+ * ld: row stride of geo_l / geo_g in elements (384, or the row of the concatenated feature matrix they are columns of) */
+int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t ld, int64_t P, float eps,
+                          void* stream);
 int dfold_ipa_outfeat_bwd(const float* o_pt, const float* t7, const void* dgeo_l, const void* dgeo_g, float* do_pt, float* dt7,
                           int64_t P, float eps, void* stream);
 
@@ -218,13 +220,14 @@ int dfold_ipa_bias_grad(const float* dS, void* out_hn, void* out_nh, int64_t nh_
  * 256..399 of VT bf16 [B,F,H,400,NP] (three pieces x 48 rows of v_pts - ctr, key-contiguous; rows 0..255 = v^T are the
  * caller's, e.g. dfold_transpose_bf16; NP % 64 == 0, pad columns zero).
  * dfold_ipa_fused_fwd: q [B,F,N,H*256], kv [B,F,N,H*512] (k | v per head) bf16; bias fp32 [B,H,N,N] (linear_b(z), :396);
- * mask [B,F,N] -> o bf16 [B,F,N,H*256], o_pt fp32 [B,F,N,H,12,3] (global frame), P bf16 [B,F,H,N,N] and, if P_f32 != NULL,
+ * mask [B,F,N] -> o bf16 [B,F,N,o_ld] (head h at columns h*256; o_ld = H*256, or the row length of the concatenated feature
+ * matrix whose first columns o is), o_pt fp32 [B,F,N,H,12,3] (global frame), P bf16 [B,F,H,N,N] and, if P_f32 != NULL,
  * the same probabilities in fp32. */
 int dfold_ipa_aug_prep(const float* q_pts, const float* k_pts, const float* v_pts, const float* hw, const float* ctr,
                        void* QP_bf16, void* KP_bf16, float* kn, void* VT_bf16, int32_t B, int32_t F, int32_t N, int32_t H,
                        int32_t NP, float alpha, void* stream);
 int dfold_ipa_fused_fwd(const void* q_bf16, const void* kv_bf16, const void* QP_bf16, const void* KP_bf16, const void* VT_bf16,
-                        const float* kn, const float* bias, const float* mask, const float* ctr, void* o_bf16, float* o_pt,
+                        const float* kn, const float* bias, const float* mask, const float* ctr, void* o_bf16, int64_t o_ld, float* o_pt,
                         void* P_bf16, float* P_f32, int32_t B, int32_t F, int32_t N, int32_t H, int32_t NP, float alpha,
                         float bias_scale, float inf, void* stream);
 
