@@ -331,3 +331,81 @@ extern "C" int dfold_compose_bwd(const float* t7, const float* upd6, const float
                dupd6, (long)P);
   return dfold_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pair-side projections of an IPA block in ONE pass over the pair tensor (round 4): linear_b (:396, 8 heads; its bias drops
+// out of the softmax) and down_z (:498, 32 channels; its bias is added after the aggregation) were three GEMM launches, each
+// reading z [B,N,N,128] (134 MB at config 3) for a 8- / 32-wide output: 427 us per block.  Here a wave takes 16 consecutive
+// cells of a pair-tensor row, multiplies them with the 48 (8 + 8 zero + 32) weight rows on the matrix cores (12 MFMA
+// 16x16x32) and writes all three consumers' layouts: bias_t fp32 [B][8][N][N] (head-major planes), pz bf16 [B][N][N][32]
+// and pzT bf16 [B][N][32][N] (key-contiguous).  N % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned ppu32x4;
+__global__ __launch_bounds__(256) void ipa_pair_proj_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ wb,
+                                                            const bf16_t* __restrict__ wdz, float* __restrict__ bias_t,
+                                                            bf16_t* __restrict__ pz, bf16_t* __restrict__ pzT, int B, int N) {
+  __shared__ __attribute__((aligned(16))) bf16_t stage[4][16][40];       // wave-private [16 cells][32 channels] (+ pad)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // weight fragments (B operand: [n = output row l15][k = l4*8 ..]): tile 0 = linear_b (rows 8..15 zero), 1 / 2 = down_z
+  bf16x8 wf[3][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const ppu32x4 zero = {0u, 0u, 0u, 0u};
+    wf[0][ks] = l15 < 8 ? *(const bf16x8*)(wb + l15 * 128 + ks * 32 + l4 * 8) : __builtin_bit_cast(bf16x8, zero);
+    wf[1][ks] = *(const bf16x8*)(wdz + l15 * 128 + ks * 32 + l4 * 8);
+    wf[2][ks] = *(const bf16x8*)(wdz + (16 + l15) * 128 + ks * 32 + l4 * 8);
+  }
+  const int tpr = (N + 15) >> 4;                      // tiles per pair-tensor row
+  const long ntiles = (long)B * N * tpr;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (long t = (long)blockIdx.x * 4 + w; t < ntiles; t += (long)gridDim.x * 4) {
+    const int jt = (int)(t % tpr);
+    const long bi = t / tpr;                          // b * N + i
+    const int j0 = jt * 16;
+    const int cell = min(j0 + l15, N - 1);            // (cells past the end of the row: a valid address, results dropped)
+    const bf16_t* zr = z + (bi * N + cell) * 128 + l4 * 8;
+    bf16x8 a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a[ks] = *(const bf16x8*)(zr + ks * 32);
+    f32x4 acc[3] = {zero4, zero4, zero4};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], wf[c][ks], acc[c], 0, 0, 0);
+    // accumulator: rows = cells j0 + l4*4 + r, column = output row l15 of the tile
+    const int jq = j0 + l4 * 4;                       // N % 4 == 0: the four cells of a lane are in or out together
+    if (jq < N) {
+      const long b = bi / N;
+      const long i = bi - b * N;
+      if (l15 < 8) *(f32x4*)(bias_t + ((b * 8 + l15) * N + i) * (long)N + jq) = acc[0];
+#pragma unroll
+      for (int c = 1; c < 3; ++c)
+        *(uint2*)(pzT + (bi * 32 + (c - 1) * 16 + l15) * (long)N + jq) = make_uint2(pack2bf_hw(acc[c][0], acc[c][1]), pack2bf_hw(acc[c][2], acc[c][3]));
+    }
+    // pz rows through the wave's LDS tile: [cell][channel] -> 64-byte rows, 16 bytes per lane
+#pragma unroll
+    for (int c = 1; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[w][l4 * 4 + r][(c - 1) * 16 + l15] = f2bf_hw(acc[c][r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int row = lane >> 2, ch = (lane & 3) * 8;
+      if (j0 + row < N) *(uint4*)(pz + (bi * N + j0 + row) * 32 + ch) = *(const uint4*)&stage[w][row][ch];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int dfold_ipa_pair_proj(const void* z_bf16, const void* w_b_bf16, const void* w_dz_bf16, float* bias_t, void* pz_bf16,
+                                   void* pzT_bf16, int32_t B, int32_t N, void* stream) {
+  if (!z_bf16 || !w_b_bf16 || !w_dz_bf16 || !bias_t || !pz_bf16 || !pzT_bf16 || B <= 0 || N <= 0 || (N & 7)) return DFOLD_EINVAL;
+  const long ntiles = (long)B * N * ((N + 15) / 16);
+  long grid = (ntiles + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  DFOLD_LAUNCH(ipa_pair_proj_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z_bf16,
+               (const bf16_t*)w_b_bf16, (const bf16_t*)w_dz_bf16, bias_t, (bf16_t*)pz_bf16, (bf16_t*)pzT_bf16, B, N);
+  return dfold_check_launch();
+}

@@ -305,6 +305,7 @@ def _zT(z2d):
 
 _IPA_FUSED = os.environ.get("DFOLD_IPA_FUSED", "1") != "0"     # A/B switch: "0" = the unfused round-2 chain
 _IPA_BWD_FUSED = os.environ.get("DFOLD_IPA_BWD_FUSED", "1") != "0"   # "0": the product / VALU row pass chain instead of csrc/ipa_fused_bwd.hip
+_PAIR_PROJ_FUSED = os.environ.get("DFOLD_PAIR_PROJ_FUSED", "1") != "0"   # "0": linear_b / down_z as three GEMM launches (A/B runs)
 _IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
 _IPA_WS = {}
 
@@ -369,13 +370,19 @@ class IpaCoreFn(Function):
         # pair projections: bias_t [B,H,N,N] fp32, pzT [B,N,PZ,N] bf16, pz [B,N,N,PZ] bf16 (bias of linear_b drops out
         # of the softmax; bias of down_z is added after the aggregation since sum_j P = 1)
         bias_t = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
-        gemm(wb, z, bias_t, H, NN, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(NN), ldb=CZ, nbatch=B,
-             sb=(NN * CZ, 0), sc=(H * NN, 0))
         pzT = torch.empty((B, N, PZ, N), dtype=BF16, device=dev)
-        gemm(wdz, z, pzT, PZ, N, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(N), ldb=CZ, nbatch=B * N, nb1=N,
-             sb=(NN * CZ, N * CZ), sc=(N * PZ * N, PZ * N))
         pz = torch.empty((B, N, N, PZ), dtype=BF16, device=dev)
-        gemm(z, wdz, pz, B * NN, PZ, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(PZ), ldb=CZ)
+        if H == 8 and PZ == 32 and CZ == 128 and N % 8 == 0 and _PAIR_PROJ_FUSED:
+            # one pass over z for all three (csrc/ipa_geom.hip): three GEMM launches each read the 134 MB pair tensor for an
+            # 8- / 32-wide output (427 us per block at config 3)
+            check(L.dfold_ipa_pair_proj(_p(z), _p(wb), _p(wdz), _p(bias_t), _p(pz), _p(pzT), c_int32(B), c_int32(N), stream()),
+                  "dfold_ipa_pair_proj")
+        else:
+            gemm(wb, z, bias_t, H, NN, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(NN), ldb=CZ, nbatch=B,
+                 sb=(NN * CZ, 0), sc=(H * NN, 0))
+            gemm(wdz, z, pzT, PZ, N, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(N), ldb=CZ, nbatch=B * N, nb1=N,
+                 sb=(NN * CZ, N * CZ), sc=(N * PZ * N, PZ * N))
+            gemm(z, wdz, pz, B * NN, PZ, CZ, a_rows=rows_plain(CZ), c_rows=rows_plain(PZ), ldb=CZ)
         Pb = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
         direct = feat_ld >= HC + 768 + H * PZ and feat_ld % PZ == 0 and _ipa_fused_ok(N, C, q_pts, v_pts)
         feats = torch.empty((B, F, N, feat_ld), dtype=BF16, device=dev) if direct else None

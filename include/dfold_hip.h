@@ -154,6 +154,11 @@ int dfold_ipa_points_fwd(const float* raw_q, const float* raw_kv, const float* t
                          int64_t P, void* stream);
 int dfold_ipa_points_bwd(const float* raw_q, const float* raw_kv, const float* t7, const float* dq_pts, const float* dk_pts,
                          const float* dv_pts, float* draw_q, float* draw_kv, float* dt7, int64_t P, void* stream);
+/* Pair-side projections of an IPA block in one pass over z (round 4): linear_b (ipa_pytorch_dynamic.py:396) and down_z (:498),
+ * biases excluded (linear_b's drops out of the softmax, down_z's is added after the aggregation).  z bf16 [B][N][N][128],
+ * w_b bf16 [8][128], w_dz bf16 [32][128] -> bias_t fp32 [B][8][N][N], pz bf16 [B][N][N][32], pzT bf16 [B][N][32][N].  N % 8 == 0. */
+int dfold_ipa_pair_proj(const void* z_bf16, const void* w_b_bf16, const void* w_dz_bf16, float* bias_t, void* pz_bf16, void* pzT_bf16,
+                        int32_t B, int32_t N, void* stream);
 /* o_pt [P][8][12][3] global frame -> geo_l / geo_g bf16 [P][384] = [x|y|z|norm] of R^T(o_pt - t) and of o_pt (:470-488,504);
  * ld: row stride of geo_l / geo_g in elements (384, or the row of the concatenated feature matrix they are columns of) */
 int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t ld, int64_t P, float eps,
