@@ -251,6 +251,9 @@ class Grid:
 _N_CU = {}
 
 
+_SPLITK_CAP = int(os.environ.get("DFOLD_SPLITK_CAP", "4"))      # partial tiles in flight per CU the workspace is sized for
+
+
 def conv_splitk(M, CO, CI, device):
     """Split factor S for a narrow conv launch (few output rows, long K = 25 taps x CI): the 256x320 tile kernel runs
     one workgroup per CU, so tiles x S should fill the CUs in whole rounds.  Cost model in K steps: rounds x (steps/S + a
@@ -264,7 +267,7 @@ def conv_splitk(M, CO, CI, device):
     chunks, steps = CI // 64, 25 * (CI // 64)
     best, best_cost = 1, -(-tiles // n_cu) * (steps + 16)
     for S in (2, 4, 5, 10, 20):
-        if chunks % S or steps // S < 25 or tiles * S > 4 * n_cu:
+        if chunks % S or steps // S < 25 or tiles * S > _SPLITK_CAP * n_cu:
             continue
         cost = -(-tiles * S // n_cu) * (steps // S + 16)
         if cost < 0.9 * best_cost:
@@ -302,8 +305,8 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         S = conv_splitk(M, CO, CI, x.device)
         if S > 1:
             tiles = ((M + 255) // 256) * (CO // 320)
-            sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (4 * _N_CU[x.device] * 256 * 320,), torch.float32),
-                      splitk_cnt=ws.get("splitk_cnt", (4 * _N_CU[x.device],), torch.int32))
+            sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * _N_CU[x.device] * 256 * 320,), torch.float32),
+                      splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * _N_CU[x.device],), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
                 c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
                 seg_div=5, seg_div_mid=5, flags=flags, conv_frames=(f_lo << 16) | g.F if _SKIP_PAD_TAPS else 0)
