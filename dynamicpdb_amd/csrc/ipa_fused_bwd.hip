@@ -250,7 +250,11 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_bwd_kernel(const IpaBwdPara
   }
 
   // ---- chunk staging: global -> registers (one chunk ahead) -> LDS ----
+  // (addresses: a wave-uniform 64-bit base per operand + 32-bit lane offsets -- per-slot 64-bit pointers were what the
+  //  <32, 4> instance parked in scratch)
   ibu32x4 st[IB_SLOTS];
+  const bf16_t* const vbase = p.kv + ((bf * N) * H + h) * (long)(2 * IB_C) + IB_C;      // v half of (window, frame, head)
+  const bf16_t* const vpbase = p.VP + headrow * IB_PK;
   auto load_v = [&](int kc) __attribute__((always_inline)) {      // phase 1: 64 keys x (32 scalar + 28 point) chunks
 #pragma unroll
     for (int i = 0; i < IB_SLOTS; ++i) {
@@ -259,12 +263,12 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_bwd_kernel(const IpaBwdPara
         const int r = id >> 5, c = id & 31;
         int key = kc * IB_KC + r;
         key = key < N ? key : N - 1;                     // (rows past the end: finite values; their P is zero)
-        st[i] = *(const ibu32x4*)(p.kv + ((bf * N + key) * H + h) * (long)(2 * IB_C) + IB_C + c * 8);
+        st[i] = *(const ibu32x4*)(vbase + (unsigned)(key * H * (2 * IB_C) + c * 8));
       } else if (id < 2048 + 1792) {
         const int id2 = id - 2048, r = id2 / 28, c = id2 - r * 28;
         int key = kc * IB_KC + r;
         key = key < N ? key : N - 1;
-        st[i] = *(const ibu32x4*)(p.VP + (headrow + key) * IB_PK + c * 8);
+        st[i] = *(const ibu32x4*)(vpbase + (unsigned)(key * IB_PK + c * 8));
       }
     }
   };
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_bwd_kernel(const IpaBwdPara
 #pragma unroll
     for (int i = 0; i < IB_SLOTS; ++i) {
       const int id = tid + NTHR * i;
-      if (id < IB_KROWS * 8) st[i] = *(const ibu32x4*)(kb + (long)(id >> 3) * NP + (id & 7) * 8);
+      if (id < IB_KROWS * 8) st[i] = *(const ibu32x4*)(kb + (unsigned)((id >> 3) * NP + (id & 7) * 8));
     }
   };
   auto commit_k = [&](char* buf) __attribute__((always_inline)) {
@@ -326,39 +330,49 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_bwd_kernel(const IpaBwdPara
   // ---- dS = P (g - <g>_P) over the keys of each query (exact: the whole row is in registers) ----
   load_k(0);                                            // first K''^T chunk in flight under the row arithmetic
   {
-    const bf16_t* prow = p.Pb + (headrow + qrow) * (long)N;
-    const bf16_t* pprow = p.dPp ? p.dPp + (headrow + qrow) * (long)N : nullptr;
-    f32x4 pr[NT];
+    const bf16_t* const pbase = p.Pb + headrow * (long)N;
+    const bf16_t* const ppbase = p.dPp ? p.dPp + headrow * (long)N : nullptr;
+    const unsigned prow = (unsigned)(qrow * N);
+    // The probabilities stay PACKED (two registers per key tile instead of four) between the row sums and the product: with
+    // the unpacked copy next to the accumulators and the K''^T chunk in flight the <32, 4> instance spilled 204 bytes per lane
+    ibu32x2 praw[NT];
     float dot = 0.f, psum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int key0 = t * 16 + l4 * 4;
+      praw[t] = (ibu32x2){0u, 0u};
       if (key0 < N) {                                    // N % 4 == 0: the four keys of a lane are in or out together
-        const ibu32x2 pv = *(const ibu32x2*)(prow + key0);
-        pr[t] = (f32x4){bf_lo(pv.x), bf_hi(pv.x), bf_lo(pv.y), bf_hi(pv.y)};
-        if (pprow) {
-          const ibu32x2 gv = *(const ibu32x2*)(pprow + key0);
+        praw[t] = *(const ibu32x2*)(pbase + (prow + key0));
+        if (ppbase) {
+          const ibu32x2 gv = *(const ibu32x2*)(ppbase + (prow + key0));
           acc[t][0] += bf_lo(gv.x);
           acc[t][1] += bf_hi(gv.x);
           acc[t][2] += bf_lo(gv.y);
           acc[t][3] += bf_hi(gv.y);
         }
-      } else {
-        pr[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dot = __builtin_fmaf(pr[t][r], acc[t][r], dot);
-        psum += pr[t][r];
-      }
+      const float p0 = bf_lo(praw[t].x), p1 = bf_hi(praw[t].x), p2 = bf_lo(praw[t].y), p3 = bf_hi(praw[t].y);
+      dot = __builtin_fmaf(p0, acc[t][0], dot);
+      dot = __builtin_fmaf(p1, acc[t][1], dot);
+      dot = __builtin_fmaf(p2, acc[t][2], dot);
+      dot = __builtin_fmaf(p3, acc[t][3], dot);
+      psum += p0;
+      psum += p1;
+      psum += p2;
+      psum += p3;
     }
     dot = ib_xsum(dot);
     psum = ib_xsum(psum);
     const float mean = dot / psum;                       // a row always holds probability mass (psum ~ 1)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] = pr[t][r] * (acc[t][r] - mean);
+    for (int t = 0; t < NT; ++t) {
+      unsigned px = praw[t].x, py = praw[t].y;
+      asm volatile("" : "+v"(px), "+v"(py));             // (opaque: the unpacked values of the first pass must not be kept alive)
+      acc[t][0] = bf_lo(px) * (acc[t][0] - mean);
+      acc[t][1] = bf_hi(px) * (acc[t][1] - mean);
+      acc[t][2] = bf_lo(py) * (acc[t][2] - mean);
+      acc[t][3] = bf_hi(py) * (acc[t][3] - mean);
+    }
     // the LDS buffers are idle here (the phase-1 loop ended with a barrier, the first K''^T chunk is still in registers)
     if (q0 < N) {
       char* stage = smem + w * (16 * (NT * 32 + 16));

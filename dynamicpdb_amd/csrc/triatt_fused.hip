@@ -327,11 +327,14 @@ __global__ __launch_bounds__(512) void triatt_fused_kernel(const TriAttFusedPara
 // ------------------------------------------------------------------------------------------------------------------
 // pass 0: triangle bias only.  tri[b][h][q][k] = log2(e) * w_tri[h] . LN(x'[q][k]) in the blocked layout read above -- a
 // pure streaming pass (x in, 4 floats per cell out): 16 lanes per cell, four cells per pass, one wave per 64-key tile.
+// For the query-block row kernel (csrc/triatt_rows.hip, any N_res) the same pass also writes the LayerNorm output itself
+// as bf16 in the operator's coordinates (xn != nullptr: the ending node's transpose happens in this copy).  (bf16 bias
+// blocks were tried with that kernel: half the per-row re-read of [4, N, N], 1 % of its time -- not kept.)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tri_bias_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ wtri,
-                                                       float* __restrict__ tri, int B, int N, int NP, int ending, int x_bf16,
-                                                       float eps) {
+                                                       float* __restrict__ tri, bf16_t* __restrict__ xn, int B, int N,
+                                                       int NP, int ending, int x_bf16, float eps) {
   __shared__ __attribute__((aligned(16))) float stage[4][4][64];      // [wave][head][key]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -376,6 +379,9 @@ __global__ __launch_bounds__(256) void tri_bias_kernel(const void* __restrict__ 
       const float rstd = rsqrtf(tf_row16_sum(q2) * (1.f / 128.f) + eps);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e] * rstd, gam[e], bet[e]);     // fp32, as the two-kernel form's bias
+      if (xn != nullptr && pos < N)         // the row kernel's A operand: the same rounding as triatt_fused_kernel's LDS tile
+        *(uint4*)(xn + ((((long)b * N + line) * N + pos) * 128 + l15 * 8)) =
+            make_uint4(pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3]), pack2bf_hw(v[4], v[5]), pack2bf_hw(v[6], v[7]));
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         float th = 0.f;
@@ -404,8 +410,20 @@ extern "C" int dfold_triatt_bias_blocked(const void* x, int32_t x_is_bf16, const
   const long ntiles = (long)B * N * (NP >> 6);
   long grid = (ntiles + 3) / 4;
   if (grid > 2048) grid = 2048;
-  DFOLD_LAUNCH(tri_bias_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ln_gamma, ln_beta, w_tri, tri, B, N, NP,
-               ending ? 1 : 0, x_is_bf16 ? 1 : 0, eps);
+  DFOLD_LAUNCH(tri_bias_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ln_gamma, ln_beta, w_tri, tri,
+               (bf16_t*)nullptr, B, N, NP, ending ? 1 : 0, x_is_bf16 ? 1 : 0, eps);
+  return dfold_check_launch();
+}
+
+extern "C" int dfold_triatt_ln_bias(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const float* w_tri,
+                                    float* tri, void* xn_bf16, int32_t B, int32_t N, int32_t NP, int32_t ending,
+                                    float eps, void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w_tri || !tri || !xn_bf16 || B <= 0 || N <= 0 || NP < N || (NP & 63)) return DFOLD_EINVAL;
+  const long ntiles = (long)B * N * (NP >> 6);
+  long grid = (ntiles + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  DFOLD_LAUNCH(tri_bias_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ln_gamma, ln_beta, w_tri, tri,
+               (bf16_t*)xn_bf16, B, N, NP, ending ? 1 : 0, x_is_bf16 ? 1 : 0, eps);
   return dfold_check_launch();
 }
 

@@ -174,8 +174,10 @@ def _use_fused():
 
 
 def _use_row_kernel():
-    """triangle attention at N_res <= 256: the row kernel that keeps q|k|v|g on chip ("0": the two-kernel form)"""
-    return os.environ.get("DFOLD_TRIATT_ROW", "1") != "0"
+    """triangle attention with q|k|v|g kept on chip: "1" (default) the whole-row kernel at N_res <= 256
+    (csrc/triatt_fused.hip) and the query-block kernel above (csrc/triatt_rows.hip, any N_res), "2" the query-block kernel
+    at every N_res, "0" the two-kernel form of csrc/pair_fused.hip (q|k|v|g through HBM)"""
+    return os.environ.get("DFOLD_TRIATT_ROW", "1")
 
 
 _TRIATT_DBG = None      # tests: fp32 [4][N][32] device tensor receiving q|k|v|gate of head 0, row 0, item 0
@@ -546,12 +548,28 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
     if xc.dtype not in (torch.float32, BF16):
         xc = xc.float()
     maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
-    row_kernel = N <= 256 and _use_row_kernel()
-    # (the row kernel reads the bias in 16 x 16 accumulator-order blocks: NP x NP floats per head)
-    tri = _ws_get(ws, "tri_blk" if row_kernel else "tri", (B, 4, NP if row_kernel else N, NP), torch.float32, dev)
+    mode = _use_row_kernel()
+    row_kernel = N <= 256 and mode == "1"
+    rows_kernel = mode == "2" or (mode == "1" and N > 256)
     ending = 0 if starting else 1
     st = stream()
     out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
+    if rows_kernel:
+        # query-block form (csrc/triatt_rows.hip, any N_res): pass 0 writes LayerNorm(x') as bf16 in the operator's
+        # coordinates + the blocked triangle bias; one workgroup per (item, row, 256 queries) does q|k|v|g + gated
+        # attention (online softmax over 256-key chunks) + linear_o
+        tri = _ws_get(ws, "tri_blk", (B, 4, NP, NP), torch.float32, dev)
+        xn = _ws_get(ws, "xn", (B, N, N, 128), BF16, dev)
+        check(L.dfold_triatt_ln_bias(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(w_tri), _p(tri),
+                                     _p(xn), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending),
+                                     ctypes_float(1e-5), st), "dfold_triatt_ln_bias")
+        check(L.dfold_triatt_rows_fwd(_p(xn), _p(maskf), _p(wcat), _p(bcat), _p(tri), _p(wo), _p(b_o),
+                                      _p(out), c_int32(1 if out.dtype == BF16 else 0), _p(_TRIATT_DBG), c_int32(B), c_int32(N),
+                                      c_int32(NP), c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)), st),
+              "dfold_triatt_rows_fwd")
+        return out, xc, maskf
+    # (the row kernel reads the bias in 16 x 16 accumulator-order blocks: NP x NP floats per head)
+    tri = _ws_get(ws, "tri_blk" if row_kernel else "tri", (B, 4, NP if row_kernel else N, NP), torch.float32, dev)
     if row_kernel:
         # projections kept on chip (csrc/triatt_fused.hip): pass 0 writes only the triangle bias, then one workgroup per
         # (item, row) does LayerNorm + q|k|v|g + gated attention + linear_o

@@ -328,6 +328,21 @@ int dfold_triatt_fused_fwd(const void* x, int32_t x_is_bf16, const float* mask, 
                            const void* w_cat_bf16, const float* bias_cat, const float* tri, const void* w_o_bf16, const float* b_o,
                            void* out, int32_t out_is_bf16, float* dbg, int32_t B, int32_t N, int32_t NP, int32_t ending,
                            float inf, float scale, float eps, void* stream);
+/* The same operator for ANY N (round 4, csrc/triatt_rows.hip; triangular_attention.py:78-139, primitives.py:219-243,377-448):
+ * the query-block form of the row kernel.  Pass 0, dfold_triatt_ln_bias: one streaming pass over x that writes
+ *   xn bf16 [B][N][N][128] = LayerNorm(x') in the operator's coordinates (x' = x, or x^T for ending != 0) and
+ *   tri fp32 [B][4][NP/16][NP/16][64][4] = log2(e) * w_tri . LN(x'), the blocked layout above.
+ * dfold_triatt_rows_fwd: one workgroup per (item, row, block of 256 queries); per head and per chunk of 256 keys the
+ * q | k | v | g projections of 64-cell xn tiles on the matrix cores into LDS tiles, gated attention with an online softmax
+ * over the key chunks (one chunk: the exact softmax), linear_o accumulated over the heads; q, k, v, g never reach HBM.
+ * mask [B][N][N] and out [B][N][N][128] fp32 | bf16 in the coordinates of x.  dbg (tests, may be NULL): fp32 [4][N][32] =
+ * q | k | v | sigmoid(g) of head 0 of row 0 of item 0 (q / g rows: the first query block only). */
+int dfold_triatt_ln_bias(const void* x, int32_t x_is_bf16, const float* ln_gamma, const float* ln_beta, const float* w_tri,
+                         float* tri, void* xn_bf16, int32_t B, int32_t N, int32_t NP, int32_t ending, float eps,
+                         void* stream);
+int dfold_triatt_rows_fwd(const void* xn_bf16, const float* mask, const void* w_cat_bf16, const float* bias_cat, const float* tri,
+                          const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, float* dbg,
+                          int32_t B, int32_t N, int32_t NP, int32_t ending, float inf, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * First layer of the feature embedders (force/vel/index/rigid/angle_embeder[0:2], src/model/ipa_pytorch_dynamic.py:

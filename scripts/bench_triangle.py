@@ -150,6 +150,28 @@ def _stages_att(m, x, mask, reps):
                  bytes=cells * (2 * 128 * es + 4) + B * N * 4 * NP * NP * 4,        # x, out, mask + the bias re-read per row (L2)
                  flop=2.0 * cells * 128 * 512 + 4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
         ]
+    # the query-block form (csrc/triatt_rows.hip, any N_res): LN + bias pass that also writes xn, then one workgroup per
+    # (item, row, 256 queries)
+    xn = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+    QB = (N + 255) // 256
+    tblk = torch.empty((B, 4, NP, NP), dtype=torch.float32, device=dev)
+
+    def p0():
+        check(L.dfold_triatt_ln_bias(_p(x), c_int32(xb), _p(g), _p(b), _p(wt), _p(tblk), _p(xn), c_int32(B), c_int32(N), c_int32(NP),
+                                     c_int32(ending), ctypes_float(1e-5), stream()), "ln_bias")
+
+    def p1():
+        check(L.dfold_triatt_rows_fwd(_p(xn), _p(mask), _p(wcat), _p(bcat), _p(tblk), _p(wo), _p(bo), _p(out), c_int32(xb), c_void_p(0),
+                                      c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e9),
+                                      ctypes_float(1.0 / math.sqrt(32.0)), stream()), "rows")
+    p0()
+    rows += [
+        dict(stage="query-block form: LN -> xn bf16 + bias blocks", s=_time(p0, reps), bytes=cells * (128 * es + 128 * 2 + 16),
+             flop=2.0 * cells * 128 * 4),
+        dict(stage="query-block form: q|k|v|g+attention+gate+linear_o per (row, 256 queries)", s=_time(p1, reps),
+             bytes=cells * (128 * 2 + 128 * es + 4) + B * N * 4 * NP * NP * 4,         # xn, out, mask + the bias re-read per row (L2)
+             flop=2.0 * cells * 128 * (256 + 256 * QB) + 4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
+    ]
     return rows
 
 

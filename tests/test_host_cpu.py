@@ -51,6 +51,14 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     for (m, k, sk, fl) in ((200, 64, 1, 0), (256, 96, 1, 0), (256, 128, 2, 0)):
         assert L.dfold_gemm_tn_bf16(one, one, one, c_int32(m), c_int32(256), c_int64(k), c_int64(256), c_int64(256), c_int64(256),
                                     c_int32(1), c_int32(1), z, z, z, z, z, z, c_int32(sk), c_int32(fl), c_float(1.0), c_void_p(0)) == -1
+    # query-block triangle attention: key pitch below N_res / not a multiple of 64, missing xn
+    for (n, npad) in ((300, 256), (300, 328)):
+        assert L.dfold_triatt_rows_fwd(one, one, one, one, one, one, one, one, c_int32(0), None, c_int32(1), c_int32(n),
+                                       c_int32(npad), c_int32(0), c_float(1e9), c_float(0.17), c_void_p(0)) == -1
+        assert L.dfold_triatt_ln_bias(one, c_int32(0), one, one, one, one, one, c_int32(1), c_int32(n), c_int32(npad),
+                                      c_int32(0), c_float(1e-5), c_void_p(0)) == -1
+    assert L.dfold_triatt_ln_bias(one, c_int32(0), one, one, one, one, None, c_int32(1), c_int32(64), c_int32(64),
+                                  c_int32(0), c_float(1e-5), c_void_p(0)) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):

@@ -404,3 +404,64 @@ def test_triatt_row_kernel_stages_and_output(N, ending, monkeypatch):
     P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = torch.stack([_oracle("tri_att_end" if ending else "tri_att_start", P, x[b].cpu(), mask[b].cpu()) for b in range(B)])
     assert rel_l2(y, ref) < 1.5e-2 and rel_l2(yb.float(), ref) < 2.5e-2, (rel_l2(y, ref), rel_l2(yb.float(), ref))
+
+
+@pytest.mark.parametrize("N,ending", [(512, 0), (512, 1), (256, 1), (200, 0), (27, 1), (520, 0), (264, 1)])
+def test_triatt_query_block_kernel_stages_and_output(N, ending, monkeypatch):
+    """csrc/triatt_rows.hip (projections kept on chip, ANY N_res: one workgroup per (item, row, 256 queries), online softmax
+    over 256-key chunks; pass 0 writes LayerNorm(x') as bf16 + the blocked triangle bias): (a) the q | k | v |
+    sigmoid(g) tiles of head 0 of row 0 against fp32 torch math on the same LayerNorm output (debug tap; q / g rows of the
+    first query block), (b) the whole operator against the two-kernel form and against the CPU oracle (one item above
+    N_res 256 to bound the oracle's time), per cell as well -- one / two / three key chunks, ragged last chunk and tile, both
+    nodes; (c) at N_res <= 256 against the whole-row kernel, which rounds the same intermediates in the same places."""
+    from dynamicpdb_amd.model import triangle as T
+    dev = torch.device(DEV)
+    B = 2
+    ctor = T.TriangleAttentionEndingNode if ending else T.TriangleAttentionStartingNode
+    m = _rand_module(ctor(128, 32, 4), 93).to(dev)
+    x, mask = _inputs(B, N, 94 + N, holes=0.08)
+    x, mask = x.to(dev), mask.to(dev)
+    dbg = torch.zeros(4, N, 32, device=dev)
+    monkeypatch.setattr(T, "_TRIATT_DBG", dbg)
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "2")
+    with torch.no_grad():
+        y = m(x, mask=mask)
+        yb = m(x.to(BF16), mask=mask)
+    monkeypatch.setattr(T, "_TRIATT_DBG", None)
+    with torch.no_grad():
+        y1 = m(x[1], mask=mask[1])
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "0")
+    with torch.no_grad():
+        y2 = m(x, mask=mask)
+    assert torch.isfinite(y).all() and torch.equal(y[1], y1)
+    # (a) row 0 of item 0 in the operator's coordinates
+    xr = x[0, :, 0] if ending else x[0, 0]                    # [N, 128]
+    xn = _ln(xr, m.layer_norm.weight, m.layer_norm.bias).to(BF16).float()
+    mh = m.mha
+    for pj, (lin, act) in enumerate(((mh.linear_q, None), (mh.linear_k, None), (mh.linear_v, None), (mh.linear_g, torch.sigmoid))):
+        ref = xn @ lin.weight[:32].to(BF16).float().t()
+        if lin.bias is not None:
+            ref = ref + lin.bias[:32]
+        if act is not None:
+            ref = act(ref)
+        rows = slice(0, min(N, 256)) if pj in (0, 3) else slice(0, N)
+        assert rel_l2(dbg[pj][rows], ref[rows]) < 5e-3, (pj, rel_l2(dbg[pj][rows], ref[rows]))
+    # (b)
+    e2 = rel_l2(y, y2)
+    assert e2 < 6e-3, e2              # both round the same intermediates to bf16, in other places
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    nref = B if N <= 256 else 1
+    ref = torch.stack([_oracle("tri_att_end" if ending else "tri_att_start", P, x[b].cpu(), mask[b].cpu()) for b in range(nref)])
+    e32, e16 = rel_l2(y[:nref], ref), rel_l2(yb[:nref].float(), ref)
+    print(f"[query-block kernel N={N} ending={ending}] rel-L2 vs two-kernel form {e2:.2e}, vs oracle: fp32 I/O {e32:.2e}, "
+          f"bf16 I/O {e16:.2e}")
+    assert e32 < 1.5e-2 and e16 < 2.5e-2, (e32, e16)
+    d = (y[:nref].cpu() - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-3)
+    assert float(d.max()) < 0.15, float(d.max())
+    # (c)
+    if N <= 256:
+        monkeypatch.setenv("DFOLD_TRIATT_ROW", "1")
+        with torch.no_grad():
+            y3 = m(x, mask=mask)
+        e3 = rel_l2(y, y3)
+        assert e3 < 1e-4, e3
