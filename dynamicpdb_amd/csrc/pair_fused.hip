@@ -174,8 +174,12 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       }
       if (MODE == 0) {
         const int pos = pt * PP_TILE + w * 8 + qd * 4 + l4;
-        mk[qd] = 0.f;
-        if (l15 == 0 && pos < N) mk[qd] = p.mask[cell0 + (long)(w * 8 + qd * 4 + l4) * (p.swap ? N : 1)];
+        // unconditional (the 16 lanes of a cell read one address; positions past the row end read its last cell): a load under
+        // a lane condition merges with the 0.f through a copy that hipcc places right behind the load, with s_waitcnt
+        // vmcnt(0) in front of it -- every prefetched row of the tile was waited for before the MFMA phase it should hide
+        // under.  The consumer selects (S0 of the next tile).
+        const int posc = pos < N ? w * 8 + qd * 4 + l4 : N - 1 - pt * PP_TILE;
+        mk[qd] = p.mask[cell0 + (long)posc * (p.swap ? N : 1)];
       }
     }
   };
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         }
       }
       if (MODE == 0) {
-        if (l15 == 0) ldsM[row] = mk[qd];
+        if (l15 == 0) ldsM[row] = (pt * PP_TILE + row < N) ? mk[qd] : 0.f;
         if (p.f0 != nullptr) {
           const int pos = pt * PP_TILE + row;
           if (l15 == 0 && pos < N) {
@@ -290,7 +294,10 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     __syncthreads();
 
     // ---- S1: prefetch the next tile's rows, stream the previous tile out (both in flight during the MFMA phase) ----
-    if (t + gridDim.x < ntiles) issue(t + gridDim.x, zr, mk);     // this tile's rows have been consumed above
+    // (this tile's rows have been consumed above.  Unconditional: after the last tile it re-reads that tile -- under
+    //  `if (t + gridDim.x < ntiles)` the loaded registers reach the loop-carried ones through copies, and the wait for those
+    //  copies sat HERE, in front of the MFMA phase: the prefetch never overlapped anything)
+    issue(t + gridDim.x < ntiles ? t + gridDim.x : t, zr, mk);
     if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
     __syncthreads();
 
@@ -447,21 +454,23 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
   const unsigned ntiles = (unsigned)p.B * (unsigned)N * (unsigned)tpl;
   const int pr = tid >> 3, xv8 = tid & 7;   // x planes: channel pair (2pr, 2pr+1), cells 8*xv8 .. +8
 
-  uint4 xv[2], gv[2];
+  // first-class vector values, not arrays of HIP's uint4 struct: the struct arrays were kept in scratch memory once the
+  // prefetch became unconditional (scratch_store right behind the loads = a wait for them)
+  typedef __attribute__((ext_vector_type(4))) unsigned tou32x4;
+  tou32x4 xv0, xv1, gv0, gv1;
   auto issue = [&](unsigned t) __attribute__((always_inline)) {
     const int jt = (int)(t % (unsigned)tpl);
     const unsigned bl = t / (unsigned)tpl;
     const int i = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-      xv[c2] = *(const uint4*)(p.xpl + (((long)b * N + i) * 128 + 2 * pr + c2) * NP + jt * PP_TILE + xv8 * 8);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
-      const int pos = jt * PP_TILE + cr;
-      gv[k] = make_uint4(0, 0, 0, 0);
-      if (pos < N) gv[k] = *(const uint4*)(p.gate + (((long)b * N + i) * N + pos) * 128 + v * 8);
-    }
+    const bf16_t* xb = p.xpl + (((long)b * N + i) * 128 + 2 * pr) * NP + jt * PP_TILE + xv8 * 8;
+    xv0 = *(const tou32x4*)xb;
+    xv1 = *(const tou32x4*)(xb + NP);
+    // unconditional, positions past the row end re-read its last cell (their output rows are not stored): see pair_proj_kernel
+    const int cr0 = tid >> 4, v = tid & 15;
+    const int pos0 = jt * PP_TILE + cr0, pos1 = pos0 + 32;
+    const bf16_t* gb = p.gate + (((long)b * N + i) * N) * 128 + v * 8;
+    gv0 = *(const tou32x4*)(gb + (long)(pos0 < N ? pos0 : N - 1) * 128);
+    gv1 = *(const tou32x4*)(gb + (long)(pos1 < N ? pos1 : N - 1) * 128);
   };
 
   auto stream_out = [&](int b, int i, int jt) __attribute__((always_inline)) {   // whole 512-byte rows
@@ -502,15 +511,15 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
 
     // ---- S0a: x tile transposed into [cell][channel] (two channels per dword), gate tile ----
     {
-      const bf16_t* e0 = (const bf16_t*)&xv[0];
-      const bf16_t* e1 = (const bf16_t*)&xv[1];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        *(uint32_t*)(ldsX + (xv8 * 8 + q) * TO_XPITCH + pr * 4) = (uint32_t)e0[q] | ((uint32_t)e1[q] << 16);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int id = tid + 512 * k, cr = id >> 4, v = id & 15;
-        *(uint4*)(ldsG + cr * PP_GPITCH + v * 16) = gv[k];
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t a = xv0[q >> 1], bq = xv1[q >> 1];
+        *(uint32_t*)(ldsX + (xv8 * 8 + q) * TO_XPITCH + pr * 4) = (q & 1) ? ((a >> 16) | (bq & 0xffff0000u)) : ((a & 0xffffu) | (bq << 16));
+      }
+      {
+        const int cr = tid >> 4, v = tid & 15;       // ids tid and tid + 512: rows cr and cr + 32
+        *(tou32x4*)(ldsG + cr * PP_GPITCH + v * 16) = gv0;
+        *(tou32x4*)(ldsG + (cr + 32) * PP_GPITCH + v * 16) = gv1;
       }
     }
     __syncthreads();
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(512) void trimul_out_kernel(const TriMulOutParams p
       *(uint4*)(ldsA + a_tile_off(row, l15)) =
           make_uint4(pack2bf_hw(x[0], x[1]), pack2bf_hw(x[2], x[3]), pack2bf_hw(x[4], x[5]), pack2bf_hw(x[6], x[7]));
     }
-    if (t + gridDim.x < ntiles) issue(t + gridDim.x);
+    issue(t + gridDim.x < ntiles ? t + gridDim.x : t);         // unconditional: see pair_proj_kernel
     if (have_prev) stream_out(pb, pi, pjt);
     __syncthreads();
 
