@@ -300,6 +300,13 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_fwd_kernel(const IpaFusedPa
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   load_k(0);
+  // per-key terms of the logits, shared by every query of the (window, frame, head): |k_pts - ctr|^2 bias and mask - 1
+  float* const ldsKN = (float*)(smem + 2 * IF_BUF);
+  float* const ldsM1 = ldsKN + NT * 16;
+  for (int t = tid; t < NT * 16; t += NTHR) {
+    ldsKN[t] = t < N ? p.kn[headrow + t] : 0.f;
+    ldsM1[t] = t < N ? p.mask[bf * N + t] - 1.f : 0.f;
+  }
   commit_k(smem);
   __syncthreads();
 #pragma unroll
@@ -327,25 +334,29 @@ __global__ __launch_bounds__(NW * 64) void ipa_fused_fwd_kernel(const IpaFusedPa
   {
     const float mi_inf = p.mask[bf * N + qrow] * p.inf;
     const float* brow = p.bias + ((b * H + h) * (long)N + qrow) * N;
-    const float* knr = p.kn + headrow;
-    const float* mkr = p.mask + bf * N;
+    // All pair-bias loads of the row go out before the first one is consumed, unconditionally (keys past the end re-read the
+    // last four): under `if (key0 < N)` every key tile became its own branch with load - wait - arithmetic inside, NT memory
+    // round trips in a row with nothing to overlap them.  The per-key terms (|k_pts|^2 bias, mask) are the same for every
+    // query: staged in LDS once per workgroup (below the chunk buffers' end) instead of two more loads per tile and lane.
+    f32x4 bvs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int key0 = t * 16 + l4 * 4;
+      bvs[t] = *(const f32x4*)(brow + (key0 < N ? key0 : N - 4));       // N % 4 == 0
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int key0 = t * 16 + l4 * 4;
-      if (key0 < N) {                                    // N % 4 == 0: the four keys of a lane are in or out together
-        const f32x4 bv = *(const f32x4*)(brow + key0);
-        const f32x4 kv = *(const f32x4*)(knr + key0);
-        const f32x4 mv = *(const f32x4*)(mkr + key0);
+      const f32x4 kv = *(const f32x4*)(ldsKN + key0);
+      const f32x4 mv = *(const f32x4*)(ldsM1 + key0);
+      const bool kin = key0 < N;                         // the four keys of a lane are in or out together
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float L = __builtin_fmaf(p.alpha, acc[t][r], __builtin_fmaf(p.bias_scale, bv[r], kv[r])) + mi_inf * (mv[r] - 1.f);
-          acc[t][r] = L;
-          mx = fmaxf(mx, L);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = -INFINITY;
+      for (int r = 0; r < 4; ++r) {
+        const float L = __builtin_fmaf(p.alpha, acc[t][r], __builtin_fmaf(p.bias_scale, bvs[t][r], kv[r])) + mi_inf * mv[r];
+        acc[t][r] = kin ? L : -INFINITY;
+        mx = fmaxf(mx, acc[t][r]);
       }
     }
     mx = if_xmax(mx);
@@ -463,11 +474,11 @@ extern "C" int dfold_ipa_fused_fwd(const void* q_bf16, const void* kv_bf16, cons
   p.bias_scale = bias_scale; p.inf = inf;
   hipStream_t st = (hipStream_t)stream;
   if (N <= 256) {
-    DFOLD_MAX_LDS_ONCE((ipa_fused_fwd_kernel<16, 8>), 2 * IF_BUF);
-    DFOLD_LAUNCH((ipa_fused_fwd_kernel<16, 8>), dim3((unsigned)nwg), dim3(512), 2 * IF_BUF, st, p);
+    DFOLD_MAX_LDS_ONCE((ipa_fused_fwd_kernel<16, 8>), 2 * IF_BUF + 2 * 256 * 4);
+    DFOLD_LAUNCH((ipa_fused_fwd_kernel<16, 8>), dim3((unsigned)nwg), dim3(512), 2 * IF_BUF + 2 * 256 * 4, st, p);
   } else {
-    DFOLD_MAX_LDS_ONCE((ipa_fused_fwd_kernel<32, 4>), 2 * IF_BUF);
-    DFOLD_LAUNCH((ipa_fused_fwd_kernel<32, 4>), dim3((unsigned)nwg), dim3(256), 2 * IF_BUF, st, p);
+    DFOLD_MAX_LDS_ONCE((ipa_fused_fwd_kernel<32, 4>), 2 * IF_BUF + 2 * 512 * 4);
+    DFOLD_LAUNCH((ipa_fused_fwd_kernel<32, 4>), dim3((unsigned)nwg), dim3(256), 2 * IF_BUF + 2 * 512 * 4, st, p);
   }
   return dfold_check_launch();
 }
