@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
     for (int rb = 0; rb < rows; rb += 8) {
       float gv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) gv[u] = rb + u < rows ? bf2f(g[(r0 + rb + u) * D + o]) : 0.f;
+      for (int u = 0; u < 8; ++u) gv[u] = bf2f(g[(r0 + min(rb + u, rows - 1)) * D + o]);     // unconditional (rows past the end re-read
+                                                                                              // the last one, unused): under a condition
+                                                                                              // each load was its own branch + wait
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int r = rb + u;
@@ -146,7 +148,9 @@ __global__ __launch_bounds__(256) void embed_in_bwd_dx_kernel(const float* __res
     for (int rb = 0; rb < EMB_DXR; rb += 8) {
       float gv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) gv[u] = rb + u < rows ? bf2f(g[(r0 + rb + u) * D + o]) : 0.f;
+      for (int u = 0; u < 8; ++u) gv[u] = bf2f(g[(r0 + min(rb + u, rows - 1)) * D + o]);     // unconditional, see embed_in_bwd_kernel
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gv[u] = rb + u < rows ? gv[u] : 0.f;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int r = rb + u;

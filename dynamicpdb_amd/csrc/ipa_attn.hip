@@ -482,88 +482,105 @@ __global__ __launch_bounds__(NTHR) void ipa_col_bwd_kernel(const bf16_t* __restr
     for (int c = 0; c < VP; ++c) av[e][c] = 0.f;
   }
   const long base = ((long)bf * H + h) * N * N + (ok ? j0 : 0);
-  // tile staging: CB_TR rows x 15 float4 (6 of q, 9 of do_pt); thread t fetches chunks t, t + nthr, ... of the tile
+  // tile staging: CB_TR rows x 15 float4 (6 of q, 9 of do_pt); thread t fetches chunks t, t + nthr, ... of the tile.
+  // First-class vector values and UNCONDITIONAL loads (slots past the tile's last chunk re-fetch it and rewrite the same
+  // bytes): as `float4 stg[]` under `if (id < NCH)` the staged vectors lived in scratch memory -- every global load was
+  // waited for on the spot (scratch_store right behind it), four memory round trips per tile in a row, and came back
+  // through scratch_load before the LDS write (visible in hipcc -S; scripts/isa_audit.py flags both).
   constexpr int NCH = CB_TR * 15;
   constexpr int MAXS = (NCH + NTHR - 1) / NTHR;
-  float4 stg[MAXS];
+  f32x4 stg[MAXS];
   auto fetch = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
     for (int s_ = 0; s_ < MAXS; ++s_) {
-      const int id = tid + s_ * nthr;
-      if (id < NCH) {
-        const int r = id / 15, c = id - r * 15;
-        int i = t0 + r;
-        i = i < N ? i : N - 1;
-        stg[s_] = c < 6 ? *(const float4*)(qbase + (long)i * H * KP + 4 * c) : *(const float4*)(dbase + (long)i * H * VP + 4 * (c - 6));
-      }
+      int id = tid + s_ * nthr;
+      id = id < NCH ? id : NCH - 1;
+      const int r = id / 15, c = id - r * 15;
+      int i = t0 + r;
+      i = i < N ? i : N - 1;
+      const float* src = c < 6 ? qbase + (long)i * H * KP + 4 * c : dbase + (long)i * H * VP + 4 * (c - 6);
+      stg[s_] = *(const f32x4*)src;
     }
   };
   auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int s_ = 0; s_ < MAXS; ++s_) {
-      const int id = tid + s_ * nthr;
-      if (id < NCH) {
-        const int r = id / 15, c = id - r * 15;
-        *(float4*)&tile[buf][r][4 * c] = stg[s_];
+      int id = tid + s_ * nthr;
+      id = id < NCH ? id : NCH - 1;
+      const int r = id / 15, c = id - r * 15;
+      *(f32x4*)&tile[buf][r][4 * c] = stg[s_];
+    }
+  };
+  // this lane's dS / P values of 8 consecutive rows: independent loads; the NEXT group of 8 is requested before the current
+  // one is consumed (two register sets, static indices through the unrolled group loop) -- with one set every group of 8
+  // rows waited out a memory round trip in front of its 480 packed FMAs
+  auto load8 = [&](int row0, float (&ds)[8][KPL], float (&pp)[8][KPL]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = row0 + u;
+      i = i < N ? i : N - 1;
+      if (KPL == 2) {
+        const float2 dd = *(const float2*)(dS + base + (long)i * N);
+        const uint32_t pr = *(const uint32_t*)(P + base + (long)i * N);
+        ds[u][0] = dd.x; ds[u][KPL - 1] = dd.y;
+        pp[u][0] = bf_lo(pr); pp[u][KPL - 1] = bf_hi(pr);
+      } else {
+        ds[u][0] = dS[base + (long)i * N];
+        pp[u][0] = bf2f(P[base + (long)i * N]);
+      }
+    }
+  };
+  auto fma8 = [&](int row0, const float* rows, const float (&ds)[8][KPL], const float (&pp)[8][KPL]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (row0 + u < N) {                             // wave-uniform
+        const float* row = rows + u * CB_RP;
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) cs[e] += ds[u][e];
+#pragma unroll
+        for (int c4 = 0; c4 < KP / 4; ++c4) {
+          const float4 qv = *(const float4*)(row + 4 * c4);          // broadcast
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) {
+            aq[e][4 * c4] = __builtin_fmaf(ds[u][e], qv.x, aq[e][4 * c4]);
+            aq[e][4 * c4 + 1] = __builtin_fmaf(ds[u][e], qv.y, aq[e][4 * c4 + 1]);
+            aq[e][4 * c4 + 2] = __builtin_fmaf(ds[u][e], qv.z, aq[e][4 * c4 + 2]);
+            aq[e][4 * c4 + 3] = __builtin_fmaf(ds[u][e], qv.w, aq[e][4 * c4 + 3]);
+          }
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < VP / 4; ++c4) {
+          const float4 dv = *(const float4*)(row + KP + 4 * c4);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) {
+            av[e][4 * c4] = __builtin_fmaf(pp[u][e], dv.x, av[e][4 * c4]);
+            av[e][4 * c4 + 1] = __builtin_fmaf(pp[u][e], dv.y, av[e][4 * c4 + 1]);
+            av[e][4 * c4 + 2] = __builtin_fmaf(pp[u][e], dv.z, av[e][4 * c4 + 2]);
+            av[e][4 * c4 + 3] = __builtin_fmaf(pp[u][e], dv.w, av[e][4 * c4 + 3]);
+          }
+        }
       }
     }
   };
   fetch(0);
+  float dsA[8][KPL], pA[8][KPL], dsB[8][KPL], pB[8][KPL];
+  load8(0, dsA, pA);
   commit(0);
   __syncthreads();
   const int ntile = (N + CB_TR - 1) / CB_TR;
+  static_assert(CB_TR == 32, "the group loop below is written for four groups of 8 rows per tile");
   for (int t = 0; t < ntile; ++t) {
     const int t0 = t * CB_TR, buf = t & 1;
-    if (t + 1 < ntile) fetch(t0 + CB_TR);
-    // this lane's dS / P values of the tile's rows: independent loads, issued 8 rows at a time
-#pragma unroll 1
-    for (int r0 = 0; r0 < CB_TR; r0 += 8) {
-      float dsv[8][KPL], pv[8][KPL];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int i = t0 + r0 + u;
-        i = i < N ? i : N - 1;
-        if (KPL == 2) {
-          const float2 dd = *(const float2*)(dS + base + (long)i * N);
-          const uint32_t pp = *(const uint32_t*)(P + base + (long)i * N);
-          dsv[u][0] = dd.x; dsv[u][KPL - 1] = dd.y;
-          pv[u][0] = bf_lo(pp); pv[u][KPL - 1] = bf_hi(pp);
-        } else {
-          dsv[u][0] = dS[base + (long)i * N];
-          pv[u][0] = bf2f(P[base + (long)i * N]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (t0 + r0 + u < N) {                        // wave-uniform
-          const float* row = &tile[buf][r0 + u][0];
-#pragma unroll
-          for (int e = 0; e < KPL; ++e) cs[e] += dsv[u][e];
-#pragma unroll
-          for (int c4 = 0; c4 < KP / 4; ++c4) {
-            const float4 qv = *(const float4*)(row + 4 * c4);          // broadcast
-#pragma unroll
-            for (int e = 0; e < KPL; ++e) {
-              aq[e][4 * c4] = __builtin_fmaf(dsv[u][e], qv.x, aq[e][4 * c4]);
-              aq[e][4 * c4 + 1] = __builtin_fmaf(dsv[u][e], qv.y, aq[e][4 * c4 + 1]);
-              aq[e][4 * c4 + 2] = __builtin_fmaf(dsv[u][e], qv.z, aq[e][4 * c4 + 2]);
-              aq[e][4 * c4 + 3] = __builtin_fmaf(dsv[u][e], qv.w, aq[e][4 * c4 + 3]);
-            }
-          }
-#pragma unroll
-          for (int c4 = 0; c4 < VP / 4; ++c4) {
-            const float4 dv = *(const float4*)(row + KP + 4 * c4);
-#pragma unroll
-            for (int e = 0; e < KPL; ++e) {
-              av[e][4 * c4] = __builtin_fmaf(pv[u][e], dv.x, av[e][4 * c4]);
-              av[e][4 * c4 + 1] = __builtin_fmaf(pv[u][e], dv.y, av[e][4 * c4 + 1]);
-              av[e][4 * c4 + 2] = __builtin_fmaf(pv[u][e], dv.z, av[e][4 * c4 + 2]);
-              av[e][4 * c4 + 3] = __builtin_fmaf(pv[u][e], dv.w, av[e][4 * c4 + 3]);
-            }
-          }
-        }
-      }
-    }
+    fetch(t + 1 < ntile ? t0 + CB_TR : t0);          // (unconditional: after the last tile it re-fetches that tile)
+    const float* rows = &tile[buf][0][0];
+    load8(t0 + 8, dsB, pB);
+    fma8(t0, rows, dsA, pA);
+    load8(t0 + 16, dsA, pA);
+    fma8(t0 + 8, rows + 8 * CB_RP, dsB, pB);
+    load8(t0 + 24, dsB, pB);
+    fma8(t0 + 16, rows + 16 * CB_RP, dsA, pA);
+    load8(t0 + 32, dsA, pA);                         // first group of the next tile (rows past the end: clamped, unused)
+    fma8(t0 + 24, rows + 24 * CB_RP, dsB, pB);
     if (t + 1 < ntile) commit(buf ^ 1);
     __syncthreads();
   }
