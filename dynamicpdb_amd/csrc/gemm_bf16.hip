@@ -18,6 +18,7 @@
 // fragment reads bank-conflict free; the blockIdx -> tile map is XCD-aware (tiles that share an A row
 // panel sit on one XCD's L2).
 #include "dfold_common.h"
+typedef __attribute__((ext_vector_type(4))) unsigned gu32x4;
 #include "../../include/dfold_hip.h"
 #include <stdlib.h>
 
@@ -127,9 +128,17 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
   const int frow = lane & 31, fhalf = lane >> 5;
   const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
   const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
+  // (every global load of this epilogue is issued in a batch in front of its uses: written as `cond ? load : 0` / inside the
+  //  store loop each one became its own branch with an s_waitcnt vmcnt(0) behind it -- 5 + 2 x 10 memory round trips per tile
+  //  and wave on the launches with a residual or a ReLU mask, scripts/isa_audit.py)
   float bias_v[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) bias_v[j] = (fl & DFOLD_GEMM_BIAS) ? p.bias[nbase + j * 32 + frow] : 0.f;
+  for (int j = 0; j < NJ; ++j) bias_v[j] = 0.f;
+  if (fl & DFOLD_GEMM_BIAS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bias_v[j] = p.bias[nbase + j * 32 + frow];
+  }
+  const bool need_r = (fl & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) != 0;
   long* rowtab = (long*)(wave_lds + 32 * ROWB);  // 32 row offsets (-1 = row past M)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -149,33 +158,51 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done (wave-private region)
     __builtin_amdgcn_wave_barrier();
+    // chunk c = lane + 64 k of the 32 rows x CPR chunks of 8 bf16: element offsets first, then the residual / mask vectors
+    // of all chunks in flight together (rows past M read offset 0 of the operand and are not stored)
+    long offs[CPR / 2];
+    gu32x4 rr[CPR / 2], r2[CPR / 2];
 #pragma unroll
     for (int k = 0; k < CPR / 2; ++k) {
-      const int c = lane + 64 * k;          // chunk id: 32 rows x CPR chunks of 8 bf16
+      const int c = lane + 64 * k;
       const int r = c / CPR, c16 = c - r * CPR;
       const long ro = rowtab[r];
-      uint4 val = *(const uint4*)(wave_lds + r * ROWB + c16 * 16);
-      if (ro < 0) continue;
-      const long off = ro + c16 * 8;
-      if (c2_pre) *(uint4*)((bf16_t*)p.C2 + off) = val;
-      if (fl & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) {
-        const uint4 rr = *(const uint4*)(p.R + off);
-        const bf16_t* pr = (const bf16_t*)&rr;
-        bf16_t* pv = (bf16_t*)&val;
+      offs[k] = ro < 0 ? -1 : ro + c16 * 8;
+    }
+    if (need_r) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (fl & DFOLD_GEMM_RESID) pv[q] = f2bf(bf2f(pv[q]) + bf2f(pr[q]));
-          if (fl & DFOLD_GEMM_RELUMASK) pv[q] = bf2f(pr[q]) > 0.f ? pv[q] : (bf16_t)0;
+      for (int k = 0; k < CPR / 2; ++k) rr[k] = *(const gu32x4*)(p.R + (offs[k] < 0 ? 0 : offs[k]));
+    }
+    if (c2_mask) {
+#pragma unroll
+      for (int k = 0; k < CPR / 2; ++k) r2[k] = *(const gu32x4*)(p.R2 + (offs[k] < 0 ? 0 : offs[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < CPR / 2; ++k) {
+      const int c = lane + 64 * k;
+      const int r = c / CPR, c16 = c - r * CPR;
+      gu32x4 val = *(const gu32x4*)(wave_lds + r * ROWB + c16 * 16);
+      const long off = offs[k];
+      const bool live = off >= 0;
+      if (c2_pre && live) *(gu32x4*)((bf16_t*)p.C2 + off) = val;
+      if (need_r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t v2 = val[q];
+          const uint32_t rq = rr[k][q];
+          if (fl & DFOLD_GEMM_RESID) v2 = (uint32_t)f2bf(bf_lo(v2) + bf_lo(rq)) | ((uint32_t)f2bf(bf_hi(v2) + bf_hi(rq)) << 16);
+          if (fl & DFOLD_GEMM_RELUMASK) v2 = (bf_lo(rq) > 0.f ? (v2 & 0xffffu) : 0u) | (bf_hi(rq) > 0.f ? (v2 & 0xffff0000u) : 0u);
+          val[q] = v2;
         }
       }
-      *(uint4*)((bf16_t*)p.C + off) = val;
+      if (live) *(gu32x4*)((bf16_t*)p.C + off) = val;
       if (c2_mask) {
-        const uint4 r2 = *(const uint4*)(p.R2 + off);
-        const bf16_t* p2 = (const bf16_t*)&r2;
-        bf16_t* pv = (bf16_t*)&val;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pv[q] = bf2f(p2[q]) > 0.f ? pv[q] : (bf16_t)0;
-        *(uint4*)((bf16_t*)p.C2 + off) = val;
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t rq = r2[k][q];
+          val[q] = (bf_lo(rq) > 0.f ? (val[q] & 0xffffu) : 0u) | (bf_hi(rq) > 0.f ? (val[q] & 0xffff0000u) : 0u);
+        }
+        if (live) *(gu32x4*)((bf16_t*)p.C2 + off) = val;
       }
     }
     __builtin_amdgcn_wave_barrier();
