@@ -12,7 +12,9 @@
 // 256 x 256 x 64 tile, 8 waves as 4 (M) x 2 (N), 2 x 4 v_mfma_f32_32x32x16_bf16 tiles per wave (rows (wm + 4i) * 32,
 // columns (wn + 2j) * 32), two LDS stages of 64 KiB, the second wave of every SIMD half a K step behind the first.
 // Split-K (a long reduction with a small output: the K range is cut over blockIdx.z, partial tiles meet in fp32 atomics)
-// and a two-level batch.  M, N multiples of 256, K (per split) a multiple of 64.
+// and a two-level batch.  K (per split) a multiple of 64; M, N multiples of 8: a tile that hangs over the edge of the output
+// re-reads chunk 0 of its row for the columns past M (N) -- finite values whose products land in accumulator columns that are
+// never stored -- so the 128-, 192-, 480-, 640-wide weight gradients run here too instead of on transposed copies.
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
 
@@ -36,6 +38,7 @@ struct TnGemmParams {
   long sa0, sa1, sb0, sb1, sc0, sc1;  // batch strides (elements): z = (z0, z1), z1 = z % nb1
   long ksplit;                        // rows of the reduction per blockIdx.z
   int tiles_n, nb1, nsteps, flags;
+  int M, N;
   float alpha;
 };
 
@@ -92,8 +95,9 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
   {
     const int row = 2 * w + (lane >> 5);
     const int lc = (lane & 31) ^ ((row & 3) << 2);
-    aoff0 = (unsigned)(row * pitchA + lc * 16);
-    boff0 = (unsigned)(row * pitchB + lc * 16);
+    // columns past the edge of the output: chunk 0 of the tile instead (in range: m0 < M, n0 < N)
+    aoff0 = (unsigned)(row * pitchA + (m0 + lc * 8 < p.M ? lc : 0) * 16);
+    boff0 = (unsigned)(row * pitchB + (n0 + lc * 8 < p.N ? lc : 0) * 16);
   }
   const long dA = GBK * pitchA, dB = GBK * pitchB;
   int st_left = p.nsteps;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
         const uint4 v = *(const uint4*)(stg + r * 272 + ch * 16);
         const long m = (long)m0 + (wm + 4 * i) * 32 + r;
         const long n = (long)n0 + (wn + 2 * j) * 32 + qq * 8;
-        *(uint4*)((bf16_t*)p.C + cbase + m * p.ldc + n) = v;
+        if (m < p.M && n < p.N) *(uint4*)((bf16_t*)p.C + cbase + m * p.ldc + n) = v;
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -255,15 +259,19 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
     for (int e = 0; e < 16; ++e) {
       const long m = (long)m0 + (wm + 4 * i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
       float* row = cb + m * p.ldc;
+      const int ncol = n0 + wn * 32 + frow;              // column of tile j: ncol + 64 j
+      if (m >= p.M) continue;
       if (atomic) {
 #pragma unroll
-        for (int j = 0; j < GNJ; ++j) atomicAdd(row + j * 64, acc[i][j][e] * p.alpha);
+        for (int j = 0; j < GNJ; ++j)
+          if (ncol + j * 64 < p.N) atomicAdd(row + j * 64, acc[i][j][e] * p.alpha);
       } else {
         float cv[GNJ];
 #pragma unroll
-        for (int j = 0; j < GNJ; ++j) cv[j] = accum ? row[j * 64] : 0.f;
+        for (int j = 0; j < GNJ; ++j) cv[j] = (accum && ncol + j * 64 < p.N) ? row[j * 64] : 0.f;
 #pragma unroll
-        for (int j = 0; j < GNJ; ++j) row[j * 64] = acc[i][j][e] * p.alpha + cv[j];
+        for (int j = 0; j < GNJ; ++j)
+          if (ncol + j * 64 < p.N) row[j * 64] = acc[i][j][e] * p.alpha + cv[j];
       }
     }
   }
@@ -274,7 +282,7 @@ extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t
                                   int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags,
                                   float alpha, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || splitk <= 0) return DFOLD_EINVAL;
-  if ((M % GBT) || (N % GBT) || (K % ((long)splitk * GBK))) return DFOLD_EINVAL;
+  if ((M & 7) || (N & 7) || (K % ((long)splitk * GBK))) return DFOLD_EINVAL;
   if (lda < M || ldb < N || ldc < N || (lda & 7) || (ldb & 7) || ((sa0 | sa1 | sb0 | sb1) & 7)) return DFOLD_EINVAL;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return DFOLD_EINVAL;
   if (flags & ~(DFOLD_GEMM_OUT_BF16 | DFOLD_GEMM_ATOMIC | DFOLD_GEMM_ACCUM)) return DFOLD_EINVAL;
@@ -288,8 +296,9 @@ extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sa0 = sa0; p.sa1 = sa1; p.sb0 = sb0; p.sb1 = sb1; p.sc0 = sc0; p.sc1 = sc1;
   p.ksplit = K / splitk;
-  p.tiles_n = N / GBT; p.nb1 = nb1 > 0 ? nb1 : 1; p.nsteps = (int)(p.ksplit / GBK); p.flags = flags; p.alpha = alpha;
-  dim3 grid((unsigned)((M / GBT) * (N / GBT)), (unsigned)nbatch, (unsigned)splitk);
+  p.tiles_n = (N + GBT - 1) / GBT; p.nb1 = nb1 > 0 ? nb1 : 1; p.nsteps = (int)(p.ksplit / GBK); p.flags = flags; p.alpha = alpha;
+  p.M = M; p.N = N;
+  dim3 grid((unsigned)(((M + GBT - 1) / GBT) * p.tiles_n), (unsigned)nbatch, (unsigned)splitk);
   DFOLD_MAX_LDS_ONCE(dfold_tn_gemm_kernel, 2 * G_STAGE);
   DFOLD_LAUNCH(dfold_tn_gemm_kernel, grid, dim3(512), (size_t)(2 * G_STAGE), (hipStream_t)stream, p);
   return dfold_check_launch();

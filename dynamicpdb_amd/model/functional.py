@@ -83,7 +83,7 @@ def _linear_backward(x2d, weight, g2d, need_dx=True):
         wt = CACHE.wt(weight)                       # [K][N8]
         dx = torch.empty((M, K), dtype=BF16, device=x2d.device)
         gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
-    if ops.gemm_tn_ok(N8, K, M) and g8.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
+    if ops.gemm_tn_ok(N8, K, M, ragged=True) and K % 8 == 0 and g8.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
         # both operands have the reduction index (the rows) as their slow axis: csrc/tn_gemm.hip reads them as they lie
         dW = ops.weight_grad_tn(g8, x2d, M, N8, K)
         db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)

@@ -51,6 +51,12 @@ def _linear_grads(x2d, g2d):
     """dW fp32 [N,K], db fp32 [N] of y = x W^T + b from x bf16 [R,K], g bf16 [R,N] (split-K reduction over R)."""
     R, K = x2d.shape
     N = g2d.shape[1]
+    if ops.gemm_tn_ok(N, K, R, ragged=True) and g2d.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
+        # both operands have the reduction index (the cells) as their slow axis: csrc/tn_gemm.hip reads them as they lie
+        dW = ops.weight_grad_tn(g2d, x2d, R, N, K)
+        db = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+        ops.colsum_bf16(g2d, db, R, N, N)
+        return dW, db
     gT = ops.transpose_bf16(g2d, R, N)
     xT = ops.transpose_bf16(x2d, R, K)
     dW = ops.gemm_reduce_rows(gT, xT, N, K, R)

@@ -112,15 +112,21 @@ def gemm_tn(A, B, C, M, N, K, lda, ldb, ldc, *, nbatch=1, nb1=1, sa=(0, 0), sb=(
     return C
 
 
-def gemm_tn_ok(M, N, K):
-    """shapes the reduction-major product covers (256 x 256 output tiles, 64-row K steps)"""
-    return M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and os.environ.get("DFOLD_GEMM_TN", "1") != "0"
+def gemm_tn_ok(M, N, K, ragged=False):
+    """shapes the reduction-major product covers (256 x 256 output tiles, 64-row K steps).  ragged: output extents that are
+    only multiples of 8 (tiles hanging over the edge compute on re-read columns and store nothing there): the weight
+    gradients of the 128- / 192- / 480- / 640-wide layers, whose alternative is two transposed operand copies."""
+    if os.environ.get("DFOLD_GEMM_TN", "1") == "0" or K % 64:
+        return False
+    if ragged and os.environ.get("DFOLD_GEMM_TN_RAGGED", "1") != "0":
+        return M % 8 == 0 and N % 8 == 0
+    return M % 256 == 0 and N % 256 == 0
 
 
 def weight_grad_tn(g2d, x2d, M, N, K, out=None):
     """dW fp32 [N, K] (+)= g2d^T x2d for g2d bf16 [M, N], x2d bf16 [M, K]: the long row axis M is cut into split-K parts so
     that the few 256 x 256 output tiles still fill the chip."""
-    tiles = (N // 256) * (K // 256)
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
     S = max(1, min(64, 512 // tiles))
     while S > 1 and (M % (S * 64)):
         S -= 1

@@ -122,7 +122,7 @@ int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, in
    the IPA backward (dK = dS^T Q, dV = P^T dO; src/model/ipa_pytorch_dynamic.py:396-469).  Batch z -> (z / nb1, z % nb1)
    with element strides (sa0, sa1) / (sb0, sb1) / (sc0, sc1).  flags: DFOLD_GEMM_OUT_BF16 (C bf16, stored), DFOLD_GEMM_ACCUM
    (C fp32 += ), DFOLD_GEMM_ATOMIC (C fp32, atomics: required when splitk > 1 -- the K range is cut into splitk parts, C must
-   hold the running sum / zeros), else C fp32 stored.  M, N multiples of 256; K a multiple of 64 * splitk; lda, ldb, ldc and
+   hold the running sum / zeros), else C fp32 stored.  M, N multiples of 8 (256 x 256 output tiles; a tile over the edge stores only its valid part); K a multiple of 64 * splitk; lda, ldb, ldc and
    the A / B strides multiples of 8, A / B 16-byte aligned. */
 int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
                        int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,

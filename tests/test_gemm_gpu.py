@@ -421,3 +421,21 @@ def test_gemm_tn_reduction_major_operands(dev):
     assert rel_l2(dkv[..., C:], refk) < 4e-3
     with pytest.raises(ValueError):
         ops.gemm_tn(g, x, dW, N, K, R, N + 8, K, K, splitk=4)              # split-K without atomics
+    # (c) output extents that are only multiples of 8 (tiles hanging over the edge re-read column chunk 0 and store nothing
+    #     there): the weight gradients of the 640 x 128, 480 x 256, 8 x 1280, 136 x 328 layers; fp32 atomics / store /
+    #     accumulate must leave everything outside [N, K] of a LARGER destination untouched; bf16 output as well
+    for (R2, N2, K2) in ((2048, 640, 128), (1024, 480, 256), (2048, 8, 1280), (512, 136, 328)):
+        g2 = torch.randn(R2, N2, generator=gen).to(dev).to(torch.bfloat16)
+        x2 = torch.randn(R2, K2, generator=gen).to(dev).to(torch.bfloat16)
+        ref2 = g2.double().t() @ x2.double()
+        assert ops.gemm_tn_ok(N2, K2, R2, ragged=True) and not ops.gemm_tn_ok(N2, K2, R2)
+        assert rel_l2(ops.weight_grad_tn(g2, x2, R2, N2, K2), ref2) < 1e-5, (R2, N2, K2)
+        big = torch.full((N2 + 8, K2 + 8), 7.0, dtype=torch.float32, device=dev)
+        ops.gemm_tn(g2, x2, big, N2, K2, R2, N2, K2, K2 + 8)
+        assert rel_l2(big[:N2, :K2], ref2) < 1e-5 and float((big[N2:] - 7).abs().max()) == 0 and float((big[:, K2:] - 7).abs().max()) == 0
+        ops.gemm_tn(g2, x2, big, N2, K2, R2, N2, K2, K2 + 8, flags=ops.GEMM_ACCUM, alpha=-1.0)
+        assert float(big[:N2, :K2].abs().max()) < 1e-3 * float(ref2.abs().max()) and float((big[N2:] - 7).abs().max()) == 0
+        bigb = torch.full((N2 + 8, K2 + 8), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm_tn(g2, x2, bigb, N2, K2, R2, N2, K2, K2 + 8)
+        assert rel_l2(bigb[:N2, :K2], ref2) < 4e-3 and float((bigb[N2:].float() - 7).abs().max()) == 0 \
+            and float((bigb[:, K2:].float() - 7).abs().max()) == 0
