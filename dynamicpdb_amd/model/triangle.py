@@ -153,14 +153,22 @@ class TriangleMultiplicationFn(Function):
         gemm(dy, CACHE.wt(w_z), dxn, R, c, cz, a_rows=rows_plain(cz), c_rows=rows_plain(c), ldb=cz)
         dx, dg_out, db_out = _row_ln_bwd(x, st_out, g_out.detach(), dxn, dx_bf16=True)
         dxp = _to_planes(dx, B, N, True)                                               # [B][c][N][N]
-        planesT = ops.transpose_bf16(planes, N, N, nbatch=B * 2 * c, nb1=1, bs_src=(NN, 0))   # [B][2c][k][i|j]
-        dxpT = ops.transpose_bf16(dxp, N, N, nbatch=B * c, nb1=1, bs_src=(NN, 0))
         dplanes = torch.empty((B, 2 * c, N, N), dtype=BF16, device=dev)
         # da_c[i,k] = sum_j dx_c[i,j] b_c[j,k];   db_c[j,k] = sum_i dx_c[i,j] a_c[i,k]     (batch = (item, channel))
-        gemm(dxp, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
-             sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), b_off=c * NN)
-        gemm(dxpT, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
-             sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), c_off=c * NN)
+        dxpT = ops.transpose_bf16(dxp, N, N, nbatch=B * c, nb1=1, bs_src=(NN, 0))
+        if ops.gemm_tn_ok(N, N, N, ragged=True):
+            # both products have their reduction index as the slow axis of both operands once dx^T exists (csrc/tn_gemm.hip):
+            # da_c = (dx_c^T)^T b_c, db_c = dx_c^T a_c -- the a | b planes are read as they lie (no transposed copy of them)
+            ops.gemm_tn(dxpT, planes, dplanes, N, N, N, N, N, N, nbatch=B * c, nb1=c, sa=(c * NN, NN), sb=(2 * c * NN, NN),
+                        sc=(2 * c * NN, NN), b_off=c * NN)
+            ops.gemm_tn(dxp, planes, dplanes, N, N, N, N, N, N, nbatch=B * c, nb1=c, sa=(c * NN, NN), sb=(2 * c * NN, NN),
+                        sc=(2 * c * NN, NN), c_off=c * NN)
+        else:
+            planesT = ops.transpose_bf16(planes, N, N, nbatch=B * 2 * c, nb1=1, bs_src=(NN, 0))   # [B][2c][k][i|j]
+            gemm(dxp, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
+                 sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), b_off=c * NN)
+            gemm(dxpT, planesT, dplanes, N, N, N, a_rows=rows_plain(N), c_rows=rows_plain(N), ldb=N, nbatch=B * c, nb1=c,
+                 sa=(c * NN, NN), sb=(2 * c * NN, NN), sc=(2 * c * NN, NN), c_off=c * NN)
         dab = _from_planes(dplanes, B, N, outgoing)
         check(L.dfold_trimul_gate_bwd(_p(proj), _p(maskf), _p(dab), _p(dproj), c_int64(R), c_int32(c), stream()),
               "dfold_trimul_gate_bwd")
