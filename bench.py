@@ -361,6 +361,10 @@ def main():
     # headline: every frame through the conv tower, the work the reference does (SURVEY 8d FLOP model)
     trainer = experiment.Trainer(model, lr=1e-4, last_frame_only=(args.mode == "last_frame"))
     trainer.reducer.timing = world > 1
+    # the benchmark step runs one and the same autograd graph on every rank and in every step (like the reference under
+    # DistributedDataParallel without find_unused_parameters): after two clean steps the reducer drops its per-step flag
+    # collective and the host no longer waits for the device once per step (DFOLD_DP_STATIC_GRAPH=0 keeps the collective)
+    trainer.reducer.static_graph = os.environ.get("DFOLD_DP_STATIC_GRAPH", "1") != "0"
     if world > 1:
         ck = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
         lo, hi = ck.clone(), ck.clone()
@@ -418,7 +422,8 @@ def main():
             ver = None
         gb = sum(r["mb"] for r in prof)
         dp_info = {"backend": dist.get_backend(), "rccl_version": ver, "ranks_seen": seen, "gradient_mb_per_step": round(gb, 1),
-                   "payload_dtype": "bf16" if red.payload_dtype == torch.bfloat16 else "fp32", "buckets": prof,
+                   "payload_dtype": "bf16" if red.payload_dtype == torch.bfloat16 else "fp32", "static_graph": bool(red.static_graph),
+                   "buckets": prof,
                    "note": "launched_ms_before_backward_end: compute-stream time between a bucket's all-reduce launch and the end "
                            "of backward (what can overlap; buckets launched in finish() show ~0); isolated_ms / bus_GBps: the same "
                            "bucket's collective alone, bus bandwidth = 2 (n-1)/n bytes / time (xGMI ring: per-link bound)"}
@@ -428,6 +433,8 @@ def main():
     el2 = None
     if not args.no_last_frame_mode and args.mode == "all_frames":
         trainer.last_frame_only = True
+        trainer.reducer.reset_structure()         # another graph: re-discover (and, static_graph, re-arm the flag collective)
+        trainer.update_fn(batches[0])
         trainer.update_fn(batches[0])
         el2, _ = timed_steps(trainer, batches[1:1 + args.steps], args.steps, sync)
         el2 = torch.tensor([el2], device=dev, dtype=torch.float64)

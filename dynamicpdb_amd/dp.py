@@ -74,8 +74,13 @@ def broadcast_parameters(tensors, src=0, group=None):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, force=False, payload_dtype=None):
-        """params: the trainable parameters in a fixed order (identical on all ranks).  force: run the collectives even
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, force=False, payload_dtype=None, static_graph=None):
+        """params: the trainable parameters in a fixed order (identical on all ranks).  static_graph (default: the environment
+        variable DFOLD_DP_STATIC_GRAPH, off): the caller promises that every rank runs the same autograd graph in every step
+        (DFOLDv2 training does: the reference wraps it in DistributedDataParallel without find_unused_parameters,
+        train_DFOLD_dynamics.py:373-376).  After two clean steps the per-step flag collective of finish() -- and with it the
+        host's wait for the device once per step -- is skipped; a late or stray gradient seen LOCALLY then raises instead of
+        being repaired (a change on one rank cannot be agreed on without the collective: loud failure, never a silent one).  force: run the collectives even
         in a single-rank world (test / single-GPU coverage of the multi-GPU code path).  payload_dtype: torch.bfloat16
         sends every bucket as bf16 (half the bytes per xGMI link; the bucket is rounded once before and the average once
         after the collective -- relative error 2^-8 per gradient entry, opt-in; default / None = fp32, exact); the
@@ -112,6 +117,10 @@ class GradReducer:
         if payload_dtype is None and os.environ.get("DFOLD_DP_GRAD_BF16", "0") == "1":
             payload_dtype = torch.bfloat16
         self.payload_dtype = payload_dtype
+        if static_graph is None:
+            static_graph = os.environ.get("DFOLD_DP_STATIC_GRAPH", "0") == "1"
+        self.static_graph = bool(static_graph)
+        self._clean_steps = 0
 
     # ---------------------------------------------------------------- wiring
     def attach(self, model=None):
@@ -151,6 +160,12 @@ class GradReducer:
                 m._tower.on_final = None
 
     # ---------------------------------------------------------------- per-step protocol
+    def reset_structure(self):
+        """the caller is about to run a DIFFERENT graph (e.g. another step mode): discover the gradient structure again and,
+        under static_graph, run the per-step flag collective again until two clean steps have been seen."""
+        self._pending_rebuild = self.flat is not None
+        self._clean_steps = 0
+
     def begin_step(self):
         """call before forward: zero the gradients (flat buffer once built) and re-arm the buckets."""
         if self._ev is not None:             # last step's wait time (events of the previous step have long completed)
@@ -309,6 +324,12 @@ class GradReducer:
         """one small collective per step: flags [late parameter i ...| stray parameter i ...], MAX over ranks.  late: this
         rank's late accumulations {parameter index: tensor}"""
         n = len(self.params)
+        if self.static_graph and self._clean_steps >= 2:
+            if self._late or self._stray:
+                raise RuntimeError("GradReducer(static_graph=True): the autograd graph of this rank changed (late accumulations of "
+                                   f"parameters {sorted(self._late)}, stray gradients of {sorted(self._stray)}); run without "
+                                   "static_graph to have such steps repaired collectively")
+            return                                # no collective, no host wait: the stream waits, the host runs ahead
         flags = torch.zeros(2 * n, dtype=torch.int32)
         for i in self._late:
             flags[i] = 1
@@ -320,7 +341,9 @@ class GradReducer:
             dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
             flags = f.cpu()
         if not bool(flags.any()):
+            self._clean_steps += 1
             return
+        self._clean_steps = 0
         for i in torch.nonzero(flags[:n]).flatten().tolist():
             p = self.params[i]
             g = late.get(i)

@@ -267,7 +267,38 @@ def _dp_worker(rank, world, port, q):
                 if b.grad is not None:
                     bf16_err = max(bf16_err, float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-30)))
         bf16_ok = 0.0 < bf16_err < 8e-3 and tr2.reducer.payload_dtype == torch.bfloat16
-        info = dict(late_ok=late_ok, bf16_ok=bf16_ok, bf16_err=bf16_err, n_buckets=len(red.buckets), views=all(p.grad is None or p.grad.untyped_storage().data_ptr() ==
+        # static_graph: after two clean steps the per-step flag collective (and the host's wait for it) is skipped; the averages
+        # stay exact; a graph change seen locally then raises instead of being repaired
+        m3, ref3 = copy.deepcopy(ref), copy.deepcopy(ref)
+        tr3 = experiment.Trainer(m3, lr=1e-2, bucket_bytes=1024, last_frame_only=False)
+        tr3.reducer.static_graph = True
+        static_err, n_coll = 0.0, []
+        orig_allreduce = dist.all_reduce
+        for step in range(5):
+            calls = [0]
+
+            def counting(t, *a, **k):
+                if t.dtype == torch.int32:
+                    calls[0] += 1
+                return orig_allreduce(t, *a, **k)
+            dist.all_reduce = counting
+            xs = [torch.randn(5, 8, generator=torch.Generator().manual_seed(800 + 10 * step + r)) for r in range(world)]
+            tr3.update_fn({"x": xs[rank]}, step_optimizer=False)
+            dist.all_reduce = orig_allreduce
+            n_coll.append(calls[0])
+            ref3.zero_grad(set_to_none=True)
+            for r in range(world):
+                (ref3(dict(x=xs[r])).pow(2).mean() / world).backward()
+            for a, b in zip(m3.parameters(), ref3.parameters()):
+                if b.grad is not None:
+                    static_err = max(static_err, float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-30)))
+        raised = False
+        try:                                        # every rank changes its graph in the same step: each one raises locally
+            tr3.update_fn({"x": xs[rank], "use_dead": True}, step_optimizer=False)
+        except RuntimeError as e:
+            raised = "static_graph" in str(e)
+        static_ok = static_err < 1e-5 and n_coll[:2] == [1, 1] and n_coll[-2:] == [0, 0] and raised
+        info = dict(late_ok=late_ok, bf16_ok=bf16_ok, static_ok=static_ok, n_coll=n_coll, static_err=static_err, bf16_err=bf16_err, n_buckets=len(red.buckets), views=all(p.grad is None or p.grad.untyped_storage().data_ptr() ==
                                                           red.flat.untyped_storage().data_ptr() for p in model.parameters()),
                     expected_shared=red._expected[id(model.shared.weight)], rediscoveries=red.rediscoveries,
                     started_equal=started_equal, synced=synced, bytes_broadcast=tr.bytes_broadcast,
@@ -287,7 +318,8 @@ def test_data_parallel_gradient_average_gloo_world2():
     step in which ONE rank's graph uses a parameter that had no gradient in the discovery step is still averaged exactly
     and followed by a re-discovery; a step in which one rank accumulates again AFTER its buckets were launched (the late
     parts land in tensors of their own, never in a bucket in flight) is averaged exactly too; the optimizer trajectories
-    match a single-process reference; with the opt-in bf16 gradient payload the average agrees to bf16 rounding."""
+    match a single-process reference; with the opt-in bf16 gradient payload the average agrees to bf16 rounding; with
+    static_graph the per-step flag collective disappears after two clean steps and a local graph change raises."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -306,6 +338,7 @@ def test_data_parallel_gradient_average_gloo_world2():
                 if g is not None:
                     assert np.allclose(g, w, rtol=1e-5, atol=1e-7), (rank, step)
         assert info["n_buckets"] >= 3 and info["views"] and info["expected_shared"] == 1 and info["params_equal"], info
+        assert info["static_ok"], info
         assert info["rediscoveries"] == 2 and info["late_ok"] and info["bf16_ok"] and info["synced"] and info["bytes_broadcast"] > 0, info
         assert info["started_equal"] == (rank == 0), info
 
