@@ -527,3 +527,27 @@ def test_transpose_read_kernels_addressing_emulation():
     assert emulate_wgrad_tn.run(CA=256, CB=64, Wn=1, F=2, N=64, check_wgs=2) == (0, 2)
     assert emulate_wgrad_tn.run(CA=256, CB=128, Wn=1, F=1, N=64, flip=1, seed=4, check_wgs=1) == (0, 1)
     assert emulate_tn_gemm.run(lda=256, ldb=256, seed=2) == (0, 0)
+
+
+def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
+    """Regression guard without a GPU (hipcc -S, scripts/isa_audit.py): the kernels whose exposed memory round trips were
+    removed in round 4 must not grow them back -- no chains of `global_load .. s_waitcnt vmcnt(0) .. global_load` in the
+    query-block triangle-attention kernel, the IPA column pass and the embedder backward's row loop, and no scratch traffic
+    inside the loops of the column pass (its staged tiles once lived in scratch memory)."""
+    sys.path.insert(0, ROOT)
+    from scripts.isa_audit import audit
+    csrc = os.path.join(ROOT, "dynamicpdb_amd", "csrc")
+    rows = {r[0]: r for src in ("triatt_rows.hip", "ipa_attn.hip", "embed.hip") for r in audit(os.path.join(csrc, src))}
+
+    def find(prefix):
+        hits = [v for k, v in rows.items() if prefix in k]
+        assert hits, prefix
+        return hits
+    for (_, vgpr, _, scratch, mfma, loads, serial, scr_loop) in find("triatt_rows_kernel"):
+        assert serial == 0 and vgpr <= 256 and mfma >= 64, (serial, vgpr, mfma)
+    for (name, vgpr, _, scratch, _, loads, serial, scr_loop) in find("ipa_col_bwd_kernel"):
+        assert serial == 0 and scr_loop == 0 and scratch == 0, (name, serial, scr_loop, scratch)
+    for (name, *_rest) in find("embed_in_bwd_kernel"):
+        assert _rest[5] == 0, (name, _rest)          # serialized pairs
+    for (name, *_rest) in find("embed_in_bwd_dx_kernel"):
+        assert _rest[5] <= 8, (name, _rest)          # only the once-per-kernel weight loads of the prologue remain
