@@ -88,6 +88,42 @@ __device__ __forceinline__ void tb_load_planes(const bf16_t* __restrict__ srcT, 
   }
 }
 
+// The four LDS tiles of a row -- two [rows][32] head slices (row-major) and the same two channel-major -- staged TOGETHER:
+// every global load is issued before the first LDS write, unconditionally (rows / cells past the end re-read the last valid
+// one and are zeroed by a select).  As four calls of tb_load_rows / tb_load_planes with `if (row < nvalid) v = load` each
+// iteration was a branch with load - s_waitcnt vmcnt(0) - LDS write inside: 16 (N_res <= 256: 8 ...) memory round trips in
+// a row per pair-tensor row in kernel K, whose arithmetic per row is 32 MFMAs per wave (hipcc -S, scripts/isa_audit.py).
+template <int NMAX, int NT>
+__device__ __forceinline__ void tb_stage_row(const bf16_t* __restrict__ r0, long ld0, const bf16_t* __restrict__ r1, long ld1,
+                                             const bf16_t* __restrict__ t0, const bf16_t* __restrict__ t1, long ldT, int nvalid,
+                                             char* lds0, char* lds1, char* ldsT0, char* ldsT1, int tid) {
+  constexpr int IT = NMAX * 4 / NT, TP = NMAX * 2 + 16, CPR = NMAX / 8;
+  tbu32x4 a[IT], b[IT], c[IT], d[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int id = it * NT + tid, row = id >> 2, cc = id & 3;
+    const int rc = row < nvalid ? row : nvalid - 1;
+    a[it] = *(const tbu32x4*)(r0 + (long)rc * ld0 + cc * 8);
+    b[it] = *(const tbu32x4*)(r1 + (long)rc * ld1 + cc * 8);
+    const int ch = id / CPR, cell0 = (id - ch * CPR) * 8;
+    const int cl = cell0 < nvalid ? cell0 : nvalid - 8;                  // nvalid % 8 == 0
+    c[it] = *(const tbu32x4*)(t0 + (long)ch * ldT + cl);
+    d[it] = *(const tbu32x4*)(t1 + (long)ch * ldT + cl);
+  }
+  const tbu32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int id = it * NT + tid, row = id >> 2, cc = id & 3;
+    const bool rin = row < nvalid;
+    *(tbu32x4*)(lds0 + tb_k_off(row, cc)) = rin ? a[it] : z;
+    *(tbu32x4*)(lds1 + tb_k_off(row, cc)) = rin ? b[it] : z;
+    const int ch = id / CPR, cell0 = (id - ch * CPR) * 8;
+    const bool cin = cell0 < nvalid;
+    *(tbu32x4*)(ldsT0 + ch * TP + cell0 * 2) = cin ? c[it] : z;
+    *(tbu32x4*)(ldsT1 + ch * TP + cell0 * 2) = cin ? d[it] : z;
+  }
+}
+
 // A operand whose reduction index is permuted to the accumulator-derived B operand: 4 + 4 elements 32 bytes apart
 __device__ __forceinline__ bf16x8 tb_frag_perm(const char* p) {
   const tbu32x2 lo = *(const tbu32x2*)p, hi = *(const tbu32x2*)(p + 32);
@@ -115,11 +151,16 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
   const long bi = blockIdx.x >> 2;                    // b * N + i
   const int b = (int)(bi / N);
   const long row0 = bi * N;                           // first cell of the row
-  tb_load_rows<NMAX>(p.proj + row0 * 512 + 128 + h * 32, 512, N, ldsK, tid);
-  tb_load_rows<NMAX>(p.proj + row0 * 512 + 256 + h * 32, 512, N, ldsV, tid);
-  tb_load_planes<NMAX>(p.projT + (long)(128 + h * 32) * p.R + row0, p.R, N, ldsKT, tid);
-  tb_load_planes<NMAX>(p.projT + (long)(256 + h * 32) * p.R + row0, p.R, N, ldsVT, tid);
-  for (int t = tid; t < NMAX; t += 256) ldsMB[t] = t < N ? p.inf * (p.mask[row0 + t] - 1.f) * TB_L2E : -INFINITY;
+  {
+    float mraw[NMAX / 256];
+#pragma unroll
+    for (int u = 0; u < NMAX / 256; ++u) mraw[u] = p.mask[row0 + min(tid + 256 * u, N - 1)];      // (in flight with the tiles)
+    tb_stage_row<NMAX, 256>(p.proj + row0 * 512 + 128 + h * 32, 512, p.proj + row0 * 512 + 256 + h * 32, 512,
+                            p.projT + (long)(128 + h * 32) * p.R + row0, p.projT + (long)(256 + h * 32) * p.R + row0, p.R, N, ldsK, ldsV,
+                            ldsKT, ldsVT, tid);
+#pragma unroll
+    for (int u = 0; u < NMAX / 256; ++u) ldsMB[tid + 256 * u] = tid + 256 * u < N ? p.inf * (mraw[u] - 1.f) * TB_L2E : -INFINITY;
+  }
   __syncthreads();
 
   const float sl2 = p.scale * TB_L2E;
@@ -326,15 +367,22 @@ __global__ __launch_bounds__(512) void triatt_bwd_k_kernel(const TriAttBwdParams
     const long bi = (long)b * N + i;
     const long row0 = bi * N;
     __syncthreads();            // the previous row's readers are done with the tiles and the reduction buffer
-    tb_load_rows_nt<NMAX, 512>(p.proj + row0 * 512 + h * 32, 512, N, ldsQ, tid);
-    tb_load_rows_nt<NMAX, 512>(p.dos + row0 * 128 + h * 32, 128, N, ldsDO, tid);
-    tb_load_planes_nt<NMAX, 512>(p.projT + (long)(h * 32) * p.R + row0, p.R, N, ldsQT, tid);
-    tb_load_planes_nt<NMAX, 512>(p.dosT + (long)(h * 32) * p.R + row0, p.R, N, ldsDOT, tid);
     {
+      // statistics of the row's queries (3 x NMAX floats), requested together with the tiles
       const float* st = p.stats + ((bi * 4 + h) * 3) * N;
-      for (int t = tid; t < 3 * NMAX; t += 512) {
-        const int which = t / NMAX, qq = t - which * NMAX;
-        ldsST[t] = qq < N ? st[which * N + qq] : 0.f;
+      constexpr int SI = (3 * NMAX + 511) / 512;
+      float sv[SI];
+#pragma unroll
+      for (int u = 0; u < SI; ++u) {
+        const int t = min(tid + 512 * u, 3 * NMAX - 1), which = t / NMAX, qq = t - which * NMAX;
+        sv[u] = st[which * N + min(qq, N - 1)];
+      }
+      tb_stage_row<NMAX, 512>(p.proj + row0 * 512 + h * 32, 512, p.dos + row0 * 128 + h * 32, 128, p.projT + (long)(h * 32) * p.R + row0,
+                              p.dosT + (long)(h * 32) * p.R + row0, p.R, N, ldsQ, ldsDO, ldsQT, ldsDOT, tid);
+#pragma unroll
+      for (int u = 0; u < SI; ++u) {
+        const int t = tid + 512 * u, which = t / NMAX, qq = t - which * NMAX;
+        if (t < 3 * NMAX) ldsST[t] = qq < N ? sv[u] : 0.f;
       }
     }
     __syncthreads();
