@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
   char* const ldsKT = smem + 2 * ROWT;
   char* const ldsVT = smem + 2 * ROWT + TRT;
   float* const ldsMB = (float*)(smem + 2 * ROWT + 2 * TRT);
+  char* const ldsWO = smem + 2 * ROWT + 2 * TRT + 3 * NMAX * 4;     // W_o^T rows of the head: [32][128 bf16], chunks XORed with (row & 15)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int N = p.N;
@@ -152,6 +153,14 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
   const int b = (int)(bi / N);
   const long row0 = bi * N;                           // first cell of the row
   {
+    // the head's 32 rows of W_o^T (8 KB) once per workgroup: fetched per query tile from global memory every one of the 8
+    // fragments was a load - wait - MFMA step
+    tbu32x4 wo2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int id = tid + 256 * j, row = id >> 4, c = id & 15;
+      wo2[j] = *(const tbu32x4*)(p.WoT + (long)(h * 32 + row) * 128 + c * 8);
+    }
     float mraw[NMAX / 256];
 #pragma unroll
     for (int u = 0; u < NMAX / 256; ++u) mraw[u] = p.mask[row0 + min(tid + 256 * u, N - 1)];      // (in flight with the tiles)
@@ -160,6 +169,11 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
                             ldsKT, ldsVT, tid);
 #pragma unroll
     for (int u = 0; u < NMAX / 256; ++u) ldsMB[tid + 256 * u] = tid + 256 * u < N ? p.inf * (mraw[u] - 1.f) * TB_L2E : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int id = tid + 256 * j, row = id >> 4, c = id & 15;
+      *(tbu32x4*)(ldsWO + row * 256 + ((c ^ (row & 15)) << 4)) = wo2[j];
+    }
   }
   __syncthreads();
 
@@ -175,13 +189,51 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
     const bool qok = q < N;
     const long qrow = row0 + (qok ? q : N - 1);
     const bf16_t* prow = p.proj + qrow * 512 + h * 32;
+    // everything this query tile reads from global memory is requested here, together: q, the four dout fragments, the gate
+    // pre-activations and the NKT triangle-bias vectors (unconditional; keys past the end re-read the last four and meet a
+    // -inf mask bias) -- as `if (key0 < N) tb = load` behind the MFMAs each bias vector was its own load - wait step
     const bf16x8 qf = *(const bf16x8*)(prow + l4 * 8);
-    // ---- S^T = K Q^T; logits * log2 e; exact softmax over the row's keys (accumulator: rows = keys kb*16 + l4*4 + r, column = query l15)
+    bf16x8 dof[4];
+    tbu32x2 ggv[2];
     f32x4 s[NKT];
+    float mx = -INFINITY;
+    if constexpr (NMAX == 256) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(p.dob + qrow * 128 + ks * 32 + l4 * 8);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) ggv[cb] = *(const tbu32x2*)(prow + 384 + cb * 16 + l4 * 4);
+    // ---- S^T = K Q^T with (triangle bias log2 e + mask bias) / (scale log2 e) as accumulator init; exact softmax over the
+    //      row's keys (accumulator: rows = keys kb*16 + l4*4 + r, column = query l15)
+    const float* trow = p.tri + (((long)b * 4 + h) * N + (qok ? q : N - 1)) * N;
+#pragma unroll
+    for (int kb = 0; kb < NKT; ++kb) {
+      const int key0 = kb * 16 + l4 * 4;
+      s[kb] = *(const f32x4*)(trow + (key0 < N ? key0 : N - 4));            // N % 4 == 0
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, NKT + 7, 0);
+    const float inv_sl2 = 1.f / sl2;
+#pragma unroll
+    for (int kb = 0; kb < NKT; ++kb) {
+      const f32x4 mb = *(const f32x4*)(ldsMB + kb * 16 + l4 * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[kb][r] = __builtin_fmaf(s[kb][r], TB_L2E, mb[r]) * inv_sl2;
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKT; ++kb) s[kb] = TB_MFMA(*(const bf16x8*)(ldsK + (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4)), qf, s[kb]);
+#pragma unroll
+    for (int kb = 0; kb < NKT; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kb][r] *= sl2;
+        mx = fmaxf(mx, s[kb][r]);
+      }
+    } else {
+      // (N_res <= 512 instance, one wave per SIMD with half its values in AGPRs: the batched form measured 3-6 % slower there --
+      //  hipcc serialises the loads it cannot place -- so it keeps the products first and the bias loads behind them)
+    // ---- S^T = K Q^T; logits * log2 e; exact softmax over the row's keys (accumulator: rows = keys kb*16 + l4*4 + r, column = query l15)
 #pragma unroll
     for (int kb = 0; kb < NKT; ++kb) s[kb] = TB_MFMA(*(const bf16x8*)(ldsK + (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4)), qf, zero4);
     const float* trow = p.tri + (((long)b * 4 + h) * N + (qok ? q : N - 1)) * N;
-    float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NKT; ++kb) {
       const int key0 = kb * 16 + l4 * 4;
@@ -193,6 +245,11 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
         s[kb][r] = __builtin_fmaf(s[kb][r], sl2, __builtin_fmaf(tb[r], TB_L2E, mb[r]));
         mx = fmaxf(mx, s[kb][r]);
       }
+    }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(p.dob + qrow * 128 + ks * 32 + l4 * 8);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) ggv[cb] = *(const tbu32x2*)(prow + 384 + cb * 16 + l4 * 4);
     }
     mx = tb_xmax(mx);
     float sum = 0.f;
@@ -217,17 +274,16 @@ __global__ __launch_bounds__(256, NMAX == 256 ? 2 : 1) void triatt_bwd_q_kernel(
     f32x4 dg[2] = {zero4, zero4};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 dof = *(const bf16x8*)(p.dob + qrow * 128 + ks * 32 + l4 * 8);
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
-        dg[cb] = TB_MFMA(*(const bf16x8*)(p.WoT + (long)(h * 32 + cb * 16 + l15) * 128 + ks * 32 + l4 * 8), dof, dg[cb]);
+        dg[cb] = TB_MFMA(*(const bf16x8*)(ldsWO + (cb * 16 + l15) * 256 + (((ks * 4 + l4) ^ l15) << 4)), dof[ks], dg[cb]);
     }
     // ---- gate; do = dog * sigma, dg = dog * o * sigma (1 - sigma), og = o * sigma, D = <do, o>
     f32x4 dov[2];
     float Dp = 0.f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      const tbu32x2 gg = *(const tbu32x2*)(prow + 384 + cb * 16 + l4 * 4);
+      const tbu32x2 gg = ggv[cb];
       const float gp[4] = {bf_lo(gg.x), bf_hi(gg.x), bf_lo(gg.y), bf_hi(gg.y)};
       float ogv[4], dgv[4];
 #pragma unroll
@@ -483,15 +539,15 @@ extern "C" int dfold_triatt_bwd_core(const void* proj_bf16, const void* proj_t_b
   const unsigned gq = (unsigned)((long)B * N * 4), gk = (unsigned)((long)n_chunks * B * 4 * p.KB);
   if (N <= 256) {
     constexpr int LDS = 2 * 256 * 64 + 2 * 32 * (256 * 2 + 16) + 3 * 256 * 4, LDSK = LDS + 4 * 1 * 16 * 64 * 4;
-    DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<256>), LDS);
+    DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<256>), LDS + 8192);
     DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<256>), LDSK);
-    DFOLD_LAUNCH(triatt_bwd_q_kernel<256>, dim3(gq), dim3(256), LDS, (hipStream_t)stream, p);
+    DFOLD_LAUNCH(triatt_bwd_q_kernel<256>, dim3(gq), dim3(256), LDS + 8192, (hipStream_t)stream, p);
     DFOLD_LAUNCH(triatt_bwd_k_kernel<256>, dim3(gk), dim3(512), LDSK, (hipStream_t)stream, p);
   } else {
     constexpr int LDS = 2 * 512 * 64 + 2 * 32 * (512 * 2 + 16) + 3 * 512 * 4, LDSK = LDS + 2 * 3 * 16 * 64 * 4;
-    DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<512>), LDS);
+    DFOLD_MAX_LDS_ONCE((triatt_bwd_q_kernel<512>), LDS + 8192);
     DFOLD_MAX_LDS_ONCE((triatt_bwd_k_kernel<512>), LDSK);
-    DFOLD_LAUNCH(triatt_bwd_q_kernel<512>, dim3(gq), dim3(256), LDS, (hipStream_t)stream, p);
+    DFOLD_LAUNCH(triatt_bwd_q_kernel<512>, dim3(gq), dim3(256), LDS + 8192, (hipStream_t)stream, p);
     DFOLD_LAUNCH(triatt_bwd_k_kernel<512>, dim3(gk), dim3(512), LDSK, (hipStream_t)stream, p);
   }
   return dfold_check_launch();

@@ -1,4 +1,4 @@
-# round 4 (second session), call 15: batched row staging in the streaming triangle-attention backward kernels -- parity, times
+# round 4 (second session), call 15-16: batched row staging, query-tile loads of kernel Q in the streaming triangle-attention backward kernels -- parity, times
 set -u
 cd $GRAFT_REPO_ROOT
 ( timeout 600 python -m pytest tests/test_pair_fused_gpu.py -q -x -k "stream_backward_stages or (gradients_vs_oracle and tri_att) or (batched_backward and tri_att)" 2>&1 | tail -n 3 ) | cut -c1-200
