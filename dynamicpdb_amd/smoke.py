@@ -28,9 +28,11 @@ def run(F=3, N=16, seed_w=0):
     loss, aux = experiment.loss_fn(out, batch)
     loss.backward()
     torch.cuda.synchronize()
+    loss = loss.detach()
     ref = O.full_score_network(sd, O.Schedules(), w)
     ref_loss, _ = O.loss_fn(ref, w)
-    err = float((out["rigids"][0, ..., 4:].cpu() - ref["rigids"][..., 4:]).abs().max())
+    ref_loss = ref_loss.detach()
+    err = float((out["rigids"][0, ..., 4:].detach().cpu() - ref["rigids"][..., 4:].detach()).abs().max())
     rel = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
     gn = sum(float(p.grad.double().norm() ** 2) for p in model.parameters() if p.grad is not None) ** 0.5
     print(f"smoke: loss {float(loss):.5f} (oracle {float(ref_loss):.5f}, rel {rel:.2e}), max |dtrans| {err:.2e} A, "
