@@ -551,3 +551,56 @@ def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
         assert _rest[5] == 0, (name, _rest)          # serialized pairs
     for (name, *_rest) in find("embed_in_bwd_dx_kernel"):
         assert _rest[5] <= 8, (name, _rest)          # only the once-per-kernel weight loads of the prologue remain
+
+
+def test_triatt_rows_addressing_host_emulation():
+    """Index arithmetic of csrc/triatt_rows.hip / the bias pass of csrc/triatt_fused.hip restated on the host (no GPU): (a) the
+    LDS-DMA of a 256-row xn chunk -- wave w, instruction j, lane l writes the 16 bytes at (j*8 + w)*1024 + 16 l and fetches
+    chunk (l & 15) ^ (((w & 3) << 2) + (l >> 4)) of row j*32 + w*4 + (l >> 4) -- fills exactly the XOR-swizzled tile the MFMA
+    A-fragment reads address (tr_a_off), every (row, chunk) once; (b) the K / Q tile: what the projection epilogue writes at
+    tr_k_off(cell, ch >> 3) + (ch & 7) * 2 is what a fragment read of lane (l15, l4) at (kb*16 + l15)*64 + ((l4 ^ kswz) << 4)
+    expects: channels 8 l4 .. 8 l4 + 7 of key kb*16 + l15; (c) the blocked triangle bias: the element the bias pass stores for
+    (query, key) is the one the attention reads into accumulator register r of lane l for its (query tile, key block)."""
+    a_off = lambda row, chunk: row * 256 + ((chunk ^ (row & 15)) << 4)
+    k_off = lambda row, chunk: row * 64 + ((chunk ^ ((-(row >> 2)) & 3)) << 4)
+    # (a)
+    seen = {}
+    for j in range(8):
+        for w in range(8):
+            for lane in range(64):
+                dst = (j * 8 + w) * 1024 + lane * 16
+                row = j * 32 + w * 4 + (lane >> 4)
+                chunk = (lane & 15) ^ (((w & 3) << 2) + (lane >> 4))
+                assert dst == a_off(row, chunk), (j, w, lane)
+                seen[(row, chunk)] = seen.get((row, chunk), 0) + 1
+    assert len(seen) == 256 * 16 and set(seen.values()) == {1}
+    for rt in range(16):                       # reader: row tile rt, k-step ks, lane (l15, l4) -> chunk ks*4 + l4 of row rt*16 + l15
+        for ks in range(4):
+            for l15 in range(16):
+                for l4 in range(4):
+                    assert a_off(rt * 16 + l15, ks * 4 + l4) % 16 == 0 and (rt * 16 + l15, ks * 4 + l4) in seen
+    # conflict-free: the 64 lanes of one fragment read cover 64 distinct 16-byte slots spread over all banks (4 lanes per row)
+    for rt in range(16):
+        slots = {(a_off(rt * 16 + l15, l4) // 16) % 16 for l15 in range(16) for l4 in range(4)}
+        assert len(slots) == 16
+    # (b)
+    for kb in range(16):
+        for l15 in range(16):
+            kswz = (-(l15 >> 2)) & 3
+            for l4 in range(4):
+                rd = (kb * 16 + l15) * 64 + ((l4 ^ kswz) << 4)
+                for e in range(8):
+                    ch = l4 * 8 + e
+                    assert k_off(kb * 16 + l15, ch >> 3) + (ch & 7) * 2 == rd + e * 2
+    # (c) NP = 320 (nt16 = 20): writer = tri_bias_kernel (line = query, 64-key tile pt, lane h*16 + v16 stores keys pt*64 + 4 v16 .. +4),
+    #     reader = tr_attend (block kbg of query tile qt: lane l4*16 + l15, register r <-> key kbg*16 + l4*4 + r, query qt*16 + l15)
+    nt16 = 20
+    for line in (0, 5, 17, 319):
+        for pt in range(nt16 // 4):
+            for v16 in range(16):
+                base = (((line >> 4) * nt16 + pt * 4 + (v16 >> 2)) * 64 + (v16 & 3) * 16 + (line & 15)) * 4
+                for r in range(4):
+                    key = pt * 64 + v16 * 4 + r
+                    qt, l15 = line >> 4, line & 15
+                    kbg, l4, rr = key >> 4, (key & 15) >> 2, key & 3
+                    assert base + r == (qt * nt16) * 256 + kbg * 256 + (l4 * 16 + l15) * 4 + rr
