@@ -10,12 +10,25 @@ G_PITCH = GBT * 2
 G_TILE = GBK * G_PITCH
 
 
-def run(lda=320, ldb=512, seed=0):
+def run(lda=320, ldb=512, seed=0, M=None, N=None):
+    """M, N (multiples of 8, <= 256): ragged output extents -- the tile hangs over the edge of the output: columns past M (N) are
+    fetched from column chunk 0 instead and neither epilogue stores there."""
     rng = np.random.default_rng(seed)
     A = rng.integers(-3, 4, size=(GBK, lda)).astype(np.int64)
     B = rng.integers(-3, 4, size=(GBK, ldb)).astype(np.int64)
     m0, n0 = 0, 256 if ldb >= 512 else 0
-    ref = A[:, m0:m0 + GBT].T @ B[:, n0:n0 + GBT]
+    ragged = M is not None
+    if ragged:
+        n0 = 0
+        assert M <= lda and N <= ldb and M % 8 == 0 and N % 8 == 0
+        # a poisoned element right behind each operand: a fetch past the last valid chunk of the LAST row would pick it up
+        A = np.concatenate([A.reshape(-1), np.full(4096, 10 ** 9, dtype=np.int64)])[:GBK * lda + 4096]
+        B = np.concatenate([B.reshape(-1), np.full(4096, 10 ** 9, dtype=np.int64)])[:GBK * ldb + 4096]
+        ref = np.zeros((GBT, GBT), dtype=np.int64)
+        ref[:M, :N] = A[:GBK * lda].reshape(GBK, lda)[:, :M].T @ B[:GBK * ldb].reshape(GBK, ldb)[:, :N]
+    else:
+        M, N = m0 + GBT, n0 + GBT
+        ref = A[:, m0:m0 + GBT].T @ B[:, n0:n0 + GBT]
     Ab, Bb = A.reshape(-1), B.reshape(-1)
     pitchA, pitchB = lda * 2, ldb * 2
     pa, pb = m0 * 2, n0 * 2
@@ -24,7 +37,8 @@ def run(lda=320, ldb=512, seed=0):
     for w in range(8):
         row = 2 * w + (lane >> 5)
         lc = (lane & 31) ^ ((row & 3) << 2)
-        aoff0, boff0 = row * pitchA + lc * 16, row * pitchB + lc * 16
+        aoff0 = row * pitchA + np.where(m0 + lc * 8 < M, lc, 0) * 16
+        boff0 = row * pitchB + np.where(n0 + lc * 8 < N, lc, 0) * 16
         for t in range(4):
             for (src0, base, flat) in ((pa + t * 16 * pitchA + aoff0, 0, Ab), (pb + t * 16 * pitchB + boff0, G_TILE, Bb)):
                 dst = base + (t * 8 + w) * 1024 + lane * 16
@@ -66,7 +80,8 @@ def run(lda=320, ldb=512, seed=0):
                     frow, fhalf = l & 31, l >> 5
                     for e in range(16):
                         m = (wm + 4 * i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf
-                        out[m, wn * 32 + frow + j * 64] += acc[i, j, l, e]
+                        if m0 + m < M and n0 + wn * 32 + frow + j * 64 < N:
+                            out[m, wn * 32 + frow + j * 64] += acc[i, j, l, e]
         # bf16 epilogue through the staging rows (272-byte pitch, 16-byte chunks)
         for i in range(2):
             stg = np.zeros(32 * 136, dtype=np.int64)
@@ -84,12 +99,13 @@ def run(lda=320, ldb=512, seed=0):
                     v = stg[(r * 272 + ch * 16) // 2:(r * 272 + ch * 16) // 2 + 8]
                     m = (wm + 4 * i) * 32 + r
                     n = (wn + 2 * j) * 32 + qq * 8
-                    stored[m, n:n + 8] += v
+                    if m0 + m < M and n0 + n < N:
+                        stored[m, n:n + 8] += v
     return int(np.abs(out - ref).max()), int(np.abs(stored - ref).max())
 
 
 if __name__ == "__main__":
-    for kw in (dict(), dict(lda=256, ldb=256, seed=1)):
+    for kw in (dict(), dict(lda=256, ldb=256, seed=1), dict(lda=128, ldb=136, seed=2, M=128, N=136), dict(lda=8, ldb=328, seed=3, M=8, N=256)):
         e = run(**kw)
         print(kw, "max |diff| fp32 / bf16 epilogue:", e)
         assert e == (0, 0)

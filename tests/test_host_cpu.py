@@ -527,6 +527,8 @@ def test_transpose_read_kernels_addressing_emulation():
     assert emulate_wgrad_tn.run(CA=256, CB=64, Wn=1, F=2, N=64, check_wgs=2) == (0, 2)
     assert emulate_wgrad_tn.run(CA=256, CB=128, Wn=1, F=1, N=64, flip=1, seed=4, check_wgs=1) == (0, 1)
     assert emulate_tn_gemm.run(lda=256, ldb=256, seed=2) == (0, 0)
+    # ragged output extents (tiles hanging over the edge: clamped column chunks in the DMA, masked stores in both epilogues)
+    assert emulate_tn_gemm.run(lda=136, ldb=8, seed=5, M=136, N=8) == (0, 0)
 
 
 def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
