@@ -1,4 +1,5 @@
 # round 4 (second session), call 13: 4-wave form of the query-block kernel (128-key chunks, two workgroups per CU) -- parity, stage times
+# (the 4-wave template this call measured was reverted afterwards -- slower; the script is kept as the record of the run)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
