@@ -1,0 +1,269 @@
+// 5x5 conv implicit GEMM (forward and data gradient), one wave per SIMD (gfx950, MI355X).
+//
+//   out[cell, co] = epilogue( sum over (df, dn, ci)  x[cell + (df, dn), ci] * W[co, (df, dn), ci] )
+//   (reference: ConvNet, src/model/ipa_pytorch_dynamic.py:664-706; the data gradient is the same product with the
+//    tap-flipped transposed weights)
+//
+// Same operands, descriptor and epilogues as the 256 x 320 "halo" kernel of gemm_bf16.hip; what changes is how much of
+// every byte that passes through the LDS is turned into matrix work (that kernel's K loop loses a
+// third of its matrix-core cycles to the issue cost of its LDS-DMA pieces and fragment reads):
+//
+//   * tile 512 (cells) x 160 (output channels), FOUR waves, each 128 x 160 = 4 x 5 MFMA 32x32x16 tiles: 9 fragment reads
+//     per 20 MFMAs (0.45 per MFMA; the 64 x 160 wave tile: 0.7).  The 320 accumulator registers of a wave are placed by
+//     hand: 16 tiles in the 256 AGPRs, 4 tiles in VGPRs (inline-assembly MFMAs with "a" / "v" register-class constraints;
+//     left to itself hipcc shuttles accumulators between the two files inside the K loop);
+//   * the M tile is TWO runs of 256 consecutive residues (two frame rows at N_res 256): the weight tile of a K step is
+//     shared by twice as many cells as in the 256-row tile -- 33.2 instead of 46.6 KB of LDS-DMA per 64 channels of a tap;
+//   * K steps of 32 channels: a (64-channel chunk, frame tap, channel half) GROUP stages the activations once as two
+//     272-row x 64-byte halo tiles which the five residue taps read shifted by one row each; weights [160][32] per step
+//     in a ring of three stages, prefetched two steps ahead with a counted s_waitcnt vmcnt.
+//
+// One wave per SIMD has no partner wave to cover its stalls, so the loop is software-pipelined across the barrier: a step
+// is [MFMAs of K16 block 0 | fragment reads of block 1] -- barrier -- [MFMAs of block 1 | reads of the NEXT tile's block 0],
+// the first instruction behind every barrier is an MFMA whose operands are already in registers.  LDS-DMA pieces and
+// fragment reads are inline assembly placed one per MFMA gap (the compiler neither reorders them nor sees them: waits
+// are written by hand).
+//
+// Accumulation order per output element: (chunk, df, half, dn, k).  The 256 x 320 kernel sums (chunk, df, dn, k): results
+// of the two kernels differ by fp32 summation order (bit-identical for one kernel across tile positions and launches).
+#include "gemm_engine.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#define W4_BM 512
+#define W4_BN 160
+#define W4_HROWS 272                          // rows of one run in a halo buffer: 17 LDS-DMA pieces of 16 rows x 64 B
+#define W4_HRUN_BYTES (W4_HROWS * 64)
+#define W4_HPIECES 34                         // pieces per halo buffer (2 runs)
+#define W4_HALO_BYTES (2 * W4_HRUN_BYTES)     // 34 KiB
+#define W4_BPIECES 10                         // pieces per weight tile: 160 rows x 64 B
+#define W4_BT_BYTES (W4_BN * 64)
+#define W4_NB 3
+#define W4_LDS_BYTES (2 * W4_HALO_BYTES + W4_NB * W4_BT_BYTES)   // 98 KiB
+
+typedef __attribute__((address_space(3))) char w4_lchar;
+
+__device__ __forceinline__ void w4_dma(const char* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+#define W4_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define W4_MFMA_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define W4_MFMA_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+__global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char wl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile id (bijective for any grid size); the n tiles of one m tile are consecutive ids = one XCD
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tiles_n = p.N / W4_BN;
+  const int m0 = (lid / tiles_n) * W4_BM, n0 = (lid % tiles_n) * W4_BN;
+  const int M = p.M;
+  const char* A = (const char*)p.A;
+  const char* B = (const char*)p.B;
+
+  // ---- K walk: groups (chunk c, frame tap df, channel half h), h fastest; five residue taps dn inside a group ----
+  const long a_s0 = p.a_seg_s0, a_s1 = p.a_seg_s1, b_s0 = p.b_seg_s0, b_s1 = p.b_seg_s1;
+  const long a_0 = p.a_seg0, b_0 = p.b_seg0;
+  const unsigned b_dn2 = (unsigned)(p.b_seg_s2 * 2);        // bytes from one residue tap of the weights to the next
+  const int ngroups = (p.nseg / 25) * 10;
+  auto grp_a = [&](int g) -> const char* {
+    g = g < ngroups - 1 ? g : ngroups - 1;
+    const unsigned h = (unsigned)g & 1u, t = (unsigned)g >> 1, c = t / 5u, df = t - 5u * c;
+    return A + (a_0 + (long)c * a_s0 + (long)df * a_s1 + (long)h * 32) * 2;
+  };
+  auto grp_b = [&](int g) -> const char* {
+    g = g < ngroups - 1 ? g : ngroups - 1;
+    const unsigned h = (unsigned)g & 1u, t = (unsigned)g >> 1, c = t / 5u, df = t - 5u * c;
+    return B + (b_0 + (long)c * b_s0 + (long)df * b_s1 + (long)h * 32) * 2;
+  };
+
+  // ---- LDS-DMA lane offsets.  A piece is 16 rows x 64 B (4 chunks of 16 B): lane l fills (row l >> 2, physical chunk l & 3)
+  // with the logical chunk (l & 3) ^ key(row), key(row) = (row >> 2) & 3 = (l >> 4) & 3 (every piece starts at a multiple of
+  // 16 rows).  Halo run r starts at the tap (0, 0) corner of GEMM row m0 + 256 r (a run past M repeats run 0: computed,
+  // never stored); rows 260 .. 271 of a run are padding (they re-read row 259 .. never read back).
+  const unsigned ld2 = (unsigned)(p.am.ld * 2);
+  const unsigned ldb2 = (unsigned)(p.ldb * 2);
+  const unsigned lch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  const unsigned hl_norm = (unsigned)(lane >> 2) * ld2 + lch;
+  const unsigned hl_last = (unsigned)((lane >> 2) < 3 ? (lane >> 2) : 3) * ld2 + lch;
+  const unsigned b_lane = (unsigned)(lane >> 2) * ldb2 + lch;
+  unsigned hrow[2];
+  hrow[0] = (unsigned)(row_off(p.am, m0) * 2);
+  hrow[1] = (unsigned)(row_off(p.am, m0 + 256 < M ? m0 + 256 : m0) * 2);
+  const char* Bn = B + (long)n0 * p.ldb * 2;      // (folded into grp_b below through this delta)
+  const long bn_delta = Bn - B;
+  const unsigned lds0 = (unsigned)(uintptr_t)(w4_lchar*)wl;
+  const unsigned lds_b = lds0 + 2 * W4_HALO_BYTES;
+
+  auto halo_piece = [&](const char* gbase, int q, unsigned hbuf) {        // piece q of a group's halo tile -> buffer at hbuf
+    const int r = q >= 17 ? 1 : 0, pr = q - 17 * r;
+    const char* src = gbase + hrow[r] + (unsigned)pr * 16u * ld2;
+    w4_dma(src, pr == 16 ? hl_last : hl_norm, hbuf + (unsigned)q * 1024u);
+  };
+  auto b_piece = [&](const char* tbase, int pp, unsigned stage) {           // piece pp of a weight tile
+    w4_dma(tbase + bn_delta + (unsigned)pp * 16u * ldb2, b_lane, stage + (unsigned)pp * 1024u);
+  };
+
+  // ---- fragment read addresses (LDS byte addresses, relative to the halo buffer / the weight stage).  MFMA A operand:
+  // lane -> (row lane & 31, k half lane >> 5); the wave's rows are run w >> 1, rows (w & 1) * 128 + i * 32 + frow + dn
+  const int frow = lane & 31, fhalf = lane >> 5;
+  unsigned a_lane[5][2], bf_lane[2];
+#pragma unroll
+  for (int dn = 0; dn < 5; ++dn)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = (w & 1) * 128 + frow + dn;
+      a_lane[dn][kb] = (unsigned)((w >> 1) * W4_HRUN_BYTES + row * 64 + (((kb * 2 + fhalf) ^ ((row >> 2) & 3)) << 4));
+    }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) bf_lane[kb] = (unsigned)(frow * 64 + (((kb * 2 + fhalf) ^ ((frow >> 2) & 3)) << 4));
+
+  f32x16 acc[2][2][5];        // [row pair][i][j]: rows w*128 + (2*pair + i)*32, columns j*32; j == 4 lives in VGPRs
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
+  bf16x8 fa[2][4], fb[2][5];   // [register set][fragment]
+
+  // one block of 20 MFMAs on register set S; `fill(k)` is called in the gap behind MFMA k (k = 0 .. 19)
+#define W4_BLOCK(S, FILL)                                                         \
+  _Pragma("unroll") for (int k_ = 0; k_ < 20; ++k_) {                              \
+    const int j_ = k_ >> 2, i_ = k_ & 3;                                          \
+    if (j_ < 4) W4_MFMA_A(acc[i_ >> 1][i_ & 1][j_], fa[S][i_], fb[S][j_]);        \
+    else W4_MFMA_V(acc[i_ >> 1][i_ & 1][j_], fa[S][i_], fb[S][j_]);               \
+    FILL(k_);                                                                     \
+  }
+  // the 9 fragment reads of one K16 block into register set S: read number k (0 .. 8)
+#define W4_FRAG(S, k, aaddr, baddr)                                 \
+  do {                                                             \
+    if ((k) == 0) W4_READ(fa[S][0], aaddr, 0);                      \
+    if ((k) == 1) W4_READ(fb[S][0], baddr, 0);                      \
+    if ((k) == 2) W4_READ(fa[S][1], aaddr, 2048);                   \
+    if ((k) == 3) W4_READ(fa[S][2], aaddr, 4096);                   \
+    if ((k) == 4) W4_READ(fa[S][3], aaddr, 6144);                   \
+    if ((k) == 5) W4_READ(fb[S][1], baddr, 2048);                   \
+    if ((k) == 6) W4_READ(fb[S][2], baddr, 4096);                   \
+    if ((k) == 7) W4_READ(fb[S][3], baddr, 6144);                   \
+    if ((k) == 8) W4_READ(fb[S][4], baddr, 8192);                   \
+  } while (0)
+
+  // ---- prologue: halo tile of group 0, weight tiles 0 .. 2 ----
+  const char* pa_n = grp_a(0);      // halo source of the group being prefetched
+  const char* pb_c = grp_b(0);      // weight base of the current group (dn = 0)
+  const char* pb_n = grp_b(1);      // ... of the next group
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int q = w + 4 * t;
+    if (q < W4_HPIECES) halo_piece(pa_n, q, lds0);
+  }
+#pragma unroll
+  for (int v = 0; v < 3; ++v)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int pp = w + 4 * t;
+      if (pp < W4_BPIECES) b_piece(pb_c + v * b_dn2, pp, lds_b + v * W4_BT_BYTES);
+    }
+  pa_n = grp_a(1);
+  unsigned hb_c = lds0, hb_n = lds0 + W4_HALO_BYTES;      // halo buffer of the current / the prefetched group
+  unsigned st_c = lds_b, st_1 = lds_b + W4_BT_BYTES, st_2 = lds_b + 2 * W4_BT_BYTES;   // stages of tiles u, u+1, u+2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  {
+    const unsigned aa = a_lane[0][0] + hb_c, ba = bf_lane[0] + st_c;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) W4_FRAG(0, k, aa, ba);
+  }
+
+  const int ngl = ngroups;
+  for (int g = 0; g < ngl; ++g) {
+    // one group = five K32 steps (residue taps), fully unrolled: DN is a compile-time constant of each step
+    auto step = [&](auto dnc) {
+      constexpr int DN = decltype(dnc)::value;
+      // ---- first half: MFMAs of K16 block 0 (set 0); reads of block 1 -> set 1; halo pieces of the next group ----
+      {
+        const unsigned aa = a_lane[DN][1] + hb_c, ba = bf_lane[1] + st_c;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int HB0 = DN == 0 ? 0 : DN == 1 ? 9 : DN == 2 ? 18 : DN == 3 ? 26 : 34;
+#define W4_FILL_Y(k)                                                              \
+        do {                                                                      \
+          if ((k) < 9) W4_FRAG(1, (k), aa, ba);                                   \
+          if (DN < 4 && ((k) == 10 || (k) == 13)) halo_piece(pa_n, HB0 + w + 4 * (((k) - 10) / 3), hb_n);  \
+          if (DN < 2 && (k) == 16) {          /* ninth piece of a 9-piece step: wave 0 */                  \
+            int wq = w;                                                           \
+            asm volatile("" : "+s"(wq));      /* (opaque: a hoisted predicate costs an SGPR pair per slot) */ \
+            if (wq == 0) halo_piece(pa_n, HB0 + 8, hb_n);                         \
+          }                                                                       \
+        } while (0)
+        W4_BLOCK(0, W4_FILL_Y)
+#undef W4_FILL_Y
+      }
+      // ---- tile u + 1 has landed (everything but this interval's own pieces: at least 4, or 2 without halo pieces);
+      // every wave is done reading tile u's stage and (DN == 4) the current halo buffer ----
+      if (DN < 4)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      // ---- second half: MFMAs of block 1 (set 1); reads of the next tile's block 0 -> set 0; weight tile u + 3 ----
+      {
+        constexpr int DN1 = DN == 4 ? 0 : DN + 1;
+        const unsigned aa = a_lane[DN1][0] + (DN == 4 ? hb_n : hb_c), ba = bf_lane[0] + st_1;
+        const char* tb = DN + 3 < 5 ? pb_c + (DN + 3) * b_dn2 : pb_n + (DN - 2) * b_dn2;
+        const int rot = (w + DN) & 3;
+#define W4_FILL_X(k)                                                              \
+        do {                                                                      \
+          if ((k) < 9) W4_FRAG(0, (k), aa, ba);                                   \
+          if ((k) == 10 || (k) == 13) b_piece(tb, rot + 4 * (((k) - 10) / 3), st_c);  \
+          if ((k) == 16) {                                                        \
+            int rq = rot;                                                         \
+            asm volatile("" : "+s"(rq));                                          \
+            if (rq < 2) b_piece(tb, rq + 8, st_c);                                \
+          }                                                                       \
+        } while (0)
+        W4_BLOCK(1, W4_FILL_X)
+#undef W4_FILL_X
+      }
+      // rotate the weight ring: tile u + 3 went into the stage tile u just left
+      const unsigned t0 = st_c;
+      st_c = st_1;
+      st_1 = st_2;
+      st_2 = t0;
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    // next group
+    const unsigned hb = hb_c;
+    hb_c = hb_n;
+    hb_n = hb;
+    pb_c = pb_n;
+    pb_n = grp_b(g + 2);
+    pa_n = grp_a(g + 2);
+  }
+#undef W4_BLOCK
+#undef W4_FRAG
+
+  // the surplus prefetches must have landed before the LDS is reused; MFMA results are read by VALU below
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  __syncthreads();
+  char* wave_lds = wl + w * (32 * EPI_ROWB(5) + 256);
+  gemm_epilogue_lds_bf16<5>(p, acc[0], (long)m0 + w * 128, n0, 0, lane, wave_lds);
+  gemm_epilogue_lds_bf16<5>(p, acc[1], (long)m0 + w * 128 + 64, n0, 0, lane, wave_lds);
+}
+
+// host side: called by dfold_gemm_bf16 for the conv launches that qualify (see there)
+int dfold_conv_w4_launch(const GemmParams& p, hipStream_t stream) {
+  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel, W4_LDS_BYTES);
+  const unsigned tiles = (unsigned)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
+  DFOLD_LAUNCH(dfold_conv_w4_kernel, dim3(tiles), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  return dfold_check_launch();
+}

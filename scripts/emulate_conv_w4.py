@@ -1,0 +1,205 @@
+"""Host emulation of the addressing and the pipeline of csrc/conv_fwd_w4.hip (no GPU needed).
+
+The kernel's LDS-DMA pieces, fragment reads, K walk, weight ring and halo double buffer are re-stated here formula by formula
+on TAGS instead of data: every 16-byte chunk that a DMA piece writes carries (operand, element offset of its 8 values), every
+fragment read checks that the chunk it finds is the one the MFMA operand needs for (row, k) of the implicit GEMM
+    C[m, n] = sum_k A[row(m) + tap/chunk offset + k] * B[n * ldb + tap/chunk offset + k].
+Timing model: the code between two s_barriers is an "interval"; a DMA piece issued in interval T is in flight until the barrier
+behind the first s_waitcnt vmcnt(K) of the issuing wave that covers it (loads retire in order) -- a read of its bytes in any
+interval in between is reported as a race, and so is a read that finds a later (or no) tenant.  Run: python scripts/emulate_conv_w4.py
+"""
+import sys
+
+HROWS, HRUN, HPIECES, BPIECES, BT = 272, 272 * 64, 34, 10, 160 * 64
+HALO = 2 * HRUN
+
+
+class Lds:
+    """bytes -> list of (issue interval, visible interval or None, tag) per 16-byte chunk"""
+
+    def __init__(self):
+        self.hist = {}
+
+    def write(self, addr, tag, rec):
+        assert addr % 16 == 0
+        self.hist.setdefault(addr, []).append([rec, tag])
+
+    def read(self, addr, now, what):
+        assert addr % 16 == 0, what
+        h = self.hist.get(addr)
+        assert h, f"read of never-written LDS chunk {addr} ({what})"
+        cur = None
+        for rec, tag in h:
+            t_issue, t_vis = rec["issue"], rec["visible"]
+            if t_issue <= now and (t_vis is None or now < t_vis):
+                raise AssertionError(f"race: {what} reads chunk {addr} at interval {now} while a piece issued in {t_issue} "
+                                     f"(visible {t_vis}) is in flight")
+            if t_vis is not None and t_vis <= now:
+                cur = tag
+        assert cur is not None, what
+        return cur
+
+
+def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
+    Wp, Fp = N + 4, F + 4
+    ld = CI                      # a_rows.ld
+    ldb = 25 * CI
+    M = W * F * N
+    a_s0, a_s1, a_s2 = 64, Wp * CI, CI
+    b_s0, b_s1, b_s2 = 64, 5 * CI, CI
+    nseg = 25 * (CI // 64)
+    ngroups = (nseg // 25) * 10
+    m0, n0 = m_tile * 512, n_tile * 160
+
+    def row_off(m):              # rows_in(): top-left corner of the 5x5 window of GEMM row m
+        wf, n = divmod(m, N)
+        w_, f = divmod(wf, F)
+        return ((w_ * Fp + f) * Wp + n) * ld
+
+    def grp(g, s0, s1):
+        g = min(g, ngroups - 1)
+        h, t = g & 1, g >> 1
+        c, df = divmod(t, 5)
+        return c * s0 + df * s1 + h * 32            # elements
+
+    lds = Lds()
+    lds0, lds_b = 0, 2 * HALO
+    hrow = [row_off(m0), row_off(m0 + 256 if m0 + 256 < M else m0)]
+    fifo = {w: [] for w in range(4)}                # per wave: issued pieces, oldest first
+    state = {"t": 0}                                # current interval
+
+    def dma(w, src_elem_of_lane, lds_addr, op):
+        rec = {"issue": state["t"], "visible": None}
+        for lane in range(64):
+            lds.write(lds_addr + 16 * lane, (op, src_elem_of_lane(lane)), rec)
+        fifo[w].append(rec)
+
+    def lch(lane):
+        return (lane & 3) ^ ((lane >> 4) & 3)
+
+    def halo_piece(w, gbase, q, hbuf):
+        r = 1 if q >= 17 else 0
+        pr = q - 17 * r
+        base = gbase + hrow[r] + pr * 16 * ld
+        if pr == 16:
+            dma(w, lambda l: base + min(l >> 2, 3) * ld + lch(l) * 8, hbuf + q * 1024, "A")
+        else:
+            dma(w, lambda l: base + (l >> 2) * ld + lch(l) * 8, hbuf + q * 1024, "A")
+
+    def b_piece(w, tbase, pp, stage):
+        base = tbase + n0 * ldb + pp * 16 * ldb
+        dma(w, lambda l: base + (l >> 2) * ldb + lch(l) * 8, stage + pp * 1024, "B")
+
+    def wait_vmcnt(w, k):
+        n = len(fifo[w]) - k
+        for rec in fifo[w][:max(n, 0)]:
+            rec["landed_for"] = True
+        done = fifo[w][:max(n, 0)]
+        fifo[w] = fifo[w][max(n, 0):]
+        return done
+
+    pending = []                                    # pieces waited for by their wave, visible after the next barrier
+
+    def barrier():
+        state["t"] += 1
+        for rec in pending:
+            rec["visible"] = state["t"]
+        pending.clear()
+
+    def a_lane(w, lane, dn, kb):
+        frow, fhalf = lane & 31, lane >> 5
+        row = (w & 1) * 128 + frow + dn
+        return (w >> 1) * HRUN + row * 64 + (((kb * 2 + fhalf) ^ ((row >> 2) & 3)) << 4)
+
+    def bf_lane(lane, kb):
+        frow, fhalf = lane & 31, lane >> 5
+        return frow * 64 + (((kb * 2 + fhalf) ^ ((frow >> 2) & 3)) << 4)
+
+    nchecked = [0]
+
+    def frag_reads(w, hbuf, stage, dn_addr, kb, tile_u):
+        """the nine reads of K16 block kb of tile u (its group / residue tap give the expected operands)"""
+        g, dn = divmod(tile_u, 5)
+        if g >= ngroups:
+            return                                   # reads behind the last tile: never consumed
+        assert dn == dn_addr
+        ka = grp(g, a_s0, a_s1) + dn * a_s2
+        kbo = grp(g, b_s0, b_s1) + dn * b_s2
+        for lane in range(64):
+            frow, fhalf = lane & 31, lane >> 5
+            k = (kb * 2 + fhalf) * 8
+            for i in range(4):
+                m = m0 + w * 128 + i * 32 + frow
+                mm = m if m < M else m - 256         # a run past M repeats run 0 (never stored)
+                want = ("A", row_off(mm) + ka + k)
+                got = lds.read(hbuf + a_lane(w, lane, dn, kb) + i * 2048, state["t"], f"A frag w{w} u{tile_u} kb{kb} i{i} lane{lane}")
+                assert got == want, (got, want, w, tile_u, kb, i, lane)
+            for j in range(5):
+                n = n0 + j * 32 + frow
+                want = ("B", n * ldb + kbo + k)
+                got = lds.read(stage + bf_lane(lane, kb) + j * 2048, state["t"], f"B frag w{w} u{tile_u} kb{kb} j{j} lane{lane}")
+                assert got == want, (got, want, w, tile_u, kb, j, lane)
+            nchecked[0] += 9
+
+    # ---------------- prologue ----------------
+    pa_n = {w: grp(0, a_s0, a_s1) for w in range(4)}
+    pb_c, pb_n = grp(0, b_s0, b_s1), grp(1, b_s0, b_s1)
+    for w in range(4):
+        for t in range(9):
+            q = w + 4 * t
+            if q < HPIECES:
+                halo_piece(w, pa_n[w], q, lds0)
+        for v in range(3):
+            for t in range(3):
+                pp = w + 4 * t
+                if pp < BPIECES:
+                    b_piece(w, pb_c + v * b_s2, pp, lds_b + v * BT)
+    pa_next = grp(1, a_s0, a_s1)
+    hb_c, hb_n = lds0, lds0 + HALO
+    st = [lds_b, lds_b + BT, lds_b + 2 * BT]          # stages of tiles u, u+1, u+2
+    for w in range(4):
+        pending.extend(wait_vmcnt(w, 0))
+    barrier()
+    for w in range(4):
+        frag_reads(w, hb_c, st[0], 0, 0, 0)
+
+    HB0 = [0, 9, 18, 26, 34]
+    u = 0
+    for g in range(ngroups):
+        for DN in range(5):
+            # first half: reads of block 1 of tile u, halo pieces of group g + 1
+            for w in range(4):
+                frag_reads(w, hb_c, st[0], DN, 1, u)
+                if DN < 4:
+                    for t in range(2):
+                        halo_piece(w, pa_next, HB0[DN] + w + 4 * t, hb_n)
+                if DN < 2 and w == 0:
+                    halo_piece(w, pa_next, HB0[DN] + 8, hb_n)
+            for w in range(4):
+                pending.extend(wait_vmcnt(w, 4 if DN < 4 else 2))
+            barrier()
+            # second half: reads of block 0 of tile u + 1, weight tile u + 3
+            DN1 = 0 if DN == 4 else DN + 1
+            for w in range(4):
+                frag_reads(w, hb_n if DN == 4 else hb_c, st[1], DN1, 0, u + 1)
+                tb = pb_c + (DN + 3) * b_s2 if DN + 3 < 5 else pb_n + (DN - 2) * b_s2
+                rot = (w + DN) & 3
+                for t in range(2):
+                    b_piece(w, tb, rot + 4 * t, st[0])
+                if rot < 2:
+                    b_piece(w, tb, rot + 8, st[0])
+            st = [st[1], st[2], st[0]]
+            u += 1
+        hb_c, hb_n = hb_n, hb_c
+        pb_c, pb_n = pb_n, grp(g + 2, b_s0, b_s1)
+        pa_next = grp(g + 2, a_s0, a_s1)
+    if verbose:
+        print(f"conv_w4 emulation: CI {CI}, N {N}, F {F}, tile ({m_tile}, {n_tile}): {u} steps, {nchecked[0]} fragment reads checked")
+    return nchecked[0]
+
+
+if __name__ == "__main__":
+    run(verbose=True)
+    run(CI=192, F=3, m_tile=1, n_tile=0, verbose=True)       # odd number of 256-row runs: the last tile's second run repeats run 0
+    run(CI=64, N=512, F=1, W=2, m_tile=1, verbose=True)       # one frame row = one 512-row tile
+    print("ok")

@@ -327,6 +327,58 @@ def test_conv_splitk_matches_unsplit(dev):
         assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
 
 
+def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
+    """csrc/conv_fwd_w4.hip (512 x 160 tile, one wave per SIMD, 32-channel halo groups): unsplit conv launches whose tiles are
+    runs of 256 consecutive residues.  Whole outputs against fp64 conv2d on the same bf16 operands for every epilogue of the
+    tower (bias + ReLU; + residual with the pre-residual copy; ReLU mask; residual + masked second output), an ODD number of
+    256-row runs (the last tile's second run repeats its first and stores nothing), a frame sub-range launch, N_res 512
+    (one frame row = one tile) and bit reproducibility."""
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib, ops
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    for (Wn, F, N, CI, CO) in ((11, 7, 256, 128, 1280), (3, 11, 512, 64, 1280), (16, 4, 256, 192, 640)):
+        g = ops.Grid(Wn, F, N, dev)
+        w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+        wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+        bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+        xs = torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16)
+        rs = torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16)
+        r2s = torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16)
+        x, r, r2 = g.alloc(CI), g.alloc(CO), g.alloc(CO)
+        g.interior(x).copy_(xs); g.interior(r).copy_(rs); g.interior(r2).copy_(r2s)
+        lin = torch.nn.functional.conv2d(xs.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), None, padding=2).permute(0, 2, 3, 1)
+        rd, r2d = rs.double(), r2s.double()
+        bf = lambda t: t.to(torch.bfloat16).double()      # the engine rounds the pre-residual value to bf16
+        # (a) bias + ReLU
+        o = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, o, relu=True)
+        assert rel_l2(g.interior(o), (lin + bias.double()).clamp_min(0)) < 4e-3, (N, CI, CO, "relu")
+        assert float(o[:, :2].abs().max()) == 0 and float(o[:, :, -2:].abs().max()) == 0 and float(o[:, -2:].abs().max()) == 0
+        o_again = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, o_again, relu=True)
+        assert torch.equal(o, o_again)
+        # (b) bias + ReLU, pre-residual copy, + residual
+        o, c2 = g.alloc(CO), g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, o, relu=True, resid=r, pre_resid_out=c2)
+        pre = (lin + bias.double()).clamp_min(0)
+        assert rel_l2(g.interior(c2), pre) < 4e-3 and rel_l2(g.interior(o), bf(pre) + rd) < 4e-3, (N, CI, CO, "resid")
+        # (c) ReLU mask of another tensor (the data-gradient epilogue)
+        o = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, None, o, relu=False, relu_mask=r)
+        assert rel_l2(g.interior(o), lin * (rd > 0)) < 4e-3, (N, CI, CO, "mask")
+        # (d) residual, second output masked by R2
+        o, c2 = g.alloc(CO), g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, None, o, relu=False, resid=r, C2=c2, R2=r2)
+        assert rel_l2(g.interior(o), bf(lin) + rd) < 4e-3 and rel_l2(g.interior(c2), (bf(lin) + rd) * (r2d > 0)) < 4e-3, (N, CI, CO, "c2")
+        # (e) frame sub-range (3 frames: an odd number of runs at N_res 256), rows outside untouched
+        o = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, o, relu=True, f_lo=F - 3, nf=3)
+        assert rel_l2(g.interior(o)[:, F - 3:], (lin + bias.double()).clamp_min(0)[:, F - 3:]) < 4e-3
+        assert float(o[:, : 2 + F - 3].abs().max()) == 0
+
+
 def test_convnet_vs_oracle_golden(dev):
     """ConvNet on the reference-minted capture (F=3, N=16, C=1280; tests/golden/network_F3_N16.npz)."""
     from dynamicpdb_amd import ops, synthetic
