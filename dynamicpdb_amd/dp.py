@@ -121,6 +121,9 @@ class GradReducer:
             static_graph = os.environ.get("DFOLD_DP_STATIC_GRAPH", "0") == "1"
         self.static_graph = bool(static_graph)
         self._clean_steps = 0
+        self._missing, self._was_discovery = [], False
+        self.static_check_every = int(os.environ.get("DFOLD_DP_STATIC_CHECK_EVERY", "64"))
+        self._steps_since_check = 0
 
     # ---------------------------------------------------------------- wiring
     def attach(self, model=None):
@@ -291,13 +294,15 @@ class GradReducer:
         if self.timing and torch.cuda.is_available() and self.params and self.params[0].is_cuda:
             self._bwd_end_ev = torch.cuda.Event(enable_timing=True)
             self._bwd_end_ev.record()             # the compute stream has reached the end of backward
-        if self.flat is None:
+        discovery = self.flat is None
+        if discovery:
             self._build()
             for b in range(len(self.buckets)):
                 self._launch(b)
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        self._missing = [b for b in range(len(self.buckets)) if not self._launched[b]]   # buckets whose gradients did not all arrive
+        for b in self._missing:
+            self._launch(b)
+        self._was_discovery = discovery
         dev = self.flat.device
         if self.timing and dev.type == "cuda":
             ev0 = torch.cuda.Event(enable_timing=True)
@@ -324,12 +329,19 @@ class GradReducer:
         """one small collective per step: flags [late parameter i ...| stray parameter i ...], MAX over ranks.  late: this
         rank's late accumulations {parameter index: tensor}"""
         n = len(self.params)
-        if self.static_graph and self._clean_steps >= 2:
-            if self._late or self._stray:
+        self._steps_since_check += 1
+        if self.static_graph and self._clean_steps >= 2 and self._steps_since_check < self.static_check_every:
+            # a MISSING gradient (a parameter of a bucket that received fewer accumulations than discovered: its bucket was
+            # only launched by finish()) is as much a graph change as an extra one -- its zeros would be averaged in silently
+            if self._late or self._stray or self._missing:
                 raise RuntimeError("GradReducer(static_graph=True): the autograd graph of this rank changed (late accumulations of "
-                                   f"parameters {sorted(self._late)}, stray gradients of {sorted(self._stray)}); run without "
-                                   "static_graph to have such steps repaired collectively")
+                                   f"parameters {sorted(self._late)}, stray gradients of {sorted(self._stray)}, buckets with "
+                                   f"missing gradients {self._missing}); run without static_graph to have such steps repaired "
+                                   "collectively.  The other ranks are NOT notified: they block in their next collective until "
+                                   "the process group's timeout (init_process_group(timeout=...)) ends them")
             return                                # no collective, no host wait: the stream waits, the host runs ahead
+        self._steps_since_check = 0               # (static mode: one flag collective every `static_check_every` steps catches a
+                                                  #  divergence that only another rank can see)
         flags = torch.zeros(2 * n, dtype=torch.int32)
         for i in self._late:
             flags[i] = 1
@@ -341,7 +353,11 @@ class GradReducer:
             dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
             flags = f.cpu()
         if not bool(flags.any()):
-            self._clean_steps += 1
+            # two clean steps in the STEADY state arm the static mode: the discovery step (one blocking reduction of
+            # everything) verifies nothing about the hook-driven path, and a step that needed finish() to launch a bucket
+            # is not clean either
+            if not getattr(self, "_was_discovery", False) and not self._missing:
+                self._clean_steps += 1
             return
         self._clean_steps = 0
         for i in torch.nonzero(flags[:n]).flatten().tolist():

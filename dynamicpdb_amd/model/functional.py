@@ -691,8 +691,13 @@ class IpaFeatFn(Function):
         return tuple(grads) + (dt7, None)
 
 
-def ipa_feat_direct_ok(N, C, q_pts, v_pts):
-    return os.environ.get("DFOLD_IPA_FEAT_DIRECT", "1") != "0" and _ipa_fused_ok(N, C, q_pts, v_pts)
+def ipa_feat_direct_ok(N, C, q_pts, v_pts, H=None, PZ=None):
+    """the FULL predicate of IpaCoreFn.forward's direct-write path: with H / PZ given, also the row width of the feature
+    matrix as a multiple of the pair-value width (the cell trick of its grid row map) -- a model width outside it takes the
+    IpaCoreFn + IpaOutFeatFn + cat path instead of raising inside IpaFeatFn"""
+    if os.environ.get("DFOLD_IPA_FEAT_DIRECT", "1") == "0" or not _ipa_fused_ok(N, C, q_pts, v_pts):
+        return False
+    return H is None or PZ is None or (H * C + 768 + H * PZ) % PZ == 0
 
 
 # ------------------------------------------------------------------------------------------------

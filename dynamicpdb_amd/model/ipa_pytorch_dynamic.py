@@ -190,7 +190,7 @@ class InvariantPointAttention(nn.Module):
         kvp = F_.linear(s, self.linear_kv_points.weight, self.linear_kv_points.bias, out_fp32=True)
         q_pts, k_pts, v_pts = F_.IpaPointsFn.apply(qp, kvp, t7)                       # global frame (:363-390)
         hw = Fn.softplus(self.head_weights) * math.sqrt(1.0 / (3 * (PQ * 9.0 / 2)))
-        if F_.ipa_feat_direct_ok(N, self.c_hidden, q_pts, v_pts):
+        if F_.ipa_feat_direct_ok(N, self.c_hidden, q_pts, v_pts, self.no_heads, self.down_z.weight.shape[0]):
             # one node: attention core + output features, every block written straight into the operand of linear_out
             return F_.IpaFeatFn.apply(q, kv, q_pts, k_pts, v_pts, z, self.linear_b.weight, self.down_z.weight, self.down_z.bias,
                                       mask, hw, t7, self.eps)                             # :396-504

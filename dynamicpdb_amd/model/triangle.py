@@ -217,7 +217,10 @@ def _recompute_grads(fn, x, mask, dout, head_args, params, transpose=False):
             xb, mb = xb.transpose(1, 2), mb.transpose(1, 2)
         if N8 != N:
             xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
-            mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
+            # pad KEYS carry a mask of -1e20: their bias inf * (mask - 1) is then ~ -1e29, finite but far below a real masked
+            # key's -inf, so that a fully masked real row (padding residues of a batch) spreads its softmax over its N real
+            # keys like the forward kernels and the reference do, not over N8; pad ROWS are never read back
+            mb = Fn_.pad(Fn_.pad(mb, (0, N8 - N), value=-1e20), (0, 0, 0, N8 - N))
         y = fn.apply(xb.contiguous(), mb.contiguous(), *head_args, *ps)[:, :N, :N]
         if transpose:
             y = y.transpose(1, 2)
@@ -525,9 +528,10 @@ def _triatt_stream_backward(x, mask, dout, inf, params):
          sb=(NN * cin, 0), sc=(H * NN, 0))
     dob = dout.reshape(R, cin)
     dob = dob.contiguous() if dob.dtype == BF16 else ops.cast_bf16(dob.float())
-    # the same projections channel-major ([512][R]: the GEMM with swapped operands) -- the K^T / V^T / Q^T tiles of the kernels
-    projT = torch.empty((4 * HC, R), dtype=BF16, device=dev)
-    gemm(wcat, xn, projT, 4 * HC, R, cin, a_rows=rows_plain(cin), c_rows=rows_plain(R), ldb=cin)
+    # the q | k | v projections once more, channel-major ([384][R]: the K^T / V^T / Q^T tiles of the kernels; the gate rows are
+    # never read there) -- a transpose of `proj`, so that the two layouts hold the SAME bf16 values (as a second GEMM with
+    # swapped operands they could differ by an ulp inside one kernel, and its gate rows were 25 % wasted work: ADVICE r4)
+    projT = ops.transpose_bf16(proj, R, 3 * HC, ld_src=4 * HC)
     KB = (N + 63) // 64 if N <= 256 else (N + 31) // 32         # key blocks of the second kernel (csrc/triatt_bwd.hip)
     IC = max(1, min(16, N, 512 // (B * H * KB)))
     dproj = torch.empty((R, 4 * HC), dtype=BF16, device=dev)
@@ -635,7 +639,10 @@ class TriAttFusedFn(Function):
             xb, mb, db = xb.transpose(1, 2), mb.transpose(1, 2), db.transpose(1, 2)
         if N8 != N:
             xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
-            mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
+            # pad KEYS carry a mask of -1e20: their bias inf * (mask - 1) is then ~ -1e29, finite but far below a real masked
+            # key's -inf, so that a fully masked real row (padding residues of a batch) spreads its softmax over its N real
+            # keys like the forward kernels and the reference do, not over N8; pad ROWS are never read back
+            mb = Fn_.pad(Fn_.pad(mb, (0, N8 - N), value=-1e20), (0, 0, 0, N8 - N))
             db = Fn_.pad(db, (0, 0, 0, N8 - N, 0, N8 - N))
         g = _triatt_stream_backward(xb.contiguous(), mb.contiguous(), db.contiguous(), ctx.inf, [p.detach() for p in params])
         dx = g[0][:, :N, :N]

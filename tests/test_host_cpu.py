@@ -194,6 +194,8 @@ class _Toy(torch.nn.Module):
         y = self.out(torch.tanh(self.big(h)))
         if batch.get("use_dead"):          # a step whose graph differs from the discovered one (on ONE rank only)
             y = y + self.dead(batch["x"][:, :4]).sum(-1, keepdim=True)
+        if batch.get("skip_big"):          # ... or misses gradients the discovered one had
+            y = self.out(torch.zeros(h.shape[0], 300)) + h.sum(-1, keepdim=True)
         return y
 
 
@@ -297,7 +299,19 @@ def _dp_worker(rank, world, port, q):
             tr3.update_fn({"x": xs[rank], "use_dead": True}, step_optimizer=False)
         except RuntimeError as e:
             raised = "static_graph" in str(e)
-        static_ok = static_err < 1e-5 and n_coll[:2] == [1, 1] and n_coll[-2:] == [0, 0] and raised
+        # a MISSING gradient raises too (its zeros would otherwise be averaged in silently); the discovery step does not count as
+        # one of the two clean steps (collectives per step: 1, 1, 1, 0, 0)
+        m4 = copy.deepcopy(ref)
+        tr4 = experiment.Trainer(m4, lr=1e-2, bucket_bytes=1024, last_frame_only=False)
+        tr4.reducer.static_graph = True
+        for step in range(4):
+            tr4.update_fn({"x": xs[rank]}, step_optimizer=False)
+        raised_missing = False
+        try:
+            tr4.update_fn({"x": xs[rank], "skip_big": True}, step_optimizer=False)
+        except RuntimeError as e:
+            raised_missing = "missing gradients" in str(e)
+        static_ok = static_err < 1e-5 and n_coll == [1, 1, 1, 0, 0] and raised and raised_missing
         info = dict(late_ok=late_ok, bf16_ok=bf16_ok, static_ok=static_ok, n_coll=n_coll, static_err=static_err, bf16_err=bf16_err, n_buckets=len(red.buckets), views=all(p.grad is None or p.grad.untyped_storage().data_ptr() ==
                                                           red.flat.untyped_storage().data_ptr() for p in model.parameters()),
                     expected_shared=red._expected[id(model.shared.weight)], rediscoveries=red.rediscoveries,
@@ -468,6 +482,34 @@ def test_checkpoint_loader_executes_nothing_from_the_file(tmp_path, monkeypatch)
     with pytest.warns(UserWarning, match="UNRESTRICTED"):
         checkpoint.read_checkpoint(str(bad), allow_pickle=True)          # explicit opt-in: now it does run
     assert marker.exists()
+    # protocol-4 dotted names (attribute walks below an allow-listed module) and capitalised non-classes are refused too:
+    # STACK_GLOBAL('omegaconf._utils', 'Marker.__init__.__globals__.get') would hand out the module's globals().get
+    import io
+    import pickle
+    import sys
+    import types
+    pkg, util = types.ModuleType("omegaconf"), types.ModuleType("omegaconf._utils")
+
+    class Marker:
+        def __init__(self, desc=""):
+            self.desc = desc
+    util.Marker, util.Factory, pkg._utils = Marker, (lambda *a: marker.write_text("x")), util
+    monkeypatch.setitem(sys.modules, "omegaconf", pkg)
+    monkeypatch.setitem(sys.modules, "omegaconf._utils", util)
+
+    def gadget(mod, name, *args):      # PROTO 4, STACK_GLOBAL mod.name, REDUCE(args), STOP
+        enc = lambda t: b"\x8c" + bytes([len(t)]) + t.encode()
+        body = b"\x80\x04" + enc(mod) + enc(name) + b"\x93"
+        if args:
+            body += b"".join(enc(a) for a in args) + (b"\x85" if len(args) == 1 else b"\x86") + b"R"
+        return body + b"."
+    marker.unlink()
+    for name in ("Marker.__init__.__globals__.get", "Factory", "Marker"):
+        with pytest.raises(pickle.UnpicklingError, match="allow-list|not a class"):
+            checkpoint._AllowListedPickle.load(io.BytesIO(gadget("omegaconf._utils", name, "os")))
+    assert not marker.exists()
+    util.DictConfig = type("DictConfig", (dict,), {})
+    assert checkpoint._AllowListedPickle.load(io.BytesIO(gadget("omegaconf._utils", "DictConfig"))) is util.DictConfig
 
 
 def test_geoformer_dropins_keep_the_reference_parameter_layout():
