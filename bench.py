@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
     ap.add_argument("--no-triangle", action="store_true", help="skip the triangle-operator extra object")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 5 extra objects")
+    ap.add_argument("--no-eval-config", action="store_true", help="skip the config 1 (eval / sampling) extra object")
     ap.add_argument("--same-batch", action="store_true", help="feed one batch to every step (profiling aid; default: a "
                     "fresh synthetic batch per step, generated on the device and staged in HBM before the timed region)")
     ap.add_argument("--mode", choices=("all_frames", "last_frame"), default="all_frames",
@@ -244,6 +245,114 @@ def cpu_baseline(F, N, seed_w=0):
             "reference_probe": {"value": 0.43, "unit": "frames/s", "cores": 8, "shape": "1 window, 2 frames x N_res=256, fwd+bwd",
                                 "source": "the reference's own code (FullScoreNetwork fwd+bwd) timed in the build container, "
                                           "SURVEY.md section 6 [probe]; the reference does not exist on the GPU box"}}
+
+
+def config1_eval(dev, tlog, cpu=True):
+    """Extra object: BASELINE config 1 is the reference's EVAL configuration (run_eval.sh:4-17, eval_DFOLD_dynamics.py:59-204 ->
+    Experiment.inference_fn, train_DFOLD_dynamics.py:1425-1547): one 16-frame window at N_res 96, num_t = 10, noise_scale 0.1.
+    GPU: the device-resident sampler (10 model forwards + the self-conditioning pass + 9 reverse steps as one HIP launch each)
+    with device Philox draws and with host-injected numpy draws.  CPU: the oracle's restatement of ONE reverse iteration of the
+    reference's loop (model forward on host cores + the host reverse step: quaternion -> rotation vector through scipy,
+    so3 / r3 Euler-Maruyama updates, back to quaternions), which the reference repeats num_t times with four host round trips
+    each (se3_diffuser.py:160-215, rigid_utils.py:208-227)."""
+    import numpy as np
+    from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    from dynamicpdb_amd.rng import DeviceRNG
+    F, N, num_t, noise = 16, 96, 10, 0.1
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    sd = synthetic.seeded_state_dict(31)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev)
+    w = synthetic.synthetic_window(32, F, N, t=1.0, diffuser=None)
+    np.random.seed(90)
+    prior = diffuser.sample_ref(n_samples=F * N, as_tensor_7=True)["rigids_t"].reshape(F, N, 7).float()
+    init = {k: v.to(dev) for k, v in w.items()}
+    init["rigids_t"] = prior.to(dev)
+    kw = dict(num_t=num_t, min_t=0.01, center=True, aux_traj=False, self_condition=True, noise_scale=noise)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    ms_dev = timed(lambda: experiment.inference_fn(model, diffuser, init, rng=DeviceRNG(seed=5, device=dev), **kw))
+    np.random.seed(91)
+    ms_inj = timed(lambda: experiment.inference_fn(model, diffuser, init, **kw))       # numpy draws, copied to the device per step
+    with torch.no_grad():
+        feats = experiment.set_t_feats(diffuser, dict(init), 0.5, torch.ones(1, device=dev))
+        feats["sc_ca_t"] = init["rigids_t"][..., 4:].clone()
+        ms_fwd = timed(lambda: model(dict(feats)), reps=5)
+        out = model(dict(feats))
+        rng = DeviceRNG(seed=6, device=dev)
+        ms_rev = timed(lambda: diffuser.reverse_t7(feats["rigids_t"], out["rot_score"], out["trans_score"], 0.5, 1.0 / num_t,
+                                                   diffuse_mask=torch.ones(F, N, device=dev), center=True, noise_scale=noise, rng=rng),
+                       reps=20)
+    tlog(f"config 1 eval: {ms_dev:.1f} ms per sample (device draws), {ms_inj:.1f} ms (numpy draws), forward {ms_fwd:.2f} ms, "
+         f"reverse step {ms_rev:.3f} ms")
+    res = {"workload": "BASELINE config 1 (the reference's eval configuration): 1 window, 16 frames x N_res 96, inference_fn with "
+                       "num_t = 10, noise_scale 0.1, self-conditioning pass; random-init seeded weights, synthetic window",
+           "ms_per_sample_device_rng": round(ms_dev, 2), "ms_per_sample_numpy_draws": round(ms_inj, 2),
+           "ms_per_model_forward": round(ms_fwd, 3), "ms_per_reverse_step_kernel": round(ms_rev, 4),
+           "frames_per_s_sampled": round(F / (ms_dev * 1e-3), 1), "model_forwards_per_sample": num_t + 1, "reverse_steps_per_sample": num_t - 1}
+    del model
+    torch.cuda.empty_cache()
+    if cpu:
+        from scipy.spatial.transform import Rotation
+        from oracle import dfold_oracle as O
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        smt = 1
+        try:
+            with open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list") as fh:
+                smt = max(1, len(fh.read().strip().replace("-", ",").split(",")))
+        except OSError:
+            pass
+        threads = max(1, cores // smt)
+        torch.set_num_threads(threads)
+        P, sched = {k: v.clone() for k, v in sd.items()}, O.Schedules()
+        wc = dict(w)
+        wc["rigids_t"] = prior.clone()
+        rs, ts = diffuser.score_scaling(0.5)
+        wc["t"] = torch.tensor([0.5])
+        wc["rot_score_scaling"], wc["trans_score_scaling"] = torch.tensor([float(rs)]), torch.tensor([float(ts)])
+        wc["sc_ca_t"] = prior[..., 4:].clone()
+
+        def one():
+            t0 = time.time()
+            with torch.no_grad():
+                o = O.full_score_network(P, sched, wc)
+            rt = wc["rigids_t"].double().numpy()
+            q = rt[..., :4]
+            rotvec = Rotation.from_quat(q.reshape(-1, 4)[:, [1, 2, 3, 0]]).as_rotvec().reshape(q.shape[:-1] + (3,))
+            zr, zt = np.random.normal(size=(F, N, 3)), np.random.normal(size=(F, N, 3))
+            rv1 = O.so3_reverse(sched, rotvec, o["rot_score"].double().numpy(), 0.5, 1.0 / num_t, noise * zr)
+            x1 = O.r3_reverse(sched, rt[..., 4:], o["trans_score"].double().numpy(), 0.5, 1.0 / num_t, noise * zt)
+            qn = Rotation.from_rotvec(rv1.reshape(-1, 3)).as_quat()[:, [3, 0, 1, 2]].reshape(F, N, 4)
+            wc["rigids_t"] = torch.tensor(np.concatenate([qn, x1], -1), dtype=torch.float32)
+            return time.time() - t0
+
+        warm = one()
+        timed_s = [one() for _ in range(2)]
+        per = sum(timed_s) / len(timed_s)
+        tlog(f"config 1 eval, CPU oracle: warm-up {warm:.2f} s, timed {timed_s[0]:.2f} s, {timed_s[1]:.2f} s per reverse iteration ({threads} threads)")
+        res["cpu_baseline"] = {"value": round(per * 1e3, 1), "unit": "ms per reverse iteration (model forward + host reverse step)",
+                               "cores": threads, "kind": "port",
+                               "sample": f"oracle forward (the reference's aten ops: F.conv2d, F.linear, broadcast point distances) + scipy / "
+                                         f"numpy reverse step, mean of 2 timed iterations ({timed_s[0]:.2f} s, {timed_s[1]:.2f} s) after a "
+                                         f"warm-up; a full sample = {num_t + 1} forwards + {num_t - 1} reverse steps",
+                               "ms_per_sample_extrapolated": round(per * 1e3 * (num_t + 1), 0)}
+        res["speedup_vs_cpu_per_sample"] = round(per * 1e3 * (num_t + 1) / ms_dev, 1)
+    return res
 
 
 def respawn(args):
@@ -483,6 +592,8 @@ def main():
             line["config5_one_gpu"] = other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog)
         if not args.no_triangle:
             line["triangle"] = triangle_roofline(dev)
+        if not args.no_eval_config:
+            line["config1_eval"] = config1_eval(dev, tlog, cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
     if rank == 0:

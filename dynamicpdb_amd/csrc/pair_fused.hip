@@ -77,8 +77,9 @@ struct PairProjParams {
 
 // MODE 0: triangle multiplication (o0 = planes [B][N][256][NP], o1 = gate [B][N][N][128], f0 = LN stats or null)
 // MODE 1: triangle attention      (o0 = q, o1 = k, o3 = gate: [B][N][N][128]; o2 = vT [B][N][128][NP]; f0 = tri [B][4][N][NP])
-#define PP_LDS0 (2 * 16384 + 512 + 256 * PP_SPITCH + 64 * PP_GPITCH)
-#define PP_LDS1 (2 * 16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 2048)
+#define PP_STAGE0 (256 * PP_SPITCH + 64 * PP_GPITCH)
+#define PP_LDS0 (2 * 16384 + 512 + 2 * PP_STAGE0 + 1024)      // (+ 1 KB: LayerNorm gamma | beta)
+#define PP_LDS1 (2 * 16384 + 3 * 64 * PP_GPITCH + 128 * PP_SPITCH + 2048 + 1024)
 
 // sum over the 16 lanes of a DPP row (all 16 lanes receive it): quad butterflies + two row rotations, 4 VALU ops
 __device__ __forceinline__ float row16_sum(float v) {
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   char* const ldsA2 = smem;                        // two A tiles (tile parity)
   // MODE 0
   float* const ldsM2 = (float*)(smem + 32768);     // two mask rows
-  char* const ldsS = smem + 32768 + 512;
-  char* const ldsG0 = ldsS + 256 * PP_SPITCH;
+  char* const ldsS2 = smem + 32768 + 512;                       // two staging areas (tile parity): planes + gate
   // MODE 1
   char* const ldsQ = smem + 32768;
   char* const ldsK = ldsQ + 64 * PP_GPITCH;
@@ -121,11 +121,16 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   }
   // LayerNorm layout: 16 lanes per cell (lane l15 holds channels 8*l15 .. +8), four cells per pass (row l4 of the quad):
   // the two reductions of a cell are 4 DPP steps each and serve four cells at once
-  float gam[8], bet[8], wt[4][8];
+  // (gamma / beta of the LayerNorm sit in LDS and are re-read per tile: 16 registers that the pipelined MFMA phase needs)
+  float* const ldsGB = (float*)(smem + (MODE == 0 ? PP_LDS0 : PP_LDS1) - 1024);
+  if (tid < 128) {
+    ldsGB[tid] = p.gamma[tid];
+    ldsGB[128 + tid] = p.beta[tid];
+  }
+  __syncthreads();
+  float wt[4][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    gam[i] = p.gamma[l15 * 8 + i];
-    bet[i] = p.beta[l15 * 8 + i];
 #pragma unroll
     for (int h = 0; h < 4; ++h) wt[h][i] = MODE == 1 ? p.wtri[h * 128 + l15 * 8 + i] * 1.44269504088896341f : 0.f;   // bias consumed in the log2 domain
   }
@@ -188,18 +193,30 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   auto stream_out = [&](int b, int line, int pt, int par) __attribute__((always_inline)) {
     const int pos0 = pt * PP_TILE;
     if (MODE == 0) {
+      const char* const ldsS = ldsS2 + par * PP_STAGE0;
+      const char* const ldsG0 = ldsS + 256 * PP_SPITCH;
       char* const pbase = (char*)p.o0 + ((((long)b * N + line) * 256) * NP + pos0) * 2;          // wave-uniform
+      // all six staged vectors first, then the six stores (as read - wait - store per vector hipcc serialised six LDS round trips)
+      u32x4 sv[6];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int id = tid + 512 * i, pl = id >> 3, v = id & 7;
-        *(uint4*)(pbase + voff_pl[i]) = *(const uint4*)(ldsS + pl * PP_SPITCH + v * 16);
+        sv[i] = *(const u32x4*)(ldsS + pl * PP_SPITCH + v * 16);
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
+        sv[4 + i] = *(const u32x4*)(ldsG0 + cr * PP_GPITCH + v * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(u32x4*)(pbase + voff_pl[i]) = sv[i];
       const long cell0 = p.swap ? ((long)b * N + pos0) * N + line : ((long)b * N + line) * N + pos0;
       char* const gbase = (char*)p.o1 + cell0 * 256;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int id = tid + 512 * i, cr = id >> 4, v = id & 15;
-        if (pos0 + cr < N) *(uint4*)(gbase + voff_cl[i]) = *(const uint4*)(ldsG0 + cr * PP_GPITCH + v * 16);
+        const int id = tid + 512 * i, cr = id >> 4;
+        if (pos0 + cr < N) *(u32x4*)(gbase + voff_cl[i]) = sv[4 + i];
       }
     } else {
       const long cell0 = ((long)b * N + line) * N + pos0;
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
       }
       const float rstd = rsqrtf(row16_sum(q2) * (1.f / 128.f) + p.eps);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i] * rstd, gam[i], bet[i]);
+      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i] * rstd, ldsGB[l15 * 8 + i], ldsGB[128 + l15 * 8 + i]);
       *(uint4*)(ldsA + a_tile_off(row, l15)) =
           make_uint4(pack2bf_hw(x[0], x[1]), pack2bf_hw(x[2], x[3]), pack2bf_hw(x[4], x[5]), pack2bf_hw(x[6], x[7]));
       if (MODE == 1) {
@@ -299,45 +316,71 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     //  copies sat HERE, in front of the MFMA phase: the prefetch never overlapped anything)
     issue(t + gridDim.x < ntiles ? t + gridDim.x : t, zr, mk);
     if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
-    __syncthreads();
+    // MODE 0: the staging area alternates with the tile parity, so this tile's results go where tile t - 2's were read from
+    // before every wave's barrier above -- no second barrier per tile
+    if (MODE == 1) __syncthreads();
+    char* const ldsS = ldsS2 + par * PP_STAGE0;
+    char* const ldsG0 = ldsS + 256 * PP_SPITCH;
 
     // ---- S2: projections on MFMA 16x16x32, gates, staging ----
+    // Software-pipelined over the four 16-cell row tiles: the 20 MFMAs of row tile rt + 1 are issued BETWEEN the gate
+    // arithmetic of row tile rt (sched_group_barrier: 1 MFMA per few VALU).  Written as [all MFMAs of rt][all gates of rt] the
+    // two waves of a SIMD ran the same phase at the same time -- matrix pipe and VALU took turns instead of overlapping
+    // (hipcc -S: ~20 MFMAs, then ~100 VALU, four times).  The bias enters as the accumulator init of the first K step.
+    // fragments of a row tile (four K steps), one K step of its products, the gate arithmetic of ONE of its four cell rows
+    auto frags_rt = [&](int rt, bf16x8 (&af)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[ks] = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
+    };
+    auto mma_ks = [&](int ks, const bf16x8 (&af)[4], f32x4 (&acc)[NG]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const f32x4 c0 = {bv[g], bv[g], bv[g], bv[g]};
+        acc[g] = MFMA16(af[ks], wf[g][ks], ks == 0 ? c0 : acc[g]);
+      }
+    };
+    // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
+    const int ch = 16 * w + l15;
+    float ga[4], gb[4];
+    auto gate_row = [&](int rt, int r, const f32x4 (&acc)[NG]) __attribute__((always_inline)) {
+      const int cell0 = rt * 16 + l4 * 4;
+      if (MODE == 0) {
+        const float m = ldsM[cell0 + r];
+        ga[r] = acc[0][r] * sigm_f(acc[1][r]) * m;
+        gb[r] = acc[2][r] * sigm_f(acc[3][r]) * m;
+        *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[4][r]));
+        if (r == 3) {
+          *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(ga[0], ga[1]), pack2bf_hw(ga[2], ga[3]));
+          *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(gb[0], gb[1]), pack2bf_hw(gb[2], gb[3]));
+        }
+      } else {
+        *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[0][r]);
+        *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[1][r]);
+        *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[3][r]));
+        ga[r] = acc[2][r];
+        if (r == 3) *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(ga[0], ga[1]), pack2bf_hw(ga[2], ga[3]));
+      }
+    };
+    f32x4 accA[NG], accB[NG];
+    bf16x8 afA[4], afB[4];
+    frags_rt(0, afA);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) mma_ks(ks, afA, accA);
+    frags_rt(1, afB);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      f32x4 acc[NG];
+      f32x4 (&cur)[NG] = (rt & 1) ? accB : accA;
+      f32x4 (&nxt)[NG] = (rt & 1) ? accA : accB;
+      bf16x8 (&afn)[4] = (rt & 1) ? afA : afB;        // fragments of row tile rt + 1 (requested one row tile ahead)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 af = *(const bf16x8*)(ldsA + a_tile_off(rt * 16 + l15, ks * 4 + l4));
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = MFMA16(af, wf[g][ks], acc[g]);
+      for (int q = 0; q < 4; ++q) {
+        // chunk q: the NG products of K step q of row tile rt + 1 go to the matrix pipe, then the gates of cell row q of row
+        // tile rt issue on the VALU while they run
+        if (rt + 1 < 4) mma_ks(q, afn, nxt);
+        gate_row(rt, q, cur);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // accumulator layout: column (channel) = l15, rows (cells) = l4*4 + r
-      const int cell0 = rt * 16 + l4 * 4;
-      const int ch = 16 * w + l15;
-      if (MODE == 0) {
-        const f32x4 m = *(const f32x4*)(ldsM + cell0);
-        float a[4], bb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = (acc[0][r] + bv[0]) * sigm_f(acc[1][r] + bv[1]) * m[r];
-          bb[r] = (acc[2][r] + bv[2]) * sigm_f(acc[3][r] + bv[3]) * m[r];
-          *(bf16_t*)(ldsG0 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[4][r] + bv[4]));
-        }
-        *(uint2*)(ldsS + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(a[0], a[1]), pack2bf_hw(a[2], a[3]));
-        *(uint2*)(ldsS + (128 + ch) * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(bb[0], bb[1]), pack2bf_hw(bb[2], bb[3]));
-      } else {
-        float vv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          *(bf16_t*)(ldsQ + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[0][r] + bv[0]);
-          *(bf16_t*)(ldsK + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(acc[1][r] + bv[1]);
-          *(bf16_t*)(ldsG1 + (cell0 + r) * PP_GPITCH + ch * 2) = f2bf_hw(sigm_f(acc[3][r] + bv[3]));
-          vv[r] = acc[2][r] + bv[2];
-        }
-        *(uint2*)(ldsV + ch * PP_SPITCH + cell0 * 2) = make_uint2(pack2bf_hw(vv[0], vv[1]), pack2bf_hw(vv[2], vv[3]));
-      }
+      if (rt + 2 < 4) frags_rt(rt + 2, (rt & 1) ? afB : afA);
     }
     pb = b; pline = line; ppt = pt; par ^= 1; have_prev = true;
   };

@@ -217,10 +217,7 @@ def _recompute_grads(fn, x, mask, dout, head_args, params, transpose=False):
             xb, mb = xb.transpose(1, 2), mb.transpose(1, 2)
         if N8 != N:
             xb = Fn_.pad(xb, (0, 0, 0, N8 - N, 0, N8 - N))
-            # pad KEYS carry a mask of -1e20: their bias inf * (mask - 1) is then ~ -1e29, finite but far below a real masked
-            # key's -inf, so that a fully masked real row (padding residues of a batch) spreads its softmax over its N real
-            # keys like the forward kernels and the reference do, not over N8; pad ROWS are never read back
-            mb = Fn_.pad(Fn_.pad(mb, (0, N8 - N), value=-1e20), (0, 0, 0, N8 - N))
+            mb = Fn_.pad(mb, (0, N8 - N, 0, N8 - N))
         y = fn.apply(xb.contiguous(), mb.contiguous(), *head_args, *ps)[:, :N, :N]
         if transpose:
             y = y.transpose(1, 2)

@@ -144,6 +144,39 @@ def test_inference_fn_vs_reference_golden():
     assert rel_l2(ret["psi_pred"], g["out_psi_pred"]) < 5e-2
 
 
+def test_inference_fn_vs_reference_golden_config1():
+    """BASELINE config 1 IS the reference's eval configuration (run_eval.sh:4-17: 16-frame window, N_res ~ 96, num_t = 10,
+    noise_scale = 0.1): the device-resident sampler against the reference's own Experiment.inference_fn
+    (train_DFOLD_dynamics.py:1425-1547) at that size -- same prior sample, weights and normal draws (numpy stream in the
+    reference's order), ten model forwards + the self-conditioning pass + nine reverse steps.  Inputs other than the prior are
+    regenerated from the seed and pinned by the minted checksum."""
+    from dynamicpdb_amd import experiment, synthetic
+    dev = torch.device(DEV)
+    g = load_golden("sampler_F16_N96.npz")
+    F, N, seed_w, seed_x, num_t = [int(v) for v in g["meta"]]
+    w = synthetic.synthetic_window(seed_x, F, N, t=1.0, diffuser=None)
+    sums = np.array([float(np.asarray(w[k].numpy(), dtype=np.float64).sum()) for k in sorted(w)])
+    assert np.array_equal(sums, g["in_checksum"]), "synthetic_window no longer reproduces the minted inputs"
+    model, diffuser = _build(F, seed_w, dev)
+    init = {k: v.to(dev) for k, v in w.items()}
+    init["rigids_t"] = torch.tensor(g["in_rigids_t"]).float().to(dev)
+    np.random.seed(int(g["seed_z"][0]))
+    draws = [(np.random.normal(size=(F, N, 3)), np.random.normal(size=(F, N, 3))) for _ in range(num_t - 1)]
+    ret = experiment.inference_fn(model, diffuser, init, num_t=num_t, min_t=0.01, center=True, aux_traj=True,
+                                  self_condition=True, noise_scale=float(g["noise_scale"][0]), z_draws=draws)
+    keep = g["traj_steps"]
+    rt, rr = torch.tensor(ret["rigid_traj"].copy()), torch.tensor(g["out_rigid_traj"])
+    errs = dict(quat=max_abs(canon_quat(rt), canon_quat(rr)), trans=max_abs(rt[..., 4:], rr[..., 4:]),
+                trans_traj=max_abs(ret["trans_traj"].copy(), g["out_trans_traj"]),
+                backbone=max_abs(ret["prot_traj"][keep][..., :3, :].copy(), g["out_prot_traj"][..., :3, :]),
+                atoms_rms=float(np.sqrt(np.mean((ret["prot_traj"][keep] - g["out_prot_traj"]) ** 2))),
+                psi=rel_l2(ret["psi_pred"], g["out_psi_pred"]))
+    print("config-1 sampler vs the reference:", {k: round(float(v), 5) for k, v in errs.items()})
+    assert errs["quat"] < 1e-2 and errs["trans"] < 2e-2 and errs["trans_traj"] < 2e-2     # frames: Angstrom
+    assert errs["backbone"] < 4e-2 and errs["atoms_rms"] < 5e-2 and errs["psi"] < 5e-2
+    assert np.array_equal(ret["prot_traj"][keep] == 0, g["out_prot_traj"] == 0)           # atom masks / gathers exact
+
+
 def test_score_heads_vs_reference_golden():
     """calc_rot_score (fp32 quaternions in, float64 score out, the reference's mixed-precision series) and
     calc_trans_score on device tensors against the reference's outputs."""
