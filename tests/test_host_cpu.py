@@ -573,6 +573,34 @@ def test_transpose_read_kernels_addressing_emulation():
     assert emulate_tn_gemm.run(lda=136, ldb=8, seed=5, M=136, N=8) == (0, 0)
 
 
+def test_conv_one_wave_per_simd_kernel_addressing_and_pipeline_emulation():
+    """csrc/conv_fwd_w4.hip replayed on the host on TAGS (scripts/emulate_conv_w4.py): every LDS-DMA piece of the halo tiles and
+    of the weight ring, every fragment read of every wave and step is checked against the operand the implicit GEMM needs there,
+    with the barrier / s_waitcnt vmcnt(K) timing model (a read of bytes whose DMA piece may still be in flight is a race): the
+    K walk (chunk, frame tap, channel half, residue tap), the three-stage weight ring prefetched two steps ahead, the halo
+    double buffer, an odd number of 256-row runs, N_res 512; and the fragment reads are bank-conflict free for every residue
+    tap (ds_read_b128 lane groups of the hardware guide)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import emulate_conv_w4 as E
+    assert E.run(CI=64, F=2) == 50 * 4 * 64 * 9 * 2           # steps x waves x lanes x reads per K16 block x blocks
+    assert E.run(CI=128, F=3, m_tile=1) > 0                   # the last tile's second run repeats its first
+    assert E.run(CI=64, N=512, F=1, W=2, m_tile=1, n_tile=1) > 0
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[lane + 32 for lane in grp] for grp in groups]
+    for w in range(4):
+        for dn in range(5):
+            for kb in range(2):
+                for grp in groups:
+                    banks = {}
+                    for lane in grp:
+                        frow, fhalf = lane & 31, lane >> 5
+                        row = (w & 1) * 128 + frow + dn
+                        a = (w >> 1) * 272 * 64 + row * 64 + (((kb * 2 + fhalf) ^ ((row >> 2) & 3)) << 4)
+                        for b in range(4):
+                            banks[(a // 4 + b) % 64] = banks.get((a // 4 + b) % 64, 0) + 1
+                    assert max(banks.values()) == 1, (w, dn, kb)
+
+
 def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
     """Regression guard without a GPU (hipcc -S, scripts/isa_audit.py): the kernels whose exposed memory round trips were
     removed in round 4 must not grow them back -- no chains of `global_load .. s_waitcnt vmcnt(0) .. global_load` in the

@@ -157,3 +157,40 @@ def test_reference_warm_start_and_eval_checkpoint_load_over_the_dropins(entry, t
     assert type(ev.diffuser).__module__ == "dynamicpdb_amd.data.se3_diffuser"
     for k, v in ref.model.state_dict().items():
         assert torch.equal(ev.model.state_dict()[k], v), k
+
+
+def test_reference_loss_fn_consumes_the_dropin_outputs_of_a_device_step(entry, tmp_path):
+    """The reference's OWN Experiment.loss_fn (train_DFOLD_dynamics.py:1182-1400), unmodified, on the output dict that the
+    drop-in network produced ON THE GPU for the golden window (tests/golden/dropin_step_F3_N16.npz, dumped by
+    tests/test_training_gpu.py::test_dropin_plain_torch_step_without_the_engine_trainer -- plain model(batch) + torch Adam, no
+    engine trainer): the model call inside loss_fn is answered with those outputs, and the loss / rot / trans / torsion terms the
+    reference computes from them must equal what the GPU-side step computed with the restated formulas.  Together with that
+    GPU test this is one reference `update_fn` over the drop-ins, split where the build container has no GPU."""
+    import random
+    import numpy as np
+    from util import load_golden, window_from_golden
+    path = os.path.join(ROOT, "tests", "golden", "dropin_step_F3_N16.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/dropin_step_F3_N16.npz not minted yet (GPU half of the check)")
+    d = np.load(path)
+    g = load_golden("network_F3_N16.npz")
+    _, train_ours, _ = entry
+    exp = train_ours.Experiment(conf=_conf(tmp_path, F=int(g["meta"][0])))
+    outs = {k[4:]: torch.tensor(d[k]).requires_grad_(d[k].dtype.kind == "f") for k in d.files if k.startswith("out_")}
+    calls = []
+
+    def answered(feats, drop_ref=False):
+        calls.append(sorted(feats))
+        return outs
+    exp._model.forward = answered                      # instance attribute: nn.Module.__call__ dispatches to it
+    random.seed(0)                                     # (the coin of the self-conditioning pass, as when the golden was minted)
+    batch = window_from_golden(g)
+    loss, aux = exp.loss_fn({k: v.clone() for k, v in batch.items()})
+    assert calls and {"rigids_t", "res_mask", "t", "node_repr", "edge_repr"} <= set(calls[-1])
+    assert abs(float(loss.detach()) - float(d["loss"])) < 1e-5 * abs(float(d["loss"])), (float(loss.detach()), float(d["loss"]))
+    for k in ("rot_loss", "trans_loss", "torsion_loss"):
+        assert abs(float(aux[k]) - float(d["aux_" + k])) < 1e-5 * max(1.0, abs(float(d["aux_" + k]))), k
+    # and against the reference's own end-to-end value for this window (its own network): the bf16 class of the forward
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    loss.backward()                                    # the reference's loss differentiates through the drop-in's output dict
+    assert all(outs[k].grad is not None and torch.isfinite(outs[k].grad).all() for k in ("angles", "rigids", "rot_score"))

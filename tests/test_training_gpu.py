@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import canon_quat, load_golden, max_abs, record_relu_masks, rel_l2
+from util import ROOT, canon_quat, load_golden, max_abs, record_relu_masks, rel_l2, window_from_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -175,6 +175,54 @@ def test_inference_fn_vs_reference_golden_config1():
     assert errs["quat"] < 1e-2 and errs["trans"] < 2e-2 and errs["trans_traj"] < 2e-2     # frames: Angstrom
     assert errs["backbone"] < 4e-2 and errs["atoms_rms"] < 5e-2 and errs["psi"] < 5e-2
     assert np.array_equal(ret["prot_traj"][keep] == 0, g["out_prot_traj"] == 0)           # atom masks / gathers exact
+
+
+def test_dropin_plain_torch_step_without_the_engine_trainer():
+    """One training step of the drop-in network the way the REFERENCE drives it (train_DFOLD_dynamics.py:660-667, 1182-1400),
+    with nothing of dynamicpdb_amd.experiment / dp in the loop: reference-shaped [F, N, ...] inputs, plain `model(batch)`, the
+    reference's loss formulas (the oracle restatement, which runs on device tensors), `loss.backward()` through the HIP
+    autograd nodes, `torch.optim.Adam(amsgrad=True).step()`.  Outputs / loss / gradients against the reference-minted golden;
+    the outputs, loss and aux terms are dumped (gpurun_out/dropin_step_F3_N16.npz -> tests/golden/) for the build-container
+    half of the check: tests/test_reference_experiment.py feeds them to the reference's OWN Experiment.loss_fn."""
+    import os
+    from oracle import dfold_oracle as O
+    dev = torch.device(DEV)
+    g = load_golden("network_F3_N16.npz")
+    F, N, seed_w = [int(v) for v in g["meta"][:3]]
+    model, _ = _build(F, seed_w, dev)
+    model.train()
+    w = window_from_golden(g, dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, amsgrad=True)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt.zero_grad()
+    out = model({k: v.clone() for k, v in w.items()})                    # [F, N, ...] in, [F, N, ...] out: no batch axis
+    for k in ("angles", "rot_score", "trans_score", "rigids", "atom37"):
+        assert tuple(out[k].shape) == tuple(g["out_" + k].shape), k
+    loss, aux = O.loss_fn(out, w)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    P = dict(model.named_parameters())
+    worst = 0.0
+    for k in g:
+        if k.startswith("gsub_") and float(g["gnorm_" + k[5:]]) > 1e-6:
+            gr, ref = P[k[5:]].grad, torch.tensor(g[k]).double()
+            mine = (gr.reshape(-1)[::9973] if gr.numel() > 70000 else gr).double().cpu().reshape(ref.shape)
+            worst = max(worst, float((mine - ref).norm() / (ref.norm() + 1e-30)))
+    assert worst < 0.25, worst                                         # the class of test_network_gpu::test_gradients
+    opt.step()
+    moved = [k for k, v in model.named_parameters() if v.grad is not None and not torch.equal(v.detach(), before[k])]
+    assert len(moved) > 100 and all(torch.isfinite(v).all() for v in model.parameters())
+    # amsgrad's first step moves every parameter with a gradient by lr * sign(g) (|update| = lr up to eps)
+    k0 = "score_model.trunk.ipa_0.linear_q.weight"
+    step0 = (P[k0].detach() - before[k0])[P[k0].grad.abs() > 1e-6]
+    assert float((step0.abs() - 1e-4).abs().max()) < 2e-6
+    dump = {f"out_{k}": v.detach().cpu().numpy() for k, v in out.items() if torch.is_tensor(v)}
+    dump["loss"] = np.array(float(loss.detach()))
+    for k, v in aux.items():
+        if torch.is_tensor(v) and v.numel() == 1:
+            dump[f"aux_{k}"] = np.array(float(v))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "dropin_step_F3_N16.npz"), **dump)
 
 
 def test_score_heads_vs_reference_golden():
