@@ -51,9 +51,171 @@ __global__ __launch_bounds__(256) void row_ln_fwd_kernel(const void* __restrict_
   }
 }
 
+// C = 128 (the pair tensor's width): 16 lanes per row -- lane l15 holds channels 8 l15 .. + 8 as 16-byte vectors --, four rows
+// per wave and pass, two passes in flight; the two reductions of a row are 4 DPP steps each and serve four rows at once
+// (one wave per row with 4-byte accesses and two 6-step wave reductions per row ran the LayerNorm_in backward of the triangle
+// multiplication at 1.9 TB/s, profiles/r5_trimul_bwd_kernel_stats.csv).
+typedef __attribute__((ext_vector_type(4))) unsigned lnu32x4;
+__device__ __forceinline__ float ln_row16_sum(float v) {
+  v += dpp_mov_f<0xb1>(0.f, v);
+  v += dpp_mov_f<0x4e>(0.f, v);
+  v += dpp_mov_f<0x124>(0.f, v);
+  v += dpp_mov_f<0x128>(0.f, v);
+  return v;
+}
+template <bool XBF16>
+__device__ __forceinline__ void ln128_load(const void* xv, long r, int l15, float (&x)[8]) {
+  if (XBF16) {
+    const lnu32x4 u = *(const lnu32x4*)((const bf16_t*)xv + r * 128 + l15 * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[2 * k] = bf_lo(u[k]);
+      x[2 * k + 1] = bf_hi(u[k]);
+    }
+  } else {
+    const f32x4 a = *(const f32x4*)((const float*)xv + r * 128 + l15 * 8), b = *(const f32x4*)((const float*)xv + r * 128 + l15 * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[k] = a[k];
+      x[4 + k] = b[k];
+    }
+  }
+}
+
+template <bool XBF16>
+__global__ __launch_bounds__(256) void row_ln_fwd128_kernel(const void* __restrict__ xv, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ stats, long R, float eps) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    gm[k] = gamma[l15 * 8 + k];
+    bt[k] = beta[l15 * 8 + k];
+  }
+  for (long r0 = wave * 8; r0 < R; r0 += nw * 8) {
+    float x[2][8];
+    long rr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rr[u] = r0 + u * 4 + l4;
+      ln128_load<XBF16>(xv, rr[u] < R ? rr[u] : R - 1, l15, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float (&v)[8] = x[u];
+      const float mean = ln_row16_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * (1.f / 128.f);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] -= mean;
+        q = __builtin_fmaf(v[k], v[k], q);
+      }
+      const float rstd = rsqrtf(ln_row16_sum(q) * (1.f / 128.f) + eps);
+      if (rr[u] < R) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k] * rstd, gm[k], bt[k]);
+        *(lnu32x4*)(y + rr[u] * 128 + l15 * 8) = (lnu32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (l15 == 0) {
+          stats[2 * rr[u]] = mean;
+          stats[2 * rr[u] + 1] = rstd;
+        }
+      }
+    }
+  }
+}
+
+template <bool XBF16, bool DXBF16>
+__global__ __launch_bounds__(256) void row_ln_bwd128_kernel(const void* __restrict__ xv, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const bf16_t* __restrict__ g,
+                                                            void* __restrict__ dxv, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, long R) {
+  __shared__ float red[4][2][128];
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4, w = threadIdx.x >> 6;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  float gm[8], ag[8], ab[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    gm[k] = gamma[l15 * 8 + k];
+    ag[k] = ab[k] = 0.f;
+  }
+  for (long r0 = wave * 8; r0 < R; r0 += nw * 8) {
+    float x[2][8], gy[2][8], mean[2], rstd[2];
+    long rr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rr[u] = r0 + u * 4 + l4;
+      const long rc = rr[u] < R ? rr[u] : R - 1;
+      ln128_load<XBF16>(xv, rc, l15, x[u]);
+      ln128_load<true>(g, rc, l15, gy[u]);
+      mean[u] = stats[2 * rc];
+      rstd[u] = stats[2 * rc + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bool live = rr[u] < R;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (x[u][k] - mean[u]) * rstd[u];
+        const float gg = live ? gy[u][k] : 0.f;
+        ag[k] = __builtin_fmaf(gg, xh, ag[k]);
+        ab[k] += gg;
+        x[u][k] = xh;
+        gy[u][k] = gg * gm[k];
+        s1 += gy[u][k];
+        s2 = __builtin_fmaf(gy[u][k], xh, s2);
+      }
+      s1 = ln_row16_sum(s1) * (1.f / 128.f);
+      s2 = ln_row16_sum(s2) * (1.f / 128.f);
+      if (live) {
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = rstd[u] * (gy[u][k] - s1 - x[u][k] * s2);
+        if (DXBF16) {
+          *(lnu32x4*)((bf16_t*)dxv + rr[u] * 128 + l15 * 8) = (lnu32x4){pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7])};
+        } else {
+          *(f32x4*)((float*)dxv + rr[u] * 128 + l15 * 8) = (f32x4){d[0], d[1], d[2], d[3]};
+          *(f32x4*)((float*)dxv + rr[u] * 128 + l15 * 8 + 4) = (f32x4){d[4], d[5], d[6], d[7]};
+        }
+      }
+    }
+  }
+  // the four l4 groups of a wave hold the same channels; then the block's four waves; one atomic per channel and block
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float a = ag[k], b = ab[k];
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (l4 == 0) {
+      red[w][0][l15 * 8 + k] = a;
+      red[w][1][l15 * 8 + k] = b;
+    }
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
+  atomicAdd((which ? dbeta : dgamma) + c, (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]));
+}
+
 extern "C" int dfold_row_ln_fwd(const void* x, int32_t x_is_bf16, const float* gamma, const float* beta, void* y_bf16,
                                 float* stats, int64_t R, int32_t C, float eps, void* stream) {
   if (!x || !gamma || !beta || !y_bf16 || !stats || R <= 0 || C <= 0 || C > 64 * LN_MAXE) return DFOLD_EINVAL;
+  if (C == 128 && (((uintptr_t)x | (uintptr_t)y_bf16) & 15) == 0) {
+    long blocks128 = (R + 31) / 32;
+    if (blocks128 > 2048) blocks128 = 2048;
+    if (x_is_bf16)
+      DFOLD_LAUNCH(row_ln_fwd128_kernel<true>, dim3((unsigned)blocks128), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                   (bf16_t*)y_bf16, stats, (long)R, eps);
+    else
+      DFOLD_LAUNCH(row_ln_fwd128_kernel<false>, dim3((unsigned)blocks128), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                   (bf16_t*)y_bf16, stats, (long)R, eps);
+    return dfold_check_launch();
+  }
   long blocks = (R + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (x_is_bf16)
@@ -133,6 +295,20 @@ extern "C" int dfold_row_ln_bwd(const void* x, int32_t x_is_bf16, const float* s
   dim3 grid((unsigned)blocks), blk(256);
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* g = (const bf16_t*)g_bf16;
+  if (C == 128 && (((uintptr_t)x | (uintptr_t)g_bf16 | (uintptr_t)dx) & 15) == 0) {
+    long b128 = (R + 31) / 32;
+    if (b128 > 2048) b128 = 2048;
+    dim3 g128((unsigned)b128);
+    if (x_is_bf16 && dx_is_bf16)
+      DFOLD_LAUNCH((row_ln_bwd128_kernel<true, true>), g128, blk, 0, st, x, stats, gamma, g, dx, dgamma, dbeta, (long)R);
+    else if (x_is_bf16)
+      DFOLD_LAUNCH((row_ln_bwd128_kernel<true, false>), g128, blk, 0, st, x, stats, gamma, g, dx, dgamma, dbeta, (long)R);
+    else if (dx_is_bf16)
+      DFOLD_LAUNCH((row_ln_bwd128_kernel<false, true>), g128, blk, 0, st, x, stats, gamma, g, dx, dgamma, dbeta, (long)R);
+    else
+      DFOLD_LAUNCH((row_ln_bwd128_kernel<false, false>), g128, blk, 0, st, x, stats, gamma, g, dx, dgamma, dbeta, (long)R);
+    return dfold_check_launch();
+  }
   if (x_is_bf16 && dx_is_bf16)
     DFOLD_LAUNCH((row_ln_bwd_kernel<true, true>), grid, blk, 0, st, x, stats, gamma, g, dx, dgamma, dbeta, (long)R, C);
   else if (x_is_bf16)

@@ -234,7 +234,7 @@ def _ws_get(ws, key, shape, dtype, dev):
     return t
 
 
-def _trimul_fused(z, mask, outgoing, pack, ws=None):
+def _trimul_fused(z, mask, outgoing, pack, ws=None, stages_out=None):
     """Fused forward (csrc/pair_fused.hip), three launches: LayerNorm + 640-wide projection + gates -> a|b planes and the
     output gate; x_c = a_c b_c^T batched over (B, channel) on the MFMA engine; LayerNorm_out + linear_z + gate.
     z [B,N,N,128] fp32|bf16, mask [B,N,N]; pack = TriangleMultiplicativeUpdate._packed().  Returns (out, z used, mask used)."""
@@ -261,22 +261,121 @@ def _trimul_fused(z, mask, outgoing, pack, ws=None):
     check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(g_out), _p(b_out), _p(wz), _p(b_z), _p(out),
                                  c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
                                  ctypes_float(1e-5), st), "dfold_trimul_out_fwd")
+    if stages_out is not None:
+        stages_out.extend((planes, gate, xpl))
     return out, zc, maskf
 
 
+def _use_fused_bwd():
+    """DFOLD_TRIMUL_FUSED_BWD=0: the backward of the fused triangle multiplication re-runs the intermediate-keeping chain"""
+    return os.environ.get("DFOLD_TRIMUL_FUSED_BWD", "1") != "0"
+
+
+def _trimul_keep_stages(B, N):
+    """Keep the forward's planes / gate / x planes (4 bf16 copies of the pair tensor: 0.54 GB at batch 8 x N_res 256) for the
+    backward instead of recomputing them there (two launches, 0.3 ms at that size)?  DFOLD_TRIMUL_KEEP = 1 always, 0 never,
+    default: up to DFOLD_TRIMUL_KEEP_MB (2048) per operator call."""
+    e = os.environ.get("DFOLD_TRIMUL_KEEP", "")
+    if e in ("0", "1"):
+        return e == "1"
+    return B * N * N * 128 * 2 * 4 <= int(os.environ.get("DFOLD_TRIMUL_KEEP_MB", "2048")) * (1 << 20)
+
+
+def _trimul_fused_backward(zc, maskf, dout, outgoing, pack, kept=None):
+    """Backward of the fused triangle multiplication mirroring the forward's three passes (csrc/trimul_bwd.hip; N_res a multiple
+    of 64): planes / gate / x planes recomputed with the forward's own kernels, then  out-stage backward (one pass: gate
+    backward, dy W_z, LayerNorm_out backward -> dx planes) -> the two contraction gradients on the reduction-major MFMA kernel
+    (one transposed copy of dx) -> projection-stage backward (LayerNorm_in + projections recomputed per tile, gate backward
+    -> pre-activation gradients [cells][640]) -> dense tail (dzn, LayerNorm_in backward, weight gradients as reduction-major
+    products).  Nothing pair-sized lives between forward and backward.  Returns (dz fp32, parameter gradients in the order of
+    TriangleMultiplicativeUpdate._params())."""
+    L = _lib.lib()
+    wcat, bcat, wz, g_in, b_in, g_out, b_out, b_z = pack
+    B, N = zc.shape[0], zc.shape[1]
+    NP, NN = N, N * N
+    R, dev, st = B * NN, zc.device, stream()
+    f32 = torch.float32
+    zbf = c_int32(1 if zc.dtype == BF16 else 0)
+    inc = c_int32(0 if outgoing else 1)
+    if kept is not None:
+        planes, gate, xpl = kept
+    else:
+        planes = torch.empty((B, N, 256, NP), dtype=BF16, device=dev)
+        gate = torch.empty((B, N, N, 128), dtype=BF16, device=dev)
+        xpl = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
+        check(L.dfold_trimul_proj_fwd(_p(zc), zbf, _p(maskf), _p(g_in), _p(b_in), _p(wcat), _p(bcat), _p(planes), _p(gate), c_void_p(0),
+                                      c_int32(B), c_int32(N), c_int32(NP), inc, ctypes_float(1e-5), st), "dfold_trimul_proj_fwd")
+        gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(256 * NP), c_rows=rows_plain(128 * NP), ldb=256 * NP,
+             nbatch=B * 128, nb1=128, sa=(N * 256 * NP, NP), sb=(N * 256 * NP, NP), sc=(N * 128 * NP, NP), b_off=128 * NP)
+    # ---- out stage ----
+    do = dout.reshape(B, N, N, 128)
+    if do.dtype not in (f32, BF16):
+        do = do.float()
+    do = do.contiguous()
+    dxpl = torch.empty((B, N, 128, NP), dtype=BF16, device=dev)
+    d5 = torch.empty((R, 640), dtype=BF16, device=dev)
+    dy = torch.empty((R, 128), dtype=BF16, device=dev)
+    xn = torch.empty((R, 128), dtype=BF16, device=dev)
+    small = torch.zeros(4 * 128 + 512, dtype=f32, device=dev)          # d gamma_out | d beta_out | d b_z | d b_g | d bias (a_p a_g b_p b_g)
+    dg_out, db_out, db_z, db_g, dbias4 = small[:128], small[128:256], small[256:384], small[384:512], small[512:]
+    wzT = ops.transpose_bf16(wz, 128, 128)
+    check(L.dfold_trimul_out_bwd(_p(xpl), _p(gate), _p(do), c_int32(1 if do.dtype == BF16 else 0), _p(g_out), _p(b_out), _p(wz),
+                                 _p(wzT), _p(b_z), _p(dxpl), _p(d5, 512), c_int64(640), _p(dy), _p(xn), _p(dg_out), _p(db_out),
+                                 _p(db_z), _p(db_g), c_int32(B), c_int32(N), c_int32(NP), ctypes_float(1e-5), st), "dfold_trimul_out_bwd")
+    dw_z = ops.weight_grad_tn(dy, xn, R, 128, 128)
+    del gate, xpl, dy, xn
+    # ---- contraction gradients: da_c[i,k] = sum_j dx_c[i,j] b_c[j,k];  db_c[j,k] = sum_i dx_c[i,j] a_c[i,k]   (batch = (item, channel)) ----
+    dxplT = torch.empty_like(dxpl)
+    ops.transpose_bf16(dxpl, N, N, ld_src=128 * NP, out=dxplT, nbatch=B * 128, nb1=128, bs_src=(N * 128 * NP, NP),
+                       bs_dst=(N * 128 * NP, NP), ld_dst=128 * NP)
+    dplanes = torch.empty((B, N, 256, NP), dtype=BF16, device=dev)
+    ops.gemm_tn(dxplT, planes, dplanes, N, N, N, 128 * NP, 256 * NP, 256 * NP, nbatch=B * 128, nb1=128, sa=(N * 128 * NP, NP),
+                sb=(N * 256 * NP, NP), sc=(N * 256 * NP, NP), b_off=128 * NP)
+    ops.gemm_tn(dxpl, planes, dplanes, N, N, N, 128 * NP, 256 * NP, 256 * NP, nbatch=B * 128, nb1=128, sa=(N * 128 * NP, NP),
+                sb=(N * 256 * NP, NP), sc=(N * 256 * NP, NP), c_off=128 * NP)
+    del dxpl, dxplT, planes
+    # ---- projection stage ----
+    zn = torch.empty((R, 128), dtype=BF16, device=dev)
+    stats = torch.empty((R, 2), dtype=f32, device=dev)
+    check(L.dfold_trimul_proj_bwd(_p(zc), zbf, _p(maskf), _p(g_in), _p(b_in), _p(wcat), _p(bcat), _p(dplanes), _p(d5), c_int64(640),
+                                  _p(zn), _p(stats), _p(dbias4), c_int32(B), c_int32(N), c_int32(NP), inc, ctypes_float(1e-5), st),
+          "dfold_trimul_proj_bwd")
+    del dplanes
+    # ---- dense tail ----
+    dwcat = ops.weight_grad_tn(d5, zn, R, 640, 128)
+    wcatT = ops.transpose_bf16(wcat, 640, 128)                                       # [128][640]
+    dzn = torch.empty((R, 128), dtype=BF16, device=dev)
+    gemm(d5, wcatT, dzn, R, 128, 640, a_rows=rows_plain(640), c_rows=rows_plain(128), ldb=640)
+    dz, dg_in, db_in = _row_ln_bwd(zc.reshape(R, 128), stats, g_in, dzn, dx_bf16=False)
+    c = 128
+    sp = lambda t, i: t[i * c:(i + 1) * c]
+    return dz.view(zc.shape), (dg_in, db_in, sp(dwcat, 0), sp(dbias4, 0), sp(dwcat, 1), sp(dbias4, 1), sp(dwcat, 2), sp(dbias4, 2),
+                               sp(dwcat, 3), sp(dbias4, 3), sp(dwcat, 4), db_g, dw_z, db_z, dg_out, db_out)
+
+
 class TriMulFusedFn(Function):
-    """autograd node of the fused forward; the backward re-derives the unfused chain from the saved inputs"""
+    """autograd node of the fused forward; backward: the fused three-pass backward (csrc/trimul_bwd.hip) at N_res multiples of
+    64, else the unfused chain re-derived from the saved inputs"""
 
     @staticmethod
     def forward(ctx, z, mask, outgoing, pack, ws, *params):
-        out, zc, maskf = _trimul_fused(z, mask, outgoing, pack, ws)
-        ctx.save_for_backward(zc, maskf, *params)
-        ctx.outgoing = outgoing
+        N = z.shape[1]
+        fused_bwd = _use_fused_bwd() and N % 64 == 0 and ops.gemm_tn_ok(N, N, N, ragged=True)
+        stages = [] if fused_bwd and _trimul_keep_stages(z.shape[0], N) else None
+        out, zc, maskf = _trimul_fused(z, mask, outgoing, pack, None if stages is not None else ws, stages)
+        ctx.save_for_backward(zc, maskf, *params, *(stages or ()))
+        ctx.outgoing, ctx.pack, ctx.fused_bwd, ctx.kept = outgoing, pack, fused_bwd, stages is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         zc, maskf, *params = ctx.saved_tensors
+        kept = None
+        if ctx.kept:
+            params, kept = params[:-3], tuple(params[-3:])
+        if ctx.fused_bwd:
+            dz, g = _trimul_fused_backward(zc, maskf, dout, ctx.outgoing, ctx.pack, kept)
+            return (dz.to(zc.dtype), None, None, None, None, *g)
         g = _recompute_grads(TriangleMultiplicationFn, zc, maskf, dout, (ctx.outgoing,), params)
         return (g[0].to(zc.dtype), None, None, None, None, *g[1:])
 

@@ -298,6 +298,25 @@ int dfold_trimul_proj_fwd(const void* z, int32_t z_is_bf16, const float* mask, c
 int dfold_trimul_out_fwd(const void* x_planes_bf16, const void* gate_bf16, const float* ln_gamma, const float* ln_beta,
                          const void* w_z_bf16, const float* b_z, void* out, int32_t out_is_bf16, int32_t B, int32_t N,
                          int32_t NP, float eps, void* stream);
+/* Backward of stage 3 (the autograd of triangular_multiplicative_update.py:119-124), one pass over (x planes, gate, dout):
+ * LayerNorm_out recomputed, y = xn W_z^T + b_z, d(gate pre-activation) = dout y g (1 - g) written as bf16 rows of pitch dgate_ld
+ * (the last 128 columns of the [cells][640] pre-activation gradient matrix), dy = dout g and xn as bf16 [B N N][128] (operands of
+ * dW_z), dxn = dy W_z (w_z_t = W_z^T bf16 [128][128]), LayerNorm backward -> dx as bf16 planes [B][N][128][NP] (what the two
+ * contraction gradients consume); d_gamma / d_beta / d_bz / d_bg (the output gate's bias gradient) fp32 [128] are ADDED to
+ * (atomics): zero them first. */
+int dfold_trimul_out_bwd(const void* x_planes_bf16, const void* gate_bf16, const void* dout, int32_t dout_is_bf16,
+                         const float* ln_gamma, const float* ln_beta, const void* w_z_bf16, const void* w_z_t_bf16,
+                         const float* b_z, void* dx_planes_bf16, void* dgate_pre_bf16, int64_t dgate_ld, void* dy_bf16,
+                         void* xn_bf16, float* d_gamma, float* d_beta, float* d_bz, float* d_bg, int32_t B, int32_t N,
+                         int32_t NP, float eps, void* stream);
+/* Backward of stage 1 (:97-111): LayerNorm_in and the four gated projections a_p | a_g | b_p | b_g recomputed per 64-cell tile
+ * (w_cat rows 0 .. 511), gate backward against dplanes = the gradients of the a | b planes (bf16 [B][N][256][NP], the layout of
+ * dfold_trimul_proj_fwd's planes) -> d5 columns 0 .. 511 (bf16 rows of pitch d5_ld, true cell order), zn bf16 [B N N][128],
+ * LayerNorm statistics fp32 [B N N][2] (mean, 1/std: inputs of dfold_row_ln_bwd); d_bias fp32 [512] is ADDED to. */
+int dfold_trimul_proj_bwd(const void* z, int32_t z_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
+                          const void* w_cat_bf16, const float* bias_cat, const void* dplanes_bf16, void* d5_bf16,
+                          int64_t d5_ld, void* zn_bf16, float* stats, float* d_bias, int32_t B, int32_t N, int32_t NP,
+                          int32_t incoming, float eps, void* stream);
 /* Triangle attention, stage 1 (triangular_attention.py:92-113, primitives.py:363-383): LayerNorm, q|k|v|g projections
  * (w_cat [512][128] bf16, bias_cat [512] = 0|0|0|b_g), triangle bias (w_tri fp32 [4][128]).  ending != 0: the operator
  * acts on x' = x^T (cell (i,j) of every output = cell (j,i) of x).  q, k, gate(=sigmoid) bf16 [B][N][N][128];

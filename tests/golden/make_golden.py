@@ -182,6 +182,59 @@ def golden_sampler(F=3, N=16, seed_w=4, seed_x=8, num_t=3, noise_scale=0.5, seed
     print("sampler golden written", {k: v.shape for k, v in fix.items() if k.startswith("out_")})
 
 
+def golden_bf16_sensitivity(big=False):
+    """How far does the REFERENCE move from itself under the engine's declared storage class?  For the small goldens' windows
+    the reference's own loss gradients in fp32 against the same reference code with (a) every parameter rounded to bf16 and
+    (b) the output of every nn.Linear / nn.Conv2d rounded to bf16 (forward AND, through the cast's own backward, the gradient
+    that flows back through that point) -- nothing else changes: same modules, same aten kernels, same ReLU code, branches free
+    to flip.  Per parameter tensor: relative L2 distance and relative norm difference, full loss and torsion_loss_weight = 0.
+    This is the yardstick for the engine's raw gradient tolerances (tests/test_parity_baseline_gpu.py): an implementation
+    that stores bf16 between its kernels cannot be closer to the fp32 reference than the reference is to its own bf16-storage
+    run."""
+    import train_DFOLD_dynamics as T
+    fix = {}
+    small = (("F3_N16", 3, 16, 0, 1, 0.5, 0.0), ("F6_N40_holes", 6, 40, 27, 28, 0.5, 0.1), ("F16_N96", 16, 96, 11, 12, 0.4, 0.0),
+             ("F2_N256", 2, 256, 13, 14, 0.6, 0.0))
+    large = (("F32_N128", 32, 128, 23, 24, 0.35, 0.0), ("F32_N256", 32, 256, 21, 22, 0.45, 0.0), ("F8_N512", 8, 512, 25, 26, 0.55, 0.0))
+    for tag, F, N, seed_w, seed_x, t, holes in (large if big else small):
+        conf = ref_import.make_conf(F, cache_dir=".cache/")
+        exp = T.Experiment(conf=conf)
+        model = exp.model
+        win = synthetic.synthetic_window(seed_x, F, N, t=t, diffuser=exp.diffuser, rigid_cls=Rigid, holes=holes)
+
+        def grads(torsion_w):
+            exp._exp_conf.torsion_loss_weight = torsion_w
+            random.seed(0)
+            model.zero_grad()
+            loss, _ = exp.loss_fn({k: v.clone() for k, v in win.items()})
+            loss.backward()
+            return float(loss), {n: p.grad.detach().double().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        model.load_state_dict(synthetic.seeded_state_dict(seed_w), strict=True)
+        model.eval()
+        ref = {w: grads(w) for w in (1.0, 0.0)}
+        with torch.no_grad():
+            for p in model.parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+        hooks = [m.register_forward_hook(lambda mod, inp, out: out.to(torch.bfloat16).to(out.dtype))
+                 for m in model.modules() if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d))]
+        low = {w: grads(w) for w in (1.0, 0.0)}
+        for h in hooks:
+            h.remove()
+        exp._exp_conf.torsion_loss_weight = 1.0
+        for w, wtag in ((1.0, "full"), (0.0, "notorsion")):
+            names = sorted(n for n in ref[w][1] if float(ref[w][1][n].norm()) > 1e-6)
+            rel = np.array([float((low[w][1][n] - ref[w][1][n]).norm() / ref[w][1][n].norm()) for n in names])
+            nrm = np.array([abs(float(low[w][1][n].norm() / ref[w][1][n].norm()) - 1.0) for n in names])
+            fix[f"{tag}/{wtag}/rel"], fix[f"{tag}/{wtag}/nrm"] = rel, nrm
+            fix[f"{tag}/{wtag}/names"] = np.array(names)
+            fix[f"{tag}/{wtag}/loss"] = np.array([ref[w][0], low[w][0]])
+            print(f"bf16-storage reference vs fp32 reference, {tag}, {wtag}: loss {ref[w][0]:.5f} / {low[w][0]:.5f}; per-tensor rel-L2 "
+                  f"median {np.median(rel):.4f} max {rel.max():.4f} ({names[int(rel.argmax())]}); norm error median "
+                  f"{np.median(nrm):.4f} max {nrm.max():.4f}")
+    np.savez_compressed(os.path.join(HERE, "bf16_sensitivity_big.npz" if big else "bf16_sensitivity.npz"), **fix)
+
+
 def golden_triangle(N=24, seed=3):
     from openfold.model.triangular_multiplicative_update import (TriangleMultiplicationIncoming,
                                                                   TriangleMultiplicationOutgoing)
@@ -488,6 +541,9 @@ if __name__ == "__main__":
         # BASELINE config 1 IS an eval configuration (run_eval.sh:4-17, config/eval_DFOLDv2.yaml: 16-frame window, N_res ~ 96,
         # data.num_t = 10, noise_scale = 0.1): the reference's own inference_fn at that size
         golden_sampler(F=16, N=96, seed_w=31, seed_x=32, num_t=10, noise_scale=0.1, seed_z=91, compact=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bf16_sensitivity":
+        golden_bf16_sensitivity(big=len(sys.argv) > 2 and sys.argv[2] == "big")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pair_transition":
         golden_pair_transition()

@@ -250,6 +250,45 @@ def test_fused_equals_unfused_chain_fwd_bwd(name, monkeypatch):
         assert rel_l2(res["1"][2][k], res["0"][2][k]) < tol, (k, rel_l2(res["1"][2][k], res["0"][2][k]))
 
 
+@pytest.mark.parametrize("name,B,N,dt", [("tri_mul_out", 2, 64, "fp32"), ("tri_mul_in", 2, 128, "fp32"), ("tri_mul_in", 1, 64, "bf16"),
+                                       ("tri_mul_out", 1, 192, "bf16")])
+def test_trimul_fused_backward_vs_chain_and_oracle(name, B, N, dt, monkeypatch):
+    """The three-pass fused backward of the triangle multiplication (csrc/trimul_bwd.hip: out-stage backward, contraction
+    gradients on the reduction-major kernel, projection-stage backward; N_res multiples of 64) against (a) the
+    intermediate-keeping HIP chain it replaces -- two bf16-class evaluations of the same gradient -- and (b) the oracle's
+    autograd: input gradient and all 16 parameter gradients, both orientations, batch, fp32 and bf16 pair tensors, holes in
+    the mask."""
+    dev = torch.device(DEV)
+    z, mask = _inputs(B, N, 61 + N, holes=0.1)
+    gy = torch.tensor(np.random.default_rng(62).standard_normal((B, N, N, 128), dtype=np.float32))
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DFOLD_TRIMUL_FUSED_BWD", fused)
+        m = _rand_module(_names()[name](), 63).to(dev)
+        zz = z.to(dev)
+        if dt == "bf16":
+            zz = zz.to(torch.bfloat16)
+        zz.requires_grad_(True)
+        y = m(zz, mask=mask.to(dev))
+        y.backward(gy.to(dev).to(y.dtype))
+        res[fused] = (zz.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    tol = 2e-2 if dt == "fp32" else 3e-2
+    worst = {"dz": rel_l2(res["1"][0], res["0"][0])}
+    for k in res["0"][1]:
+        worst[k] = rel_l2(res["1"][1][k], res["0"][1][k])
+    print(f"[{name} B{B} N{N} {dt}] fused backward vs chain: dz {worst['dz']:.2e}, worst parameter {max(worst, key=worst.get)} {max(worst.values()):.2e}")
+    assert max(worst.values()) < tol, worst
+    if dt == "fp32" and N <= 64:
+        m = _rand_module(_names()[name](), 63)
+        P = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        zr = z.clone().requires_grad_(True)
+        for b in range(B):
+            _oracle(name, P, zr[b], mask[b]).backward(gy[b])
+        assert rel_l2(res["1"][0], zr.grad) < 3e-2, rel_l2(res["1"][0], zr.grad)
+        for k, v in res["1"][1].items():
+            assert rel_l2(v, P[k].grad) < 3e-2, (k, rel_l2(v, P[k].grad))
+
+
 @pytest.mark.parametrize("name", ["tri_mul_out", "tri_att_end"])
 def test_fused_long_chain_properties(name):
     """N_res = 320 (two key chunks / five tiles per line), no oracle: (a) a batch of two equals two single calls bit for

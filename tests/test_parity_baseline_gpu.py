@@ -29,7 +29,7 @@ def _build(F, seed_w, dev):
     return model.to(dev), diffuser
 
 
-def _step_vs_golden(name, atom_max=1.5, keep=None):
+def _step_vs_golden(name, keep=None):
     from dynamicpdb_amd import experiment
     dev = torch.device(DEV)
     g = load_golden(name)
@@ -57,9 +57,19 @@ def _step_vs_golden(name, atom_max=1.5, keep=None):
     rms = float(d37.pow(2).sum(-1).mean().sqrt())
     far = float((d37.norm(dim=-1) > 0.3).double().mean())
     print(f"[{name}] atom37 rms {rms:.4f} A, max {float(d37.abs().max()):.3f} A, fraction of atoms off by > 0.3 A: {far:.2e}")
-    # RMS at the SURVEY 8c coordinate class; single side-chain atoms behind an ill-conditioned torsion may flip by up to
-    # twice their lever arm (the more residues x frames, the larger the maximum over them: a robust count bounds it)
-    assert rms < 5e-2 and float(d37.abs().max()) < atom_max and far < 5e-3, (rms, float(d37.abs().max()), far)
+    # RMS at the SURVEY 8c coordinate class, a robust count of outliers, and every outlier EXPLAINED: an atom off by more than
+    # 0.3 A must sit on a residue with an ill-conditioned torsion -- a raw 2-vector (the reference's own `unorm_angles`) shorter
+    # than half the RMS length of all raw vectors, where normalising (openfold/utils/loss.py:58, feats.py torsion frames)
+    # turns the bf16-level difference of the raw vector into a rotation of tens of degrees, i.e. up to twice the lever arm
+    raw = torch.tensor(g["out_unorm_angles"]).double().norm(dim=-1)                     # [F, N, 7]
+    ill = raw < 0.5 * float(raw.pow(2).mean().sqrt())
+    off = d37.norm(dim=-1) > 0.3                                                         # [F, N, 37]
+    n_off = int(off.sum())
+    explained = int((off & ill.any(-1)[..., None]).sum())
+    print(f"[{name}] atoms off by > 0.3 A: {n_off}, of which on a residue with an ill-conditioned torsion: {explained}; "
+          f"ill-conditioned torsions: {float(ill.double().mean()):.3f} of all")
+    assert rms < 5e-2 and far < 5e-3 and float(d37.abs().max()) < 8.0, (rms, float(d37.abs().max()), far)
+    assert explained >= n_off - max(1, n_off // 50), (n_off, explained)
     from oracle import dfold_oracle as O
     _, a37 = O.frames_to_atoms(out["rigids"].detach().cpu(), out["angles"].detach().cpu(), w["aatype"].long())
     assert max_abs(out["atom37"], a37) < 2e-3
@@ -148,13 +158,13 @@ def test_step_vs_reference_golden_config3_window():
     are independent: test_network_gpu::test_batched_equals_independent_windows) -- against the reference's own fp32 run
     (train_DFOLD_dynamics.py:660-667,1182-1400; src/model/Dfold_network_dynamic.py:450-546): every output, the loss
     terms, every parameter gradient (norm + sampled entries)."""
-    full, frames = _step_vs_golden("network_F32_N256.npz", atom_max=6.0)
+    full, frames = _step_vs_golden("network_F32_N256.npz")
     _check_big(full, frames, "cfg3 F32 N256")
 
 
 def test_step_vs_reference_golden_config2_window():
     """One window of BASELINE config 2 (32 frames x N_res 128) against the reference's own fp32 run."""
-    full, frames = _step_vs_golden("network_F32_N128.npz", atom_max=6.0)
+    full, frames = _step_vs_golden("network_F32_N128.npz")
     _check_big(full, frames, "cfg2 F32 N128")
 
 
@@ -164,7 +174,7 @@ def test_step_vs_reference_golden_config5_nres512():
     on the same chain: finite, and its two step modes agree on loss and gradients (the size-independent property)."""
     from dynamicpdb_amd import experiment, synthetic
     keep = {}
-    full, frames = _step_vs_golden("network_F8_N512.npz", keep=keep, atom_max=6.0)
+    full, frames = _step_vs_golden("network_F8_N512.npz", keep=keep)
     _check_big(full, frames, "cfg5 F8 N512")
     del keep
     torch.cuda.empty_cache()
