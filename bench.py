@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-triangle", action="store_true", help="skip the triangle-operator extra object")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 5 extra objects")
     ap.add_argument("--no-eval-config", action="store_true", help="skip the config 1 (eval / sampling) extra object")
+    ap.add_argument("--no-neighbours", action="store_true", help="skip the pair-block / dataset-transform / per-kernel HBM extra objects")
     ap.add_argument("--same-batch", action="store_true", help="feed one batch to every step (profiling aid; default: a "
                     "fresh synthetic batch per step, generated on the device and staged in HBM before the timed region)")
     ap.add_argument("--mode", choices=("all_frames", "last_frame"), default="all_frames",
@@ -184,9 +185,164 @@ def triangle_roofline(dev, reps=10):
             key = f"{name}_n{n}" + ("" if nb == 1 else f"_b{nb}")
             out[key] = {"ms": round(t * 1e3, 4), "batch": nb, "algorithmic_bytes": alg, "GBps": round(alg / t / 1e9, 1),
                         "hbm_frac": round(alg / t / 8.0e12, 4)}
+            if nb == 8:      # forward + backward through autograd (input and every parameter gradient), the same call shapes
+                zg = z.clone().requires_grad_(True)
+                gy = torch.randn_like(z)
+                for _ in range(2):
+                    m(zg, mask=mask).backward(gy)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(max(2, reps // 2)):
+                    m(zg, mask=mask).backward(gy)
+                e1.record()
+                torch.cuda.synchronize()
+                out[key]["fwd_bwd_ms"] = round(e0.elapsed_time(e1) / max(2, reps // 2), 4)
+                del zg, gy
             del m, z, mask
-    out["note"] = ("forward, fp32 pair tensor, batch 1 and batch 8, fused kernels of csrc/pair_fused.hip; bound = hbm (8 TB/s): "
-                   "algorithmic bytes = read z + write out + mask (SURVEY 8d); counters in profiles/, DESIGN.md section 4")
+    out["note"] = ("forward, fp32 pair tensor, batch 1 and batch 8, fused kernels of csrc/pair_fused.hip / triatt_*.hip; bound = hbm "
+                   "(8 TB/s): algorithmic bytes = read z + write out + mask (SURVEY 8d); fwd_bwd_ms (batch 8): forward + backward "
+                   "through autograd (fused three-pass backward of the multiplication, streaming backward of the attention); "
+                   "counters in profiles/, DESIGN.md section 4")
+    return out
+
+
+def neighbours(dev, tlog, reps=5):
+    """Extra object for SURVEY 8f ranks 2 / 3 (parity-green since round 2, never timed): one Evoformer pair block
+    (OpenFold EvoformerBlockCore: MSA transition, outer product mean, the four triangle operators, pair transition) at N_res 256
+    with 64 sequences, OmegaFold's GeometricAttention at N_res 256, and the dataset-side transforms of one 32-frame window
+    (atom37 -> frames + torsions, forward noising) on the device; forward, fp32 pair tensor, HIP events."""
+    from dynamicpdb_amd import synthetic
+    from dynamicpdb_amd.data import data_transforms as dt
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.geoformer import GeometricAttention
+    from dynamicpdb_amd.model.pair_stack import EvoformerBlockCore
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    N, S = 256, 64
+    torch.manual_seed(0)
+    blk = EvoformerBlockCore(c_m=256, c_z=128, c_hidden_opm=32, c_hidden_mul=128, c_hidden_pair_att=32, no_heads_msa=8, no_heads_pair=4,
+                             transition_n=4, pair_dropout=0.25, inf=1e9, eps=1e-8).to(dev).eval()
+    m, z = torch.randn(S, N, 256, device=dev), torch.randn(N, N, 128, device=dev)
+    mm, pm = torch.ones(S, N, device=dev), torch.ones(N, N, device=dev)
+    with torch.no_grad():
+        ms = timed(lambda: blk(m, z, mm, pm))
+    pair_bytes = N * N * 128 * 4
+    out["evoformer_block_core_n256_s64"] = {"ms": round(ms, 4), "pair_tensor_mb": round(pair_bytes / 1e6, 1),
+                                            "pair_passes_at_8TBps": round(ms * 1e-3 * 8.0e12 / (2 * pair_bytes), 1),
+                                            "note": "five pair updates + outer product mean + MSA transition, forward; "
+                                                    "pair_passes_at_8TBps = how many read+write passes over the pair tensor the "
+                                                    "time would buy at the HBM peak"}
+    del blk, m, z
+    ga = GeometricAttention(128, 32, 4, 2).to(dev).eval()
+    e, em = torch.randn(N, N, 128, device=dev), torch.ones(N, device=dev)
+    with torch.no_grad():
+        ms = timed(lambda: ga(e, em))
+    out["geometric_attention_n256"] = {"ms": round(ms, 4), "note": "OmegaFold GeometricAttention (2 gated products + 2-axis attention), forward"}
+    del ga, e
+    F = 32
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    w = synthetic.synthetic_window(5, F, N, t=0.5, diffuser=diffuser)
+    from dynamicpdb_amd.model import geometry as G
+    with torch.no_grad():
+        a37 = G.frames_to_atoms_hip(w["rigids_0"].to(dev).float(), w["torsion_angles_sin_cos"].to(dev).float(), w["aatype"].to(dev))[1]
+    prot = {"aatype": w["aatype"].to(dev).long(), "all_atom_positions": a37.double(),
+            "all_atom_mask": (a37.abs().sum(-1) > 0).double()}
+    ms = timed(lambda: dt.atom37_to_torsion_angles()(dt.atom37_to_frames(dict(prot))))
+    out["dataset_geometry_f32_n256"] = {"ms": round(ms, 4), "residues": F * N,
+                                        "note": "atom37_to_frames + atom37_to_torsion_angles of one 32-frame window (fp64, one launch)"}
+    r0 = w["rigids_0"].to(dev).float()
+    ms = timed(lambda: diffuser.forward_marginal_t7(r0, 0.5))
+    out["forward_marginal_f32_n256"] = {"ms": round(ms, 4), "note": "forward noising of one window incl. the numpy draws (host RNG) and their upload"}
+    tlog("neighbours: " + json.dumps({k: v["ms"] for k, v in out.items()}))
+    return out
+
+
+def hbm_kernels(dev, tlog, reps=10):
+    """Extra object: the other HBM-bound kernels of SURVEY 8d at the config-3 shapes, each called through the C ABI on its own
+    (HIP events): algorithmic bytes (inputs read once + outputs written once) / time against the 8 TB/s HBM peak."""
+    from ctypes import c_int32, c_int64
+    from dynamicpdb_amd import _lib, ops
+    from dynamicpdb_amd._lib import check, stream
+    from dynamicpdb_amd.model.functional import ctypes_float
+    from dynamicpdb_amd.ops import BF16, _p
+    L = _lib.lib()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+
+    def row(name, t, nbytes, what):
+        out[name] = {"ms": round(t * 1e3, 4), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / t / 1e9, 1),
+                     "hbm_frac": round(nbytes / t / 8.0e12, 4), "what": what}
+
+    B, F, N = 8, 32, 256
+    # IPA pair-side projections: linear_b + down_z in one pass over z
+    z = torch.randn(B, N, N, 128, device=dev).to(BF16)
+    wb, wdz = torch.randn(8, 128, device=dev).to(BF16), torch.randn(32, 128, device=dev).to(BF16)
+    bias_t = torch.empty((B, 8, N, N), dtype=torch.float32, device=dev)
+    pz, pzT = torch.empty((B, N, N, 32), dtype=BF16, device=dev), torch.empty((B, N, 32, N), dtype=BF16, device=dev)
+    t = timed(lambda: check(L.dfold_ipa_pair_proj(_p(z), _p(wb), _p(wdz), _p(bias_t), _p(pz), _p(pzT), c_int32(B), c_int32(N), stream()), "pair_proj"))
+    row("ipa_pair_proj", t, z.numel() * 2 + bias_t.numel() * 4 + pz.numel() * 2 * 2, "z (bf16) once in; pair bias fp32 + down_z in both layouts out")
+    del z, bias_t, pz, pzT
+    # MyLayerNorm over a window (fp64 statistics) + apply
+    P = F * N * 256
+    x = torch.randn(B, P, device=dev)
+    y = torch.empty((B, P), dtype=BF16, device=dev)
+    st, mr = torch.empty(2 * B, dtype=torch.float64, device=dev), torch.empty(2 * B, dtype=torch.float32, device=dev)
+    t = timed(lambda: check(L.dfold_gln_fwd(_p(x), _p(st), _p(y), _p(mr), c_int32(B), c_int64(P), ctypes_float(1e-4), c_int32(0), stream()), "gln"))
+    row("my_layer_norm_fwd", t, x.numel() * 4 + y.numel() * 2, "fp32 pre-norm activations in, bf16 out (the statistics pass re-reads x: counted once)")
+    del x, y
+    # embedder input layer (k = 7 -> 256, SiLU)
+    Pn = B * F * N
+    xin, W, b = torch.randn(Pn, 7, device=dev), torch.randn(256, 7, device=dev), torch.randn(256, device=dev)
+    o = torch.empty((Pn, 256), dtype=BF16, device=dev)
+    t = timed(lambda: check(L.dfold_embed_in_fwd(_p(xin), _p(W), _p(b), _p(o), c_int64(Pn), c_int32(7), c_int32(256), stream()), "embed"))
+    row("embed_in_fwd", t, xin.numel() * 4 + o.numel() * 2, "7 inputs per position in, 256 bf16 channels out")
+    del xin, o
+    # expand_edge: cast + 128 -> 128 linear over the pair tensor
+    e = torch.randn(B * N * N, 128, device=dev)
+    We = torch.randn(128, 128, device=dev).to(BF16)
+    be = torch.zeros(128, device=dev)
+
+    def expand():
+        eb = ops.cast_bf16(e)
+        ops.linear_fwd(eb, We, be, out_dtype=BF16)
+    t = timed(expand)
+    row("expand_edge", t, e.numel() * 4 + e.numel() * 2, "fp32 edge_repr in, bf16 expanded edges out (cast + MFMA linear: two launches)")
+    del e
+    # fused Adam (amsgrad) over the model's parameter count
+    from dynamicpdb_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (184_000_000 // 8,) * 8]
+    for q in ps:
+        q.grad = torch.randn_like(q)
+    opt = FusedAdam(ps, lr=1e-4, amsgrad=True)
+    opt.step()
+    t = timed(opt.step)
+    row("adam_amsgrad", t, sum(q.numel() for q in ps) * 4 * 8, "p, g, exp_avg, exp_avg_sq, max_exp_avg_sq read; all but g written")
+    tlog("hbm kernels: " + json.dumps({k: v["hbm_frac"] for k, v in out.items()}))
     return out
 
 
@@ -594,6 +750,9 @@ def main():
             line["triangle"] = triangle_roofline(dev)
         if not args.no_eval_config:
             line["config1_eval"] = config1_eval(dev, tlog, cpu=not args.no_cpu_baseline)
+        if not args.no_neighbours:
+            line["neighbours"] = neighbours(dev, tlog)
+            line["hbm_kernels"] = hbm_kernels(dev, tlog)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
     if rank == 0:

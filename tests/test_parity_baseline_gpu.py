@@ -122,17 +122,42 @@ def _report(stats, tag):
     return rel, nrm
 
 
-def _check_big(full, frames, tag):
-    """BASELINE-sized windows (hundreds of residues in the last frame).  Full loss: the torsion term's gradient ~ 1/|raw| is
-    dominated by the handful of torsions with a short raw 2-vector, where the forward's bf16-level difference changes the
-    gradient by O(1) -- measured at N_res 256 / 512: whole tensors move by tens of per cent, single AngleResnet / point
-    projection tensors by more than their norm.  So for the full loss only the typical tensor is asserted here (median of
-    the norm errors), its tight check being test_gradients_mask_aligned_oracle at this same size (<= 3e-2 per tensor);
-    the gradients of the reference's own torsion-free run are compared raw, at the class of the smaller goldens."""
+def _yardstick(ytag, which):
+    """(median, max) of the per-tensor relative L2 distance between the REFERENCE's own fp32 gradients and the same reference
+    code run with bf16 parameters and bf16-rounded nn.Linear / nn.Conv2d outputs (tests/golden/bf16_sensitivity*.npz, minted by
+    make_golden.py bf16_sensitivity): what the declared storage class costs the reference itself at this window."""
+    import os
+    from util import ROOT
+    for f in ("bf16_sensitivity.npz", "bf16_sensitivity_big.npz"):
+        d = np.load(os.path.join(ROOT, "tests", "golden", f))
+        if f"{ytag}/{which}/rel" in d.files:
+            rel = np.sort(d[f"{ytag}/{which}/rel"])
+            return float(rel[len(rel) // 2]), float(rel[-1])
+    raise KeyError(ytag)
+
+
+def _check_big(full, frames, tag, ytag, full_max=True):
+    """Raw parameter gradients (no mask feeding, every ReLU / min() branch free to differ) against the reference's fp32 run,
+    measured against the YARDSTICK of the storage class: the reference's own code with bf16 parameters and bf16-rounded
+    Linear / Conv outputs moves by median 0.02 .. 0.08 / max 0.07 .. 0.46 per tensor from its fp32 self (`_yardstick`).  SURVEY
+    8c's proposed "3e-2 for bf16 paths" is not attainable by the reference either; the engine has to be in the reference's
+    own bf16 class: median within 1.5 x and maximum within 2 x (3 x with the torsion term) of the yardstick -- for the torsion-free run at every size, for
+    the full loss where the torsion normalisation is not yet ill-conditioned (up to 32 x 128).  At 32 x 256 and 8 x 512 the
+    full-loss gradient ~ 1 / |raw| of the few short raw torsion vectors amplifies the engine's larger forward difference (it
+    also rounds the attention internals): only the typical tensor is asserted there (measured median 0.19 vs 0.076, maximum
+    3.9 vs 0.46 at 32 x 256), the tight statement at that size being test_gradients_mask_aligned_oracle (<= 3e-2 per tensor)."""
     rel, nrm = _report(full, tag + ", full loss")
-    assert nrm[len(nrm) // 2] < 5e-2 and rel[len(rel) // 2] < 0.25, (nrm[len(nrm) // 2], rel[len(rel) // 2])
+    ym, yx = _yardstick(ytag, "full")
+    print(f"[{tag}] yardstick (reference, bf16 storage vs fp32), full loss: median {ym:.4f} max {yx:.4f}")
+    assert nrm[len(nrm) // 2] < 5e-2
+    if full_max:
+        assert rel[len(rel) // 2] < 1.5 * ym + 5e-3 and rel[-1] < 3.0 * yx, (rel[len(rel) // 2], ym, rel[-1], yx)
+    else:
+        assert rel[len(rel) // 2] < 3.5 * ym, (rel[len(rel) // 2], ym)
     rel0, nrm0 = _report(frames, tag + ", torsion_loss_weight = 0")
-    assert nrm0[-1] < 0.1 and rel0[-1] < 0.4 and rel0[len(rel0) // 2] < 0.12, (rel0[len(rel0) // 2], rel0[-1], nrm0[-1])
+    ym0, yx0 = _yardstick(ytag, "notorsion")
+    print(f"[{tag}] yardstick, torsion_loss_weight = 0: median {ym0:.4f} max {yx0:.4f}")
+    assert nrm0[-1] < 0.1 and rel0[len(rel0) // 2] < 1.5 * ym0 + 5e-3 and rel0[-1] < 2.0 * yx0, (rel0[len(rel0) // 2], ym0, rel0[-1], yx0, nrm0[-1])
 
 
 def test_step_vs_reference_golden_config1():
@@ -142,7 +167,7 @@ def test_step_vs_reference_golden_config1():
     # (a flipped branch is an O(1) error on that unit).  The mask-aligned comparison below, at this same size, is the
     # tight one; the full-loss maximum sits on whichever AngleResnet tensor the ill-conditioned torsions hit (measured
     # 0.14 .. 0.33 across engine revisions whose mask-aligned error is unchanged), so it is asserted on the torsion-free run
-    _check_big(full, frames, "cfg1 F16 N96")
+    _check_big(full, frames, "cfg1 F16 N96", "F16_N96")
 
 
 def test_step_vs_reference_golden_nres256():
@@ -150,7 +175,7 @@ def test_step_vs_reference_golden_nres256():
     full, frames = _step_vs_golden("network_F2_N256.npz")
     # (2 frames: every gradient is a sum over the 256 positions of the last frame only; full loss: measured median 0.05, max
     # 0.31 .. 0.39 on an AngleResnet weight whose two ReLUs sit right in front of the ill-conditioned torsion normalisation)
-    _check_big(full, frames, "F2 N256")
+    _check_big(full, frames, "F2 N256", "F2_N256")
 
 
 def test_step_vs_reference_golden_config3_window():
@@ -159,13 +184,13 @@ def test_step_vs_reference_golden_config3_window():
     (train_DFOLD_dynamics.py:660-667,1182-1400; src/model/Dfold_network_dynamic.py:450-546): every output, the loss
     terms, every parameter gradient (norm + sampled entries)."""
     full, frames = _step_vs_golden("network_F32_N256.npz")
-    _check_big(full, frames, "cfg3 F32 N256")
+    _check_big(full, frames, "cfg3 F32 N256", "F32_N256", full_max=False)
 
 
 def test_step_vs_reference_golden_config2_window():
     """One window of BASELINE config 2 (32 frames x N_res 128) against the reference's own fp32 run."""
     full, frames = _step_vs_golden("network_F32_N128.npz")
-    _check_big(full, frames, "cfg2 F32 N128")
+    _check_big(full, frames, "cfg2 F32 N128", "F32_N128")
 
 
 def test_step_vs_reference_golden_config5_nres512():
@@ -175,7 +200,7 @@ def test_step_vs_reference_golden_config5_nres512():
     from dynamicpdb_amd import experiment, synthetic
     keep = {}
     full, frames = _step_vs_golden("network_F8_N512.npz", keep=keep)
-    _check_big(full, frames, "cfg5 F8 N512")
+    _check_big(full, frames, "cfg5 F8 N512", "F8_N512", full_max=False)
     del keep
     torch.cuda.empty_cache()
     dev = torch.device(DEV)
@@ -211,7 +236,8 @@ def test_res_mask_holes_vs_reference_golden():
     keep = {}
     stats = _step_vs_golden("network_F6_N40_holes.npz", keep=keep)
     rel, nrm = _report(stats, "holes F6 N40")
-    assert nrm[-1] < 0.1 and rel[-1] < 0.3 and rel[len(rel) // 2] < 0.12, (rel[len(rel) // 2], rel[-1], nrm[-1])
+    ym, yx = _yardstick("F6_N40_holes", "full")
+    assert nrm[-1] < 0.1 and rel[len(rel) // 2] < 1.5 * ym + 5e-3 and rel[-1] < 3.0 * yx, (rel[len(rel) // 2], ym, rel[-1], yx, nrm[-1])
     model, wd, out_all = keep["model"], keep["window"], keep["out"]
     assert float(wd["res_mask"].min()) == 0 and float(wd["res_mask"][:, 0].max()) == 0 and float(wd["res_mask"][:, -1].max()) == 0
     g_all = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
