@@ -615,13 +615,17 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     // the fixed order z = 0 .. S-1 and goes on to the epilogue, the others are done.
     const int S = gridDim.y;
     const long tile_elems = (long)BM3 * BNW;
-    float* slot = p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + (long)w * (2 * NJ * 1024) + lane;
+    // partial tiles as 16-byte vectors per lane ([accumulator tile][quad of registers][lane][4]): with 4-byte elements the
+    // reduction below was 160 S dependent dword loads per lane -- the last arriver of a 20-way split took ~0.2 ms per launch
+    float* slot = p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + (long)w * (2 * NJ * 1024) + lane * 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) slot[((i * NJ + j) * 16 + e) * 64] = acc[i][j][e];
+        for (int q4 = 0; q4 < 4; ++q4)
+          *(f32x4*)(slot + ((i * NJ + j) * 4 + q4) * 256) =
+              (f32x4){acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
     __threadfence();
     __syncthreads();
     __shared__ int s_last;
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    const float* part = p.ws + (long)lid * tile_elems + (long)w * (2 * NJ * 1024) + lane;
+    const float* part = p.ws + (long)lid * tile_elems + (long)w * (2 * NJ * 1024) + lane * 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -643,7 +647,11 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] += pz[((i * NJ + j) * 16 + e) * 64];
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = *(const f32x4*)(pz + ((i * NJ + j) * 4 + q4) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][4 * q4 + r] += v[r];
+          }
     }
     if (tid == 0) p.cnt[lid] = 0;   // counters are left clean for the next launch
   }

@@ -78,11 +78,17 @@ class SE3Diffuser:
         return self._so3_diffuser.torch_score(host_math.quat_to_rotvec(
             host_math.quat_multiply(host_math.invert_quat(quats_0), quats_t)), t)
 
-    def calc_rot_score_t7(self, quats_t, quats_0, t):
+    def calc_rot_score_t7(self, quats_t, quats_0, t, t_host=None):
         """Device path on raw quaternion tensors; the leading axis enumerates the windows of `t`
-        ([F,N,4] with t [1] as in the reference, or [B,F,N,4] with t [B])."""
+        ([F,N,4] with t [1] as in the reference, or [B,F,N,4] with t [B]).  t_host: the same diffusion times as host numbers
+        (the sigma of the series is a table look-up on the host, so3_diffuser.py:188-190) -- given by a caller that knows them
+        (the sampler, a data loader), it saves the device -> host copy of `t`, i.e. one stream synchronisation per forward,
+        and makes the forward capturable in a HIP graph."""
         from ..model import score_heads
-        t_np = np.atleast_1d(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+        if t_host is not None:
+            t_np = np.atleast_1d(np.asarray(t_host, dtype=np.float64))
+        else:
+            t_np = np.atleast_1d(t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
         so3 = self._so3_diffuser
         sigma = so3.discrete_sigma[so3.t_to_idx(t_np)]
         if len(sigma) == 1 and quats_t.dim() == 3:

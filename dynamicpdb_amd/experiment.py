@@ -127,8 +127,10 @@ class Trainer:
 
 def set_t_feats(diffuser, feats, t, like):
     """Experiment._set_t_feats (train_DFOLD_dynamics.py:1408-1413) for a batch of windows sharing one t."""
+    import numpy as np
     rs, ts = diffuser.score_scaling(t)
     feats['t'] = torch.full_like(like, float(t))
+    feats['t_host'] = np.full(tuple(like.shape), float(t))      # (the forward then needs no device -> host copy of t)
     feats['rot_score_scaling'] = torch.full_like(like, float(rs))
     feats['trans_score_scaling'] = torch.full_like(like, float(ts))
     return feats

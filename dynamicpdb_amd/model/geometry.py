@@ -29,7 +29,8 @@ def quat_mul(p, q):
 
 def quat_invert(q):
     """openfold/utils/rigid_utils.py:282-286"""
-    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0]) / (q * q).sum(-1, keepdim=True)
+    # (no constant tensor built from a Python list: that is a host -> device copy in every forward, and not capturable)
+    return torch.cat([q[..., :1], -q[..., 1:]], -1) / (q * q).sum(-1, keepdim=True)
 
 
 def rot_apply(R, x):

@@ -304,7 +304,8 @@ class DFOLDIpaScore(nn.Module):
         else:
             unorm_angles, angles = self.angle_resnet(node_feat, init_node_feat)
         t = input_feats['t'].reshape(B)
-        rot_score = self.diffuser.calc_rot_score_t7(rigids_t[..., :4], curr_rigids[..., :4], t) * node_mask[..., None]
+        rot_score = self.diffuser.calc_rot_score_t7(rigids_t[..., :4], curr_rigids[..., :4], t,
+                                                    t_host=input_feats.get('t_host')) * node_mask[..., None]
         curr_rigids = self.unscale_rigids(curr_rigids)
         trans_score = self.diffuser.calc_trans_score(rigids_t[..., 4:], curr_rigids[..., 4:], t[:, None, None, None],
                                                      use_torch=True) * node_mask[..., None]

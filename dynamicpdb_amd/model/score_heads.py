@@ -16,9 +16,25 @@ def series_envelope(sigma, L=1000):
     return (2 * ls + 1)[None, :] * np.exp(-ls[None, :] * (ls[None, :] + 1) * sigma[:, None] ** 2 / 2)
 
 
+_ENV_CACHE = {}
+
+
+def _envelope_on_device(sigma, L, device):
+    """the series envelope of a tuple of sigmas as a device tensor, cached: the sampler visits num_t diffusion times and a
+    training run a discretised schedule of 1000 sigmas, so the host series + its upload (a synchronous copy in every forward,
+    which also keeps the forward out of HIP graphs) happens once per distinct value"""
+    key = (tuple(np.atleast_1d(np.asarray(sigma, dtype=np.float64)).tolist()), L, str(device))
+    env = _ENV_CACHE.get(key)
+    if env is None:
+        if len(_ENV_CACHE) > 4096:
+            _ENV_CACHE.clear()
+        env = _ENV_CACHE[key] = torch.tensor(series_envelope(sigma, L), dtype=torch.float64, device=device)
+    return env
+
+
 def igso3_score(vec, sigma, eps=1e-6, L=1000):
     """vec [W, ..., 3] fp32 (window axis first), sigma [W] float64 (host) -> float64 score vectors."""
-    env = torch.tensor(series_envelope(sigma, L), dtype=torch.float64, device=vec.device)
+    env = _envelope_on_device(sigma, L, vec.device)
     W = env.shape[0]
     omega = torch.linalg.norm(vec, dim=-1) + eps
     if omega.numel() % W:

@@ -275,7 +275,8 @@ def conv_splitk(M, CO, CI, device):
     for S in (2, 4, 5, 10, 20):
         if chunks % S or steps // S < 25 or tiles * S > _SPLITK_CAP * n_cu:
             continue
-        cost = -(-tiles * S // n_cu) * (steps // S + 16)
+        # (+ 2 S: the last arriver adds the S partial tiles alone, ~2 K steps' worth of time per partial)
+        cost = -(-tiles * S // n_cu) * (steps // S + 16 + 2 * S)
         if cost < 0.9 * best_cost:
             best, best_cost = S, cost
     return best
@@ -307,7 +308,9 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     nf = g.F - f_lo if nf is None else nf
     M = g.Wn * nf * g.N
     S, sk = 1, {}
-    if ws is not None and nf < g.F:        # frame sub-range launches (last-frame mode): split K where the grid is thin
+    if ws is not None:        # thin grids split K: the frame sub-range launches of the last-frame mode, and every launch of a small
+        # window -- BASELINE config 1 (16 x 96: 12 / 24 output tiles for 256 CUs) ran its 32 conv launches at 5 % of the chip,
+        # 13 of the 15.6 ms of a sampler forward (conv_splitk returns 1 wherever the tiles fill the CUs: the headline shapes)
         S = conv_splitk(M, CO, CI, x.device)
         if S > 1:
             tiles = ((M + 255) // 256) * (CO // 320)
@@ -607,7 +610,7 @@ class ConvTower:
         for i in range(4):
             (l1, n1), (l2, n2) = self.cone(g.F, i) if last_frame_only else ((0, g.F), (0, g.F))
             u = self.grid(g, C // 2, slot, "u%d" % i, last_frame_only)
-            ws = self.ws if last_frame_only else None
+            ws = self.ws          # thin launches split K: the cone of the training-step mode, and whole small windows (eval)
             conv5x5_fwd(g, h, self.wf[2 * i], self.biases[2 * i], u, relu=True, f_lo=l1, nf=n1, ws=ws)
             hn, v = self.grid(g, C, slot, "h%d" % i, last_frame_only), self.grid(g, C, slot, "v%d" % i, last_frame_only)
             conv5x5_fwd(g, u, self.wf[2 * i + 1], self.biases[2 * i + 1], hn, relu=True, resid=h, pre_resid_out=v,
@@ -647,7 +650,7 @@ class ConvTower:
                 l0 = g.F - n0
             self._wgrad(g, 2 * i + 1, u, dv, l2, n2, finalize)
             du = ws.get("du", tuple(u.shape))
-            sws = ws if last_frame_only else None
+            sws = ws
             conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws)
             self._wgrad(g, 2 * i, hprev, du, l1, n1, finalize)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
