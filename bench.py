@@ -81,7 +81,7 @@ def make_batches(synthetic, diffuser, B, F, N, rank, dev, count, same):
 
 
 def conv_kernel_roofline(model, trainer, batch, B, F, N):
-    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_mfma_gemm320_kernel<1>)
+    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_conv_w4_kernel)
     of ONE extra, instrumented step, measured with HIP events on the stream the kernels are launched on."""
     from dynamicpdb_amd import ops
     events = []
@@ -129,7 +129,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     traffic, traffic_source = None, None
     # HBM-side bytes per launch: NOT measured in this run (rocprofv3 counter passes cannot ride on a timed run) but read
     # from the newest committed PMC pass of the same kernel at the same shape; `traffic_source` names the file
-    for tag in ("r4", "r3"):
+    for tag in ("r5", "r4", "r3"):
         pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_conv.json")
         if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
             with open(pmc) as fh:
@@ -149,12 +149,13 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
                   "avg_launch_ms": round(wavg * 1e3, 4), "flop_per_launch": flops}
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "dfold_mfma_gemm320_kernel<1, 5, true> (5x5 conv implicit GEMM, halo form, forward + dgrad launches)", "launches": len(ms),
+            "kernel": "dfold_conv_w4_kernel (5x5 conv implicit GEMM, one wave per SIMD, 512 x 160 tile, 32-channel halo groups; "
+                      "forward + dgrad launches; DFOLD_CONV_W4=0: dfold_mfma_gemm320_kernel<1, 5, true>)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
             "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "
-                    "binary on all-zero operands runs 1.85 PFLOP/s = 0.74 of the peak (scripts/exp_conv_dvfs.py), hipBLASLt "
-                    "on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s (scripts/bench_conv.py library); "
-                    "DESIGN.md section 5"}
+                    "binary on all-zero operands runs 2.13 PFLOP/s = 0.85 of the peak, on dense random operands 1.44-1.46 "
+                    "(scripts/exp_conv_dvfs.py); hipBLASLt on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s "
+                    "(scripts/bench_conv.py library); DESIGN.md section 5"}
 
 
 def triangle_roofline(dev, reps=10):

@@ -10,10 +10,10 @@ run() {  # $1 = tag, rest = counters
   tag=$1; shift
   rm -rf /tmp/pmc_$tag
   timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- \
-      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-triangle --no-other-configs > /tmp/pmc_$tag.log 2>&1 < /dev/null
+      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-triangle --no-other-configs --no-eval-config --no-neighbours > /tmp/pmc_$tag.log 2>&1 < /dev/null
   echo "pmc $tag rc=$?"
-  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/pmc_$tag "$R/gpurun_out/${PROF_TAG:-r4}_pmc_$tag.json" > "$R/gpurun_out/${PROF_TAG:-r4}_pmc_$tag.txt" 2>&1 < /dev/null
-  head -n 3 "$R/gpurun_out/${PROF_TAG:-r4}_pmc_$tag.txt" | cut -c1-260
+  timeout 60 python "$R/scripts/pmc_summary.py" /tmp/pmc_$tag "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.json" > "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.txt" 2>&1 < /dev/null
+  head -n 3 "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.txt" | cut -c1-260
 }
 run fetch_hit FETCH_SIZE TCC_HIT_sum
 run write_miss_req WRITE_SIZE TCC_MISS_sum TCC_REQ_sum

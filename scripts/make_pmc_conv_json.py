@@ -19,7 +19,10 @@ def entry(key, name):
             "TCC_REQ": w["TCC_REQ_sum"], "TCC_HIT": f["TCC_HIT_sum"], "TCC_MISS": w["TCC_MISS_sum"]}
 
 
-out = entry("dfold_mfma_gemm320_kernel<1, 5, true>", "dfold_mfma_gemm320_kernel<1, 5, true> (halo form)")
+try:
+    out = entry("dfold_conv_w4_kernel", "dfold_conv_w4_kernel (one wave per SIMD, 512 x 160 tile)")
+except StopIteration:      # passes taken with DFOLD_CONV_W4=0 / before round 5
+    out = entry("dfold_mfma_gemm320_kernel<1, 5, true>", "dfold_mfma_gemm320_kernel<1, 5, true> (halo form)")
 out["note"] = ("rocprofv3 --pmc, two passes (FETCH_SIZE TCC_HIT_sum | WRITE_SIZE TCC_MISS_sum TCC_REQ_sum; scripts/gpu_pmc.sh -> "
                f"profiles/{tag}_pmc_fetch_hit.txt, {tag}_pmc_write_miss_req.txt), averages per launch over the conv forward+dgrad launches of "
                "the all-frames update_fn steps of the pass at BASELINE config 3; FETCH_SIZE is doubled when converted to bytes (gfx950 "
