@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
   // measured: no gain, +16 VGPRs)
   f32x4 zrA[2][2];
   float mkA[2] = {0.f, 0.f};
-  auto issue = [&](unsigned t, f32x4 (&zr)[2][2], float (&mk)[2]) __attribute__((always_inline)) {
+  auto issue = [&](unsigned t, f32x4 (&zr)[2][2], float (&mk)[2], int only = -1) __attribute__((always_inline)) {
     const int pt = (int)(t % (unsigned)tpl);
     const unsigned bl = t / (unsigned)tpl;
     const int line = (int)(bl % (unsigned)N), b = (int)(bl / (unsigned)N);
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     const char* base = (const char*)p.x + cell0 * (128 * (long)esz);     // wave-uniform
 #pragma unroll
     for (int qd = 0; qd < 2; ++qd) {
+      if (only >= 0 && qd != only) continue;       // (MODE 0 spreads the two quads over the MFMA phase)
       // cells past the row end re-read the last valid cell: their mask is zero (a = b = 0) and their rows are not stored
       int r = w * 8 + qd * 4 + l4;
       const int over = pt * PP_TILE + r - (N - 1);
@@ -251,6 +252,35 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     }
   };
 
+  // MODE 0: the same stream-out in three parts (plane vectors 0-1, 2-3, the two gate vectors), staged reads and stores as separate
+  // calls, so that the tile loop can spread them over the MFMA / gate phase of the next tile (with everything in one burst
+  // behind the barrier the CU's one memory path and its eight waves took turns: memory-only 0.135 ms, compute-only 0.123 ms,
+  // together 0.177 ms per call at batch 8 x N_res 256, scripts/make_pairproj_lab.py)
+  u32x4 spv[2];
+  auto stream_read = [&](int part, int par) __attribute__((always_inline)) {
+    const char* const ldsS = ldsS2 + par * PP_STAGE0;
+    const char* const ldsG0 = ldsS + 256 * PP_SPITCH;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int id = tid + 512 * (part < 2 ? 2 * part + k : k);
+      spv[k] = part < 2 ? *(const u32x4*)(ldsS + (id >> 3) * PP_SPITCH + (id & 7) * 16) : *(const u32x4*)(ldsG0 + (id >> 4) * PP_GPITCH + (id & 15) * 16);
+    }
+  };
+  auto stream_store = [&](int part, int b, int line, int pt) __attribute__((always_inline)) {
+    const int pos0 = pt * PP_TILE;
+    if (part < 2) {
+      char* const pbase = (char*)p.o0 + ((((long)b * N + line) * 256) * NP + pos0) * 2;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) *(u32x4*)(pbase + voff_pl[2 * part + k]) = spv[k];
+    } else {
+      const long cell0 = p.swap ? ((long)b * N + pos0) * N + line : ((long)b * N + line) * N + pos0;
+      char* const gbase = (char*)p.o1 + cell0 * 256;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (pos0 + ((tid + 512 * k) >> 4) < N) *(u32x4*)(gbase + voff_cl[k]) = spv[k];
+    }
+  };
+
   // Per tile t: [LayerNorm(t) -> A[par]] | barrier | [prefetch rows of t+1] [stores of tile t-1 from the staging
   // area] | barrier | [MFMA + gates(t) -> staging].  Loads and stores are both issued right before the MFMA phase and
   // nothing waits on the memory counter until the next tile's LayerNorm, so neither latency sits on the critical path
@@ -314,11 +344,26 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
     // (this tile's rows have been consumed above.  Unconditional: after the last tile it re-reads that tile -- under
     //  `if (t + gridDim.x < ntiles)` the loaded registers reach the loop-carried ones through copies, and the wait for those
     //  copies sat HERE, in front of the MFMA phase: the prefetch never overlapped anything)
-    issue(t + gridDim.x < ntiles ? t + gridDim.x : t, zr, mk);
-    if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
+    const unsigned tnext = t + gridDim.x < ntiles ? t + gridDim.x : t;
+    if (MODE == 1) {
+      issue(tnext, zr, mk);
+      if (have_prev) stream_out(pb, pline, ppt, par ^ 1);
+      __syncthreads();
+    }
     // MODE 0: the staging area alternates with the tile parity, so this tile's results go where tile t - 2's were read from
-    // before every wave's barrier above -- no second barrier per tile
-    if (MODE == 1) __syncthreads();
+    // before every wave's barrier above -- no second barrier per tile; its loads and stores are spread over S2 (mem_slot)
+    auto mem_slot = [&](int rt, int q) __attribute__((always_inline)) {
+      if (MODE != 0) return;
+      if (rt == 0 && q == 0) issue(tnext, zr, mk, 0);
+      if (rt == 0 && q == 1) issue(tnext, zr, mk, 1);
+      if (!have_prev) return;
+      if (rt == 0 && q == 2) stream_read(0, par ^ 1);
+      if (rt == 1 && q == 0) stream_store(0, pb, pline, ppt);
+      if (rt == 1 && q == 1) stream_read(1, par ^ 1);
+      if (rt == 1 && q == 3) stream_store(1, pb, pline, ppt);
+      if (rt == 2 && q == 0) stream_read(2, par ^ 1);
+      if (rt == 2 && q == 2) stream_store(2, pb, pline, ppt);
+    };
     char* const ldsS = ldsS2 + par * PP_STAGE0;
     char* const ldsG0 = ldsS + 256 * PP_SPITCH;
 
@@ -378,6 +423,7 @@ __global__ __launch_bounds__(512) void pair_proj_kernel(const PairProjParams p) 
         // tile rt issue on the VALU while they run
         if (rt + 1 < 4) mma_ks(q, afn, nxt);
         gate_row(rt, q, cur);
+        mem_slot(rt, q);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (rt + 2 < 4) frags_rt(rt + 2, (rt & 1) ? afB : afA);
