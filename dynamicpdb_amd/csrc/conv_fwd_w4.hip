@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   const int tiles_n = p.N / W4_BN;
   const int m0 = (lid / tiles_n) * W4_BM, n0 = (lid % tiles_n) * W4_BN;
   const int M = p.M;
-  const char* A = (const char*)p.A;
-  const char* B = (const char*)p.B;
+  // (split-K launches: part blockIdx.y walks its own range of channel chunks -- p.nseg, p.sa0, p.sb0 are per part)
+  const char* A = (const char*)p.A + (long)blockIdx.y * p.sa0 * 2;
+  const char* B = (const char*)p.B + (long)blockIdx.y * p.sb0 * 2;
 
   // ---- K walk: groups (chunk c, frame tap df, channel half h), h fastest; five residue taps dn inside a group ----
   const long a_s0 = p.a_seg_s0, a_s1 = p.a_seg_s1, b_s0 = p.b_seg_s0, b_s1 = p.b_seg_s1;
@@ -255,15 +256,65 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   // the surplus prefetches must have landed before the LDS is reused; MFMA results are read by VALU below
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();
+  if (p.ws != nullptr) {
+    // Deterministic split-K (thin launches: the cone of the training-step mode, small eval windows), as in the 256 x 320 kernel:
+    // every part parks its fp32 partial tile in the workspace (16-byte vectors per lane), the last part to arrive adds them in
+    // the fixed order z = 0 .. S-1 and runs the epilogue.  The 512 x 160 tile has as many elements as a 256 x 320 one.
+    const int S = gridDim.y;
+    const long tile_elems = (long)W4_BM * W4_BN;
+    float* slot = p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + (long)w * (20 * 1024) + lane * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            *(f32x4*)(slot + (((a * 2 + i) * 5 + j) * 4 + q4) * 256) =
+                (f32x4){acc[a][i][j][4 * q4], acc[a][i][j][4 * q4 + 1], acc[a][i][j][4 * q4 + 2], acc[a][i][j][4 * q4 + 3]};
+    __threadfence();
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) s_last = atomicAdd(p.cnt + lid, 1) == S - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const float* part = p.ws + (long)lid * tile_elems + (long)w * (20 * 1024) + lane * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
+    for (int z = 0; z < S; ++z) {
+      const float* pz = part + (long)z * nwg * tile_elems;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const f32x4 v = *(const f32x4*)(pz + (((a * 2 + i) * 5 + j) * 4 + q4) * 256);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[a][i][j][4 * q4 + r] += v[r];
+            }
+    }
+    if (tid == 0) p.cnt[lid] = 0;   // counters are left clean for the next launch
+  }
   char* wave_lds = wl + w * (32 * EPI_ROWB(5) + 256);
   gemm_epilogue_lds_bf16<5>(p, acc[0], (long)m0 + w * 128, n0, 0, lane, wave_lds);
   gemm_epilogue_lds_bf16<5>(p, acc[1], (long)m0 + w * 128 + 64, n0, 0, lane, wave_lds);
 }
 
 // host side: called by dfold_gemm_bf16 for the conv launches that qualify (see there)
-int dfold_conv_w4_launch(const GemmParams& p, hipStream_t stream) {
+int dfold_conv_w4_launch(const GemmParams& p, int splitk, hipStream_t stream) {
   DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel, W4_LDS_BYTES);
   const unsigned tiles = (unsigned)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
-  DFOLD_LAUNCH(dfold_conv_w4_kernel, dim3(tiles), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  DFOLD_LAUNCH(dfold_conv_w4_kernel, dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
   return dfold_check_launch();
 }

@@ -760,9 +760,12 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       const char* e = getenv("DFOLD_CONV_W4");
       w4_mode = e ? atoi(e) : 1;
     }
-    if (halo && w4_mode && S == 1 && d->nbatch == 1 && (d->N % 160) == 0 && d->a_seg_s0 == BK && d->b_seg_s0 == BK &&
-        (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0)
-      return dfold_conv_w4_launch(p, (hipStream_t)stream);
+    // (split launches too, as long as the 512 x 160 tiling needs no more partial-tile slots / counters than the 256 x 320 one
+    //  the caller sized the workspace for: an odd number of 256-row runs stays on the kernel below)
+    const long tiles_w4 = (long)((d->M + 511) / 512) * (d->N / 160);
+    if (halo && w4_mode && d->nbatch == 1 && (d->N % 160) == 0 && d->a_seg_s0 == BK && d->b_seg_s0 == BK &&
+        (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 && (S == 1 || tiles_w4 <= tiles320 || w4_mode == 2))
+      return dfold_conv_w4_launch(p, S, (hipStream_t)stream);
     if (halo)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5, true>), grid3, dim3(512), (size_t)HALO_LDS, (hipStream_t)stream, p);
     else if (role == 1)

@@ -192,4 +192,4 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
 }
 
 // conv_fwd_w4.hip: the one-wave-per-SIMD 512 x 160 form of the 5x5 conv launch (dispatched from dfold_gemm_bf16)
-int dfold_conv_w4_launch(const GemmParams& p, hipStream_t stream);
+int dfold_conv_w4_launch(const GemmParams& p, int splitk, hipStream_t stream);

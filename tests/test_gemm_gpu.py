@@ -377,6 +377,32 @@ def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
         ops.conv5x5_fwd(g, x, wf, bias, o, relu=True, f_lo=F - 3, nf=3)
         assert rel_l2(g.interior(o)[:, F - 3:], (lin + bias.double()).clamp_min(0)[:, F - 3:]) < 4e-3
         assert float(o[:, : 2 + F - 3].abs().max()) == 0
+    # (f) deterministic split-K on this kernel (thin launches: the cone of the training-step mode): against the unsplit launch,
+    # every epilogue, reproducible bit for bit, counters left clean
+    Wn, F, N, CI, CO = 8, 6, 256, 640, 640
+    g = ops.Grid(Wn, F, N, dev)
+    w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+    wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+    bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+    x, r = g.alloc(CI), g.alloc(CO)
+    g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16))
+    g.interior(r).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+    ws = ops.Workspace(dev)
+    assert ops.conv_splitk(Wn * 2 * N, CO, CI, dev) > 1
+    for kw in (dict(relu=True), dict(relu=True, resid=r, pre_resid_out="c2"), dict(relu=False, relu_mask=r)):
+        outs = []
+        for use_ws in (None, ws, ws):
+            o, c2 = g.alloc(CO), g.alloc(CO)
+            k = {a: (c2 if b == "c2" else b) for a, b in kw.items()}
+            ops.conv5x5_fwd(g, x, wf, bias if kw.get("relu") else None, o, f_lo=F - 2, nf=2, ws=use_ws, **k)
+            outs.append((o, c2))
+        (o0, c0), (o1, c1), (o2, c2_) = outs
+        assert float(o0[:, 2 + F - 2:2 + F].abs().max()) > 0 and rel_l2(o1, o0) < 4e-3, sorted(kw)
+        assert torch.equal(o1, o2) and torch.equal(c1, c2_)
+        assert float(o1[:, : 2 + F - 2].abs().max()) == 0
+    assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
 
 
 def test_convnet_vs_oracle_golden(dev):
