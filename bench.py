@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--selftest-dist", action="store_true",
                     help="only rendezvous (nccl with GPUs, gloo without), all-reduce one number, report n_gpus")
     ap.add_argument("--no-last-frame-mode", action="store_true", help="skip the second timed region (profiling runs)")
+    ap.add_argument("--no-all-positions-mode", action="store_true",
+                    help="skip the third timed region (trunk without dead-code elimination; profiling runs)")
     ap.add_argument("--no-triangle", action="store_true", help="skip the triangle-operator extra object")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 2 / config 5 extra objects")
     ap.add_argument("--no-eval-config", action="store_true", help="skip the config 1 (eval / sampling) extra object")
@@ -96,7 +98,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         e0.record()
         r = orig(*a, **kw)
         e1.record()
-        events.append((e0, e1))
+        events.append((e0, e1, int(a[3])))          # a[3] = M (output positions of the launch)
         return r
 
     ops.gemm = timed_gemm
@@ -111,7 +113,8 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         e0.record()
         rc = wg_orig(*a)
         e1.record()
-        wg_events.append((e0, e1))
+        nf_arg = a[10]                                # (A, B, dWg, CA, CB, W, Fp, Wp, N, f0, nf, ...): frames of the launch
+        wg_events.append((e0, e1, int(getattr(nf_arg, "value", nf_arg))))
         return rc
 
     L.dfold_conv_wgrad_tn = timed_wgrad
@@ -121,8 +124,13 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     finally:
         ops.gemm = orig
         del L.dfold_conv_wgrad_tn        # the exported function is visible again
-    wg_ms = [e0.elapsed_time(e1) for e0, e1 in wg_events]
-    ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    # the roofline is quoted on the FULL-SIZE launches (every position of the batch: blocks 0 and 3 of the trunk, and all four
+    # with DFOLD_TRUNK_DCE=0); the inner blocks' launches cover the last frame's dependency cone only and are listed beside it
+    m_full, nf_full = max(m for _, _, m in events), max(n for _, _, n in wg_events) if wg_events else 0
+    ms_cone = [e0.elapsed_time(e1) for e0, e1, m in events if m != m_full]
+    wg_cone = [e0.elapsed_time(e1) for e0, e1, n in wg_events if n != nf_full]
+    wg_ms = [e0.elapsed_time(e1) for e0, e1, n in wg_events if n == nf_full]
+    ms = [e0.elapsed_time(e1) for e0, e1, m in events if m == m_full]
     avg_s = sum(ms) / len(ms) * 1e-3
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
@@ -152,6 +160,14 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
             "kernel": "dfold_conv_w4_kernel (5x5 conv implicit GEMM, one wave per SIMD, 512 x 160 tile, 32-channel halo groups; "
                       "forward + dgrad launches; DFOLD_CONV_W4=0: dfold_mfma_gemm320_kernel<1, 5, true>)", "launches": len(ms),
             "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
+            "cone_launches": {"what": "launches of the trunk's inner blocks (dependency cone of the last frame: 1 ... 15 of the "
+                                      "frames per layer, split-K when thin): same kernels, not part of `achieved`",
+                              "conv_fwd_dgrad": len(ms_cone), "conv_fwd_dgrad_total_ms": round(sum(ms_cone), 3),
+                              "wgrad": len(wg_cone), "wgrad_total_ms": round(sum(wg_cone), 3)},
+            "full_launches_total_ms": {"conv_fwd_dgrad": round(sum(ms), 3), "wgrad": round(sum(wg_ms), 3)},
+            # what a rocprofv3 --stats row of the same step averages over (full-size and cone launches of one kernel name)
+            "all_launches_avg_ms": {"dfold_conv_w4_kernel": round((sum(ms) + sum(ms_cone)) / max(1, len(ms) + len(ms_cone)), 4),
+                                    "conv_wgrad_tn_kernel": round((sum(wg_ms) + sum(wg_cone)) / max(1, len(wg_ms) + len(wg_cone)), 4)},
             "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "
                     "binary on all-zero operands runs 2.13 PFLOP/s = 0.85 of the peak, on dense random operands 1.44-1.46 "
                     "(scripts/exp_conv_dvfs.py); hipBLASLt on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s "
@@ -339,7 +355,7 @@ def hbm_kernels(dev, tlog, reps=10):
     ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (184_000_000 // 8,) * 8]
     for q in ps:
         q.grad = torch.randn_like(q)
-    opt = FusedAdam(ps, lr=1e-4, amsgrad=True)
+    opt = FusedAdam(ps, lr=1e-4)                     # (always amsgrad, as the reference's Adam(amsgrad=True), train_DFOLD_dynamics.py:412)
     opt.step()
     t = timed(opt.step)
     row("adam_amsgrad", t, sum(q.numel() for q in ps) * 4 * 8, "p, g, exp_avg, exp_avg_sq, max_exp_avg_sq read; all but g written")
@@ -452,13 +468,21 @@ def config1_eval(dev, tlog, cpu=True):
         ms_rev = timed(lambda: diffuser.reverse_t7(feats["rigids_t"], out["rot_score"], out["trans_score"], 0.5, 1.0 / num_t,
                                                    diffuse_mask=torch.ones(F, N, device=dev), center=True, noise_scale=noise, rng=rng),
                        reps=20)
+    # eight samples of the same protein as ONE batch of windows (the engine's window axis; the reference samples them one by one)
+    B8 = 8
+    init8 = {k: (v[None].expand((B8,) + tuple(v.shape)).contiguous() if k != "t" else v.expand(B8).contiguous()) for k, v in init.items()}
+    np.random.seed(92)
+    init8["rigids_t"] = diffuser.sample_ref(n_samples=B8 * F * N, as_tensor_7=True)["rigids_t"].reshape(B8, F, N, 7).float().to(dev)
+    ms_b8 = timed(lambda: experiment.inference_fn(model, diffuser, init8, rng=DeviceRNG(seed=7, device=dev), **kw), reps=2) / B8
     tlog(f"config 1 eval: {ms_dev:.1f} ms per sample (device draws), {ms_inj:.1f} ms (numpy draws), forward {ms_fwd:.2f} ms, "
-         f"reverse step {ms_rev:.3f} ms")
+         f"reverse step {ms_rev:.3f} ms, {ms_b8:.1f} ms per sample in a batch of {B8}")
     res = {"workload": "BASELINE config 1 (the reference's eval configuration): 1 window, 16 frames x N_res 96, inference_fn with "
                        "num_t = 10, noise_scale 0.1, self-conditioning pass; random-init seeded weights, synthetic window",
            "ms_per_sample_device_rng": round(ms_dev, 2), "ms_per_sample_numpy_draws": round(ms_inj, 2),
            "ms_per_model_forward": round(ms_fwd, 3), "ms_per_reverse_step_kernel": round(ms_rev, 4),
-           "frames_per_s_sampled": round(F / (ms_dev * 1e-3), 1), "model_forwards_per_sample": num_t + 1, "reverse_steps_per_sample": num_t - 1}
+           "ms_per_sample_batch8": round(ms_b8, 2), "frames_per_s_sampled": round(F / (ms_dev * 1e-3), 1),
+           "frames_per_s_sampled_batch8": round(F / (ms_b8 * 1e-3), 1), "model_forwards_per_sample": num_t + 1,
+           "reverse_steps_per_sample": num_t - 1}
     del model
     torch.cuda.empty_cache()
     if cpu:
@@ -509,6 +533,7 @@ def config1_eval(dev, tlog, cpu=True):
                                          f"warm-up; a full sample = {num_t + 1} forwards + {num_t - 1} reverse steps",
                                "ms_per_sample_extrapolated": round(per * 1e3 * (num_t + 1), 0)}
         res["speedup_vs_cpu_per_sample"] = round(per * 1e3 * (num_t + 1) / ms_dev, 1)
+        res["speedup_vs_cpu_per_sample_batch8"] = round(per * 1e3 * (num_t + 1) / ms_b8, 1)
     return res
 
 
@@ -708,10 +733,29 @@ def main():
             dist.all_reduce(el2, op=dist.ReduceOp.MAX)
         el2 = float(el2)
         tlog(f"training-step mode (last-frame dependency cone): {el2 / args.steps * 1e3:.1f} ms/step")
+    # third timed region: the trunk WITHOUT its dead-code elimination (every block of the conv tower on every position, the
+    # reference's eager graph; the headline of rounds 1-4).  Same outputs and gradients as the headline step
+    # (tests/test_network_gpu.py::test_trunk_dead_code_elimination_equals_all_positions).
+    el3 = None
+    dce = bool(model.score_model.trunk_dce)
+    if dce and not args.no_all_positions_mode and args.mode == "all_frames":
+        model.score_model.trunk_dce = False
+        trainer.last_frame_only = False
+        trainer.reducer.reset_structure()
+        trainer.update_fn(batches[0])
+        trainer.update_fn(batches[0])
+        el3, _ = timed_steps(trainer, batches[1:1 + args.steps], args.steps, sync)
+        el3 = torch.tensor([el3], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el3, op=dist.ReduceOp.MAX)
+        el3 = float(el3)
+        model.score_model.trunk_dce = True
+        tlog(f"all-positions mode (no dead-code elimination in the trunk): {el3 / args.steps * 1e3:.1f} ms/step")
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * F * args.steps / elapsed
-        step_flop = 3.0 * synthetic.step_flops_fwd(F, N) * B
+        step_flop = 3.0 * synthetic.step_flops_fwd(F, N, inner_cone=dce) * B
+        step_flop_all = 3.0 * synthetic.step_flops_fwd(F, N) * B
         tlog("roofline: %s" % json.dumps(roof))
         line = {
             "metric": "trajectory_frames_per_sec_fwd_bwd_nres%d" % N, "value": round(value, 2), "unit": "frames/s",
@@ -721,13 +765,28 @@ def main():
                                    "update_fn (fwd+loss+bwd+grad all-reduce+Adam amsgrad), random-init seeded weights, %s"
                                    % (N, F, B, "one batch repeated" if args.same_batch else
                                       "a fresh synthetic batch every step (staged in HBM before the timed region)"),
-                       "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world, "mode": args.mode},
+                       "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world, "mode": args.mode,
+                       "trunk_dead_code_elimination": dce,
+                       "trunk_dead_code_elimination_note":
+                           "on (product default): the node features of trunk blocks 1 and 2 feed only bb_update, whose output is "
+                           "multiplied by 0.0 on every frame but the last (reference ipa_pytorch_dynamic.py:858-869), so their conv "
+                           "tower runs on the last frame's dependency cone; every output (all keys, all frames), the loss and "
+                           "every gradient equal the all-positions evaluation (`all_positions_mode` below times that one; "
+                           "DFOLD_TRUNK_DCE=0 makes it the default)"},
             "loss": {"first_step": round(first_loss, 5), "last_step": round(float(loss), 5),
                      "steps_between": args.warmup + args.steps - 1},
             # whole step against the MFMA peak: algorithmic fwd+bwd FLOPs of the step / step time / 2.5 PF
             "step_tflop_per_gpu": round(step_flop / 1e12, 2),
             "step_mfma_frac": round(step_flop / (elapsed / args.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
             "roofline": roof,
+            "all_positions_mode": None if el3 is None else {
+                "value": round(world * B * F * args.steps / el3, 2), "unit": "frames/s",
+                "ms_per_step": round(el3 / args.steps * 1e3, 3), "steps": args.steps,
+                "step_tflop_per_gpu": round(step_flop_all / 1e12, 2),
+                "step_mfma_frac": round(step_flop_all / (el3 / args.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                "note": "the same update_fn with DFOLD_TRUNK_DCE=0: all four trunk blocks evaluate the conv tower on every position "
+                        "(the reference's eager graph, incl. the positions nothing consumes) -- the quantity rounds 1-4 reported as "
+                        "the headline; outputs, loss and gradients identical to the headline step"},
             "last_frame_mode": None if el2 is None else {
                 "value": round(world * B * F * args.steps / el2, 2), "unit": "frames/s",
                 "ms_per_step": round(el2 / args.steps * 1e3, 3), "steps": args.steps,
@@ -744,16 +803,24 @@ def main():
     if world == 1 and rank == 0:
         del trainer, model
         torch.cuda.empty_cache()
+        def extra(key, fn):      # a side object must never cost the headline line: its failure is reported in its place
+            try:
+                line[key] = fn()
+            except Exception as exc:      # noqa: BLE001
+                line[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                tlog(f"extra object {key} FAILED: {line[key]['error']}")
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
         if not args.no_other_configs and args.mode == "all_frames" and (B, F, N) == (8, 32, 256):
-            line["config2"] = other_config("BASELINE config 2", 4, 32, 128, dev, max(4, args.steps // 2), tlog)
-            line["config5_one_gpu"] = other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog)
+            extra("config2", lambda: other_config("BASELINE config 2", 4, 32, 128, dev, max(4, args.steps // 2), tlog))
+            extra("config5_one_gpu", lambda: other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog))
         if not args.no_triangle:
-            line["triangle"] = triangle_roofline(dev)
+            extra("triangle", lambda: triangle_roofline(dev))
         if not args.no_eval_config:
-            line["config1_eval"] = config1_eval(dev, tlog, cpu=not args.no_cpu_baseline)
+            extra("config1_eval", lambda: config1_eval(dev, tlog, cpu=not args.no_cpu_baseline))
         if not args.no_neighbours:
-            line["neighbours"] = neighbours(dev, tlog)
-            line["hbm_kernels"] = hbm_kernels(dev, tlog)
+            extra("neighbours", lambda: neighbours(dev, tlog))
+            extra("hbm_kernels", lambda: hbm_kernels(dev, tlog))
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(max(2, args.cpu_baseline_frames), N)
     if rank == 0:

@@ -7,6 +7,7 @@ Operators: InvariantPointAttention (:242-516), ConvNet (:664-706), BackboneUpdat
 MyLayerNorm (:709-724), AngleResnet (openfold/model/structure_module.py:47-158), DFOLDIpaScore (:726-907).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -232,6 +233,14 @@ class DFOLDIpaScore(nn.Module):
         self.trunk['conv_0'] = ConvNet(ipa_conf.c_s * 5)
         self.angle_resnet = AngleResnet(c_in=ipa_conf.c_s * 5, c_hidden=ipa_conf.c_s * 5, no_blocks=2, no_angles=7,
                                         epsilon=1e-12)
+        # Dead-code elimination inside the trunk (default on, DFOLD_TRUNK_DCE=0 / attribute False: every position, like the
+        # reference's eager graph).  The node features of the INNER blocks (0 < b < num_blocks - 1) feed nothing but
+        # bb_update_b, whose output on every frame but the last is multiplied by 0.0 (:858-869); only blocks 0 and
+        # num_blocks - 1 reach the angle head on all frames (:871-873).  So for the inner blocks the shared conv tower is
+        # evaluated on the dependency cone of the last frame alone: every output of the forward (all keys, all frames) and
+        # every gradient is the one the all-positions evaluation gives (the conv results inside the cone are bit-identical;
+        # outside it they had no consumer and exactly zero gradient).
+        self.trunk_dce = os.environ.get("DFOLD_TRUNK_DCE", "1") != "0"
         d = model_conf.node_embed_size
         self.force_embeder = _embedder(3, d)
         self.vel_embeder = _embedder(3, d)
@@ -286,7 +295,8 @@ class DFOLDIpaScore(nn.Module):
             feats = ipa.features(node_embed, edge, curr_rigids, node_mask)
             ipa_embed = F_.linear_gln(feats, ipa.linear_out.weight, ipa.linear_out.bias, False)   # linear_out + ln_b
             # cat([rigids, ipa, force, vel, angle], -1) (:846) happens inside the padded conv grid
-            node_feat = conv.run([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], last_frame_only,
+            inner_block = self.trunk_dce and 0 < b < self._ipa_conf.num_blocks - 1      # node_feat[:, :-1] has no consumer
+            node_feat = conv.run([rigids_embed, ipa_embed, force_embed, vel_embed, angle_embed], last_frame_only or inner_block,
                                  first_of_pass=(b == 0))
             # The reference evaluates BackboneUpdate on every frame and multiplies all but the last by 0.0 (:869): those
             # products -- and their gradient, which is exactly zero -- are never anything but zero, so the head runs on the

@@ -205,11 +205,16 @@ def device_batch(rng, diffuser, B, F, N, t=0.5):
     return w
 
 
-def step_flops_fwd(F, N):
-    """Algorithmic forward FLOPs of one window (conv: non-padding taps only).  fwd + bwd = 3 x."""
+def step_flops_fwd(F, N, inner_cone=False):
+    """Algorithmic forward FLOPs of one window (conv: non-padding taps only).  fwd + bwd = 3 x.
+    inner_cone: the trunk's two inner blocks evaluate the conv tower on the last frame's dependency cone
+    (DFOLDIpaScore.trunk_dce): their conv term is scaled by the fraction of (layer, frame) pairs inside the cone."""
     T = lambda L: 5 * L - 6
     P, H, C, PQ, PV = F * N, 8, 256, 8, 12
     conv = 4 * 8 * 2 * 1280 * 640 * T(F) * T(N)
+    if inner_cone:
+        inside = sum(min(F, 4 * (3 - i) + 3) + min(F, 4 * (3 - i) + 1) for i in range(4))      # ops.ConvTower.cone
+        conv = conv // 4 * 2 + int(conv // 4 * 2 * inside / (8.0 * F))
     ipa = 4 * (2 * P * 256 * 6816 + 2 * N * N * 128 * 40 + 4 * F * H * N * N * C + 9 * F * N * N * H * PQ
                + 6 * F * H * N * N * PV + 64 * F * H * N * N + 2 * P * 3072 * 256)
     angle = 2 * P * (1280 * 1280 * 6 + 1280 * 14)

@@ -59,8 +59,38 @@ def main():
     for mod in (F_, T_):
         if getattr(mod, "gemm", None) is orig:
             mod.gemm = timed
+    # the bf16 helpers around the contractions (transposes, column sums, casts), keyed by shape and CALL SITE
+    import inspect
+    ev2 = []
+
+    def wrap_helper(name, keyfn):
+        orig_h = getattr(ops, name)
+
+        def timed_h(*a_, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fr = inspect.stack()[1]
+            e0.record()
+            r = orig_h(*a_, **kw)
+            e1.record()
+            ev2.append(((name, keyfn(*a_, **kw), f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.function}"), e0, e1))
+            return r
+        setattr(ops, name, timed_h)
+        for mod in (F_, T_):
+            if getattr(mod, name, None) is orig_h:
+                setattr(mod, name, timed_h)
+    wrap_helper("transpose_bf16", lambda src, R, C, **kw: (R, C, kw.get("nbatch", 1)))
+    wrap_helper("colsum_bf16", lambda x, out, R, C, ld: (R, C, ld))
+    wrap_helper("cast_bf16", lambda x: tuple(x.shape))
+    wrap_helper("cast_f32", lambda x: tuple(x.shape))
     trainer.update_fn(batch)
     torch.cuda.synchronize()
+    agg2 = collections.defaultdict(lambda: [0.0, 0])
+    for key, e0, e1 in ev2:
+        agg2[key][0] += e0.elapsed_time(e1)
+        agg2[key][1] += 1
+    print(f"helpers in one step: {sum(v[0] for v in agg2.values()):.2f} ms over {len(ev2)} launches")
+    for key, (t, n) in sorted(agg2.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f"{t:7.3f} {n:4d}  {key[0]:15s} {str(key[1]):28s} {key[2]}")
     agg = collections.defaultdict(lambda: [0.0, 0])
     for key, e0, e1 in ev:
         agg[key][0] += e0.elapsed_time(e1)

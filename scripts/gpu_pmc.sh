@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes (own runs, no tracing domains besides --kernel-trace) for the conv kernel's HBM-side traffic:
 #   gpurun --timeout 500 -- 'bash scripts/gpu_pmc.sh'
-# Writes gpurun_out/r3_pmc_{fetch_hit,write_miss_req}.txt (per-kernel averages, scripts/pmc_summary.py).
+# Writes gpurun_out/${PROF_TAG:-r5}_pmc_{fetch_hit,write_miss_req}.txt (per-kernel averages, scripts/pmc_summary.py).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p "$R/gpurun_out"
@@ -9,8 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # $1 = tag, rest = counters
   tag=$1; shift
   rm -rf /tmp/pmc_$tag
-  timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- \
-      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-triangle --no-other-configs --no-eval-config --no-neighbours > /tmp/pmc_$tag.log 2>&1 < /dev/null
+  # (DFOLD_TRUNK_DCE=0: every conv launch of the step is full-size, so the per-kernel averages are per full-size launch)
+  DFOLD_TRUNK_DCE=0 timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -- \
+      python "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-last-frame-mode --no-all-positions-mode --no-triangle --no-other-configs --no-eval-config --no-neighbours > /tmp/pmc_$tag.log 2>&1 < /dev/null
   echo "pmc $tag rc=$?"
   timeout 60 python "$R/scripts/pmc_summary.py" /tmp/pmc_$tag "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.json" > "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.txt" 2>&1 < /dev/null
   head -n 3 "$R/gpurun_out/${PROF_TAG:-r5}_pmc_$tag.txt" | cut -c1-260

@@ -189,6 +189,55 @@ def test_last_frame_only_training_mode_equals_full(monkeypatch):
         assert float(cos) > (0.999 if not split else 0.99), (split, float(cos))
 
 
+def test_trunk_dead_code_elimination_equals_all_positions(monkeypatch):
+    """DFOLDIpaScore.trunk_dce (default on): the inner blocks' conv tower runs on the last frame's dependency cone because
+    their other output frames have no consumer (reference ipa_pytorch_dynamic.py:858-873).  Against the all-positions
+    evaluation, under a loss that reads EVERY frame of EVERY output key (so nothing is dead for the loss's sake): same
+    outputs on all frames, same loss, same gradient for every parameter.  Without the split-K of the thin launches the conv
+    results are bit-identical; with it (default) the cone launches associate their sums differently (bf16-rounding level)."""
+    from dynamicpdb_amd import ops, synthetic
+    dev = torch.device("cuda:0")
+    F, N, B = 24, 16, 2
+    model, diffuser = _build(F, 5, dev)
+    assert model.score_model.trunk_dce is True           # the product default
+    ws = [synthetic.synthetic_window(60 + i, F, N, t=0.3 + 0.4 * i, diffuser=diffuser) for i in range(B)]
+    batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0]}
+    batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
+    keys = ("angles", "unorm_angles", "rigid_update", "rigids", "rot_score", "trans_score")
+    gen = torch.Generator().manual_seed(3)
+    probes = {}
+
+    def run(dce):
+        model.score_model.trunk_dce = dce
+        model.zero_grad(set_to_none=True)
+        out = model({k: v.clone() for k, v in batch.items()})
+        loss = 0.0
+        for k in keys:
+            if k not in probes:
+                probes[k] = torch.randn(out[k].shape, generator=gen).to(dev)
+            loss = loss + (out[k].double() * probes[k].double()).sum() / out[k].numel() ** 0.5
+        loss.backward()
+        return ({k: out[k].detach().clone() for k in keys}, float(loss),
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    real_splitk = ops.conv_splitk
+    try:
+        for split, tol_out, tol_grad in ((False, 1e-5, 2e-3), (True, 2e-2, 0.3)):
+            monkeypatch.setattr(ops, "conv_splitk", real_splitk if split else (lambda *a, **k: 1))
+            full = run(False)
+            dce = run(True)
+            assert float(full[2]["score_model.trunk.conv_0.conv1.0.weight"].abs().max()) > 0
+            for k in keys:
+                assert rel_l2(dce[0][k], full[0][k]) < tol_out, (split, k, rel_l2(dce[0][k], full[0][k]))
+            assert abs(full[1] - dce[1]) < max(tol_out, 1e-6) * max(1.0, abs(full[1])), (split, full[1], dce[1])
+            assert set(full[2]) == set(dce[2])
+            worst = max(((rel_l2(dce[2][n], full[2][n]), n) for n in full[2] if float(full[2][n].abs().max()) > 0),
+                        key=lambda t: t[0])
+            assert worst[0] < tol_grad, (split, worst)
+    finally:
+        model.score_model.trunk_dce = True
+
+
 def test_ragged_nres_vs_oracle():
     """N_res that is not a multiple of 8 (27 residues, 4 frames: 108 rows): the engine pads where it needs 16-byte rows
     (masked residues inside IPA, zero columns in the weight-gradient layouts) -- outputs, loss and gradients against the

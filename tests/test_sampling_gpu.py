@@ -158,6 +158,41 @@ def test_device_sampler_runs_and_is_reproducible():
     # below; with the seeded test weights the trunk's frame update is zero, so trajectories barely see the noise)
 
 
+def test_device_sampler_batch_of_windows_equals_one_by_one():
+    """Several samples drawn as ONE batch of windows (the engine's window axis; the reference's eval loop samples them one after
+    the other, eval_DFOLD_dynamics.py:59-204): same trajectories as the per-window runs on the same priors and draws, incl. the
+    per-window centering of the reverse step."""
+    from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
+    dev = torch.device("cuda:0")
+    B, F, N, num_t = 3, 4, 32, 4
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    model = FullScoreNetwork(conf.model, diffuser)
+    model.load_state_dict(synthetic.seeded_state_dict(31), strict=True)
+    model.to(dev)
+    ws = [synthetic.synthetic_window(4 + b, F, N, t=1.0, diffuser=None) for b in range(B)]     # (different proteins: the network
+    np.random.seed(3)                                                                            # starts from rigids_0, :819)
+    prior = diffuser.sample_ref(n_samples=B * F * N, as_tensor_7=True)["rigids_t"].reshape(B, F, N, 7).float()
+    batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0] if k != "t"}
+    batch["t"] = ws[0]["t"].expand(B).contiguous().to(dev)
+    batch["rigids_t"] = prior.to(dev)
+    rng = np.random.default_rng(8)
+    zs = [(rng.standard_normal((B, F, N, 3)), rng.standard_normal((B, F, N, 3))) for _ in range(num_t)]
+    kw = dict(num_t=num_t, min_t=0.01, aux_traj=True, noise_scale=0.5, center=True)
+    whole = experiment.inference_fn(model, diffuser, batch, z_draws=zs, **kw)
+    assert whole["prot_traj"].shape == (num_t, B, F, N, 37, 3)
+    for b in range(B):
+        one = {k: v[b:b + 1].contiguous() for k, v in batch.items()}
+        zb = [(zr[b:b + 1], zt[b:b + 1]) for zr, zt in zs]
+        part = experiment.inference_fn(model, diffuser, one, z_draws=zb, **kw)
+        for key in ("prot_traj", "rigid_traj", "trans_traj"):
+            d = np.abs(whole[key][:, b] - part[key][:, 0]).max()
+            assert d < 5e-3, (b, key, d)       # (bf16 GEMM tiles see different split-K / tile shapes at batch 1: not bit-equal)
+    assert np.abs(whole["prot_traj"][:, 0] - whole["prot_traj"][:, 1]).max() > 0.1      # different windows -> different samples
+
+
 def test_fused_adam_matches_torch_adam():
     """dfold_adam_amsgrad (one launch over all tensors) vs torch.optim.Adam(amsgrad=True): same parameters and same
     states after several steps with ragged tensor sizes (chunk tails, unaligned views, a parameter without gradient),
