@@ -50,8 +50,16 @@ __device__ __forceinline__ void w4_dma(const char* base, unsigned voff, unsigned
 #define W4_MFMA_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define W4_MFMA_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
+// SK = false: one workgroup per (tile, split-K part).  SK = true ("stream-K", the thin launches: dependency cones, small eval
+// windows): a PERSISTENT grid of one workgroup per CU; the launch's work is the sequence of (tile, K group) units in tile-major
+// order, workgroup s takes units [s per, (s + 1) per) -- a run of pieces (tile, [g_begin, g_end)).  A piece that covers its
+// whole tile goes straight to the epilogue; the pieces of a shared tile park their fp32 partial tiles and the last one to arrive
+// adds them in the fixed order of the workgroup ids (deterministic: the association of the sums depends on the launch shape
+// only) -- the chip is busy for ceil(tiles x groups / CUs) group times instead of whole rounds of whole (or 1/S) tiles.
+template <bool SK>
 __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char wl[];
+  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware tile id (bijective for any grid size); the n tiles of one m tile are consecutive ids = one XCD
@@ -59,8 +67,21 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   const int tiles_n = p.N / W4_BN;
-  const int m0 = (lid / tiles_n) * W4_BM, n0 = (lid % tiles_n) * W4_BN;
   const int M = p.M;
+  const int ngroups = (p.nseg / 25) * 10;       // K groups of a whole tile (of this split-K part)
+  int u = 0, u_end = 1;                         // SK: this workgroup's unit range
+  if (SK) {
+    u = lid * p.sk_per;
+    const int U = p.sk_tiles * ngroups;
+    u_end = u + p.sk_per < U ? u + p.sk_per : U;
+    if (u >= u_end) return;
+  }
+  bool first_piece = true;
+  for (;;) {
+  const int tile = SK ? u / ngroups : lid;
+  const int g_begin = SK ? u - tile * ngroups : 0;
+  const int g_end = SK ? (g_begin + (u_end - u) < ngroups ? g_begin + (u_end - u) : ngroups) : ngroups;
+  const int m0 = (tile / tiles_n) * W4_BM, n0 = (tile % tiles_n) * W4_BN;
   // (split-K launches: part blockIdx.y walks its own range of channel chunks -- p.nseg, p.sa0, p.sb0 are per part)
   const char* A = (const char*)p.A + (long)blockIdx.y * p.sa0 * 2;
   const char* B = (const char*)p.B + (long)blockIdx.y * p.sb0 * 2;
@@ -69,28 +90,31 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   const long a_s0 = p.a_seg_s0, a_s1 = p.a_seg_s1, b_s0 = p.b_seg_s0, b_s1 = p.b_seg_s1;
   const long a_0 = p.a_seg0, b_0 = p.b_seg0;
   const unsigned b_dn2 = (unsigned)(p.b_seg_s2 * 2);        // bytes from one residue tap of the weights to the next
-  const int ngroups = (p.nseg / 25) * 10;
   auto grp_a = [&](int g) -> const char* {
-    g = g < ngroups - 1 ? g : ngroups - 1;
+    g = g < g_end - 1 ? g : g_end - 1;
     const unsigned h = (unsigned)g & 1u, t = (unsigned)g >> 1, c = t / 5u, df = t - 5u * c;
     return A + (a_0 + (long)c * a_s0 + (long)df * a_s1 + (long)h * 32) * 2;
   };
   auto grp_b = [&](int g) -> const char* {
-    g = g < ngroups - 1 ? g : ngroups - 1;
+    g = g < g_end - 1 ? g : g_end - 1;
     const unsigned h = (unsigned)g & 1u, t = (unsigned)g >> 1, c = t / 5u, df = t - 5u * c;
     return B + (b_0 + (long)c * b_s0 + (long)df * b_s1 + (long)h * 32) * 2;
   };
 
+  // (SK: the lane-dependent addresses below are recomputed per piece from an opaque copy of the lane id -- hoisted out of the
+  //  piece loop they would stay live across the epilogue, where the 320 accumulator registers leave no room: 376 B of scratch)
+  int lane_p = lane;
+  if (SK) asm volatile("" : "+v"(lane_p));
   // ---- LDS-DMA lane offsets.  A piece is 16 rows x 64 B (4 chunks of 16 B): lane l fills (row l >> 2, physical chunk l & 3)
   // with the logical chunk (l & 3) ^ key(row), key(row) = (row >> 2) & 3 = (l >> 4) & 3 (every piece starts at a multiple of
   // 16 rows).  Halo run r starts at the tap (0, 0) corner of GEMM row m0 + 256 r (a run past M repeats run 0: computed,
   // never stored); rows 260 .. 271 of a run are padding (they re-read row 259 .. never read back).
   const unsigned ld2 = (unsigned)(p.am.ld * 2);
   const unsigned ldb2 = (unsigned)(p.ldb * 2);
-  const unsigned lch = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-  const unsigned hl_norm = (unsigned)(lane >> 2) * ld2 + lch;
-  const unsigned hl_last = (unsigned)((lane >> 2) < 3 ? (lane >> 2) : 3) * ld2 + lch;
-  const unsigned b_lane = (unsigned)(lane >> 2) * ldb2 + lch;
+  const unsigned lch = (unsigned)(((lane_p & 3) ^ ((lane_p >> 4) & 3)) << 4);
+  const unsigned hl_norm = (unsigned)(lane_p >> 2) * ld2 + lch;
+  const unsigned hl_last = (unsigned)((lane_p >> 2) < 3 ? (lane_p >> 2) : 3) * ld2 + lch;
+  const unsigned b_lane = (unsigned)(lane_p >> 2) * ldb2 + lch;
   unsigned hrow[2];
   hrow[0] = (unsigned)(row_off(p.am, m0) * 2);
   hrow[1] = (unsigned)(row_off(p.am, m0 + 256 < M ? m0 + 256 : m0) * 2);
@@ -109,8 +133,8 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   };
 
   // ---- fragment read addresses (LDS byte addresses, relative to the halo buffer / the weight stage).  MFMA A operand:
-  // lane -> (row lane & 31, k half lane >> 5); the wave's rows are run w >> 1, rows (w & 1) * 128 + i * 32 + frow + dn
-  const int frow = lane & 31, fhalf = lane >> 5;
+  // lane_p -> (row lane_p & 31, k half lane_p >> 5); the wave's rows are run w >> 1, rows (w & 1) * 128 + i * 32 + frow + dn
+  const int frow = lane_p & 31, fhalf = lane_p >> 5;
   unsigned a_lane[5][2], bf_lane[2];
 #pragma unroll
   for (int dn = 0; dn < 5; ++dn)
@@ -156,9 +180,9 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   } while (0)
 
   // ---- prologue: halo tile of group 0, weight tiles 0 .. 2 ----
-  const char* pa_n = grp_a(0);      // halo source of the group being prefetched
-  const char* pb_c = grp_b(0);      // weight base of the current group (dn = 0)
-  const char* pb_n = grp_b(1);      // ... of the next group
+  const char* pa_n = grp_a(g_begin);      // halo source of the group being prefetched
+  const char* pb_c = grp_b(g_begin);      // weight base of the current group (dn = 0)
+  const char* pb_n = grp_b(g_begin + 1);  // ... of the next group
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int q = w + 4 * t;
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
       const int pp = w + 4 * t;
       if (pp < W4_BPIECES) b_piece(pb_c + v * b_dn2, pp, lds_b + v * W4_BT_BYTES);
     }
-  pa_n = grp_a(1);
+  pa_n = grp_a(g_begin + 1);
   unsigned hb_c = lds0, hb_n = lds0 + W4_HALO_BYTES;      // halo buffer of the current / the prefetched group
   unsigned st_c = lds_b, st_1 = lds_b + W4_BT_BYTES, st_2 = lds_b + 2 * W4_BT_BYTES;   // stages of tiles u, u+1, u+2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -182,8 +206,7 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
     for (int k = 0; k < 9; ++k) W4_FRAG(0, k, aa, ba);
   }
 
-  const int ngl = ngroups;
-  for (int g = 0; g < ngl; ++g) {
+  for (int g = g_begin; g < g_end; ++g) {
     // one group = five K32 steps (residue taps), fully unrolled: DN is a compile-time constant of each step
     auto step = [&](auto dnc) {
       constexpr int DN = decltype(dnc)::value;
@@ -256,31 +279,38 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   // the surplus prefetches must have landed before the LDS is reused; MFMA results are read by VALU below
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();
-  if (p.ws != nullptr) {
-    // Deterministic split-K (thin launches: the cone of the training-step mode, small eval windows), as in the 256 x 320 kernel:
-    // every part parks its fp32 partial tile in the workspace (16-byte vectors per lane), the last part to arrive adds them in
-    // the fixed order z = 0 .. S-1 and runs the epilogue.  The 512 x 160 tile has as many elements as a 256 x 320 one.
-    const int S = gridDim.y;
-    const long tile_elems = (long)W4_BM * W4_BN;
-    float* slot = p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + (long)w * (20 * 1024) + lane * 4;
+  const long tile_elems = (long)W4_BM * W4_BN;
+  const long lane_off = (long)w * (20 * 1024) + lane * 4;
+  // Partial tiles travel between workgroups on DIFFERENT XCDs (one L2 each, not coherent with each other for ordinary device
+  // memory inside a kernel).  The workspace is FINE-GRAINED device memory (hipDeviceMallocFinegrained: not cached in the L2s;
+  // w4_partials() below), written and read with agent-scope (sc1) accesses and ordered with s_waitcnt alone.  With ordinary
+  // memory (p.sk_fence, the fallback when that allocation fails) every hand-over needs __threadfence() = buffer_wbl2 +
+  // buffer_inv: a write-back and an invalidate of the WHOLE L2 of the XCD, under the 31 other workgroups that are in the middle
+  // of their K walks (split-K cone launches of the step: 21.6 -> 19.7 ms without the fences).
+  auto park = [&](float* slot) {          // the wave's accumulators as 16-byte vectors per lane: [tile][q4][lane][4]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4)
-            *(f32x4*)(slot + (((a * 2 + i) * 5 + j) * 4 + q4) * 256) =
-                (f32x4){acc[a][i][j][4 * q4], acc[a][i][j][4 * q4 + 1], acc[a][i][j][4 * q4 + 2], acc[a][i][j][4 * q4 + 3]};
-    __threadfence();
-    __syncthreads();
-    __shared__ int s_last;
-    if (tid == 0) s_last = atomicAdd(p.cnt + lid, 1) == S - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const float* part = p.ws + (long)lid * tile_elems + (long)w * (20 * 1024) + lane * 4;
+        for (int j = 0; j < 5; ++j) {
+          float* dst = slot + ((a * 2 + i) * 5 + j) * 1024;
+          // (the data operand straight from the register file the tile lives in -- AGPRs for j < 4 -- as a sub-register range)
+#define W4_PARK(Q4, OFF)                                                                                           \
+          do {                                                                                                     \
+            const f32x4 v = __builtin_shufflevector(acc[a][i][j], acc[a][i][j], 4 * Q4, 4 * Q4 + 1, 4 * Q4 + 2, 4 * Q4 + 3); \
+            if (j < 4) asm volatile("global_store_dwordx4 %0, %1, off offset:" #OFF " sc1\n\ts_nop 1" ::"v"(dst), "a"(v) : "memory"); \
+            else asm volatile("global_store_dwordx4 %0, %1, off offset:" #OFF " sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");       \
+          } while (0)
+          W4_PARK(0, 0);
+          W4_PARK(1, 1024);
+          W4_PARK(2, 2048);
+          W4_PARK(3, 3072);
+#undef W4_PARK
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto clear = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -289,32 +319,135 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
         for (int j = 0; j < 5; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
-    for (int z = 0; z < S; ++z) {
-      const float* pz = part + (long)z * nwg * tile_elems;
+  };
+  // (plain loads: the compiler tracks their completion itself.  An inline-assembly load hands back a register the compiler may
+  //  copy or spill BEFORE the data has arrived -- it did, under this much register pressure.  The workspace is not cached in
+  //  the L2s and each slot is read exactly once per launch by one workgroup, so there is nothing stale to hit.)
+  auto add = [&](const float* pz) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              const f32x4 v = *(const f32x4*)(pz + (((a * 2 + i) * 5 + j) * 4 + q4) * 256);
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = *(const f32x4*)(pz + (((a * 2 + i) * 5 + j) * 4 + q4) * 256);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[a][i][j][4 * q4 + r] += v[r];
-            }
+            for (int r = 0; r < 4; ++r) acc[a][i][j][4 * q4 + r] += v[r];
+          }
+  };
+  bool finish = true;                     // this workgroup runs the tile's epilogue
+  if (SK) {
+    if (g_begin != 0 || g_end != ngroups) {
+      // a shared tile: workgroups s_lo .. s_hi hold a piece of it; a workgroup's FIRST piece parks in slot 2 s, a later one
+      // (which can only be its last) in slot 2 s + 1
+      const int s_lo = (tile * ngroups) / p.sk_per, s_hi = ((tile + 1) * ngroups - 1) / p.sk_per;
+      park(p.ws + (long)(2 * lid + (first_piece ? 0 : 1)) * tile_elems + lane_off);
+      if (p.sk_fence) __threadfence();
+      __syncthreads();
+      if (tid == 0) s_last = atomicAdd(p.cnt + tile, 1) == s_hi - s_lo;
+      __syncthreads();
+      finish = s_last != 0;
+      if (finish) {
+        if (p.sk_fence) __threadfence();
+        clear();
+        for (int sw = s_lo; sw <= s_hi; ++sw)
+          add(p.ws + (long)(2 * sw + ((sw * p.sk_per) / ngroups == tile ? 0 : 1)) * tile_elems + lane_off);
+        if (tid == 0) p.cnt[tile] = 0;   // counters are left clean for the next launch
+      }
     }
+  } else if (p.ws != nullptr) {
+    // Deterministic split-K, as in the 256 x 320 kernel: every part parks its fp32 partial tile in the workspace, the last part
+    // to arrive adds them in the fixed order z = 0 .. S-1 and runs the epilogue.  The 512 x 160 tile has as many elements as a
+    // 256 x 320 one.
+    const int S = gridDim.y;
+    park(p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + lane_off);
+    if (p.sk_fence) __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(p.cnt + lid, 1) == S - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (p.sk_fence) __threadfence();
+    clear();
+    for (int z = 0; z < S; ++z) add(p.ws + ((long)z * nwg + lid) * tile_elems + lane_off);
     if (tid == 0) p.cnt[lid] = 0;   // counters are left clean for the next launch
   }
-  char* wave_lds = wl + w * (32 * EPI_ROWB(5) + 256);
-  gemm_epilogue_lds_bf16<5>(p, acc[0], (long)m0 + w * 128, n0, 0, lane, wave_lds);
-  gemm_epilogue_lds_bf16<5>(p, acc[1], (long)m0 + w * 128 + 64, n0, 0, lane, wave_lds);
+  if (finish) {
+    char* wave_lds = wl + w * (32 * EPI_ROWB(5) + 256);
+    gemm_epilogue_lds_bf16<5>(p, acc[0], (long)m0 + w * 128, n0, 0, lane, wave_lds);
+    gemm_epilogue_lds_bf16<5>(p, acc[1], (long)m0 + w * 128 + 64, n0, 0, lane, wave_lds);
+  }
+  if (!SK) break;
+  u += g_end - g_begin;
+  if (u >= u_end) break;
+  first_piece = false;
+  __syncthreads();            // the epilogue staged through the LDS the next piece's prologue fills
+  }
 }
 
 // host side: called by dfold_gemm_bf16 for the conv launches that qualify (see there)
-int dfold_conv_w4_launch(const GemmParams& p, int splitk, hipStream_t stream) {
-  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel, W4_LDS_BYTES);
+// Fine-grained workspace for the partial tiles (see the kernel), one per device, grown on demand and kept for the life of the
+// process.  nullptr: the allocation failed -- the caller's ordinary workspace is used with fences (DFOLD_CONV_FINE_WS=0 forces
+// that path: A/B measurements and the parity test of the two protocols).
+static float* w4_partials(size_t bytes) {
+  static float* ptr[16] = {nullptr};
+  static size_t cap[16] = {0};
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("DFOLD_CONV_FINE_WS");
+    mode = e ? atoi(e) : 1;
+  }
+  int dev = 0;
+  if (!mode || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (cap[dev] < bytes) {
+    if (ptr[dev]) {
+      (void)hipDeviceSynchronize();      // (growing: launches that still read the old buffer)
+      (void)hipFree(ptr[dev]);
+    }
+    ptr[dev] = nullptr;
+    cap[dev] = 0;
+    void* q = nullptr;
+    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    ptr[dev] = (float*)q;
+    cap[dev] = bytes;
+  }
+  return ptr[dev];
+}
+
+int dfold_conv_w4_launch(const GemmParams& p0, int splitk, hipStream_t stream) {
+  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel<false>, W4_LDS_BYTES);
+  GemmParams p = p0;
   const unsigned tiles = (unsigned)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
-  DFOLD_LAUNCH(dfold_conv_w4_kernel, dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  p.sk_fence = 1;
+  if (splitk > 1) {
+    float* fine = w4_partials((size_t)splitk * tiles * W4_BM * W4_BN * sizeof(float));
+    if (fine) {
+      p.ws = fine;
+      p.sk_fence = 0;
+    }
+  }
+  DFOLD_LAUNCH(dfold_conv_w4_kernel<false>, dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  return dfold_check_launch();
+}
+
+// stream-K form: `p` describes the UNSPLIT launch plus workspace (>= 2 n_wg partial tiles) and counters (>= tiles)
+int dfold_conv_w4_launch_streamk(const GemmParams& p0, int n_wg, hipStream_t stream) {
+  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel<true>, W4_LDS_BYTES);
+  GemmParams p = p0;
+  const int tiles = (int)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
+  const long units = (long)tiles * ((p.nseg / 25) * 10);
+  p.sk_tiles = tiles;
+  p.sk_per = (int)((units + n_wg - 1) / n_wg);
+  p.sk_fence = 1;
+  float* fine = w4_partials((size_t)2 * n_wg * W4_BM * W4_BN * sizeof(float));
+  if (fine) {
+    p.ws = fine;
+    p.sk_fence = 0;
+  }
+  DFOLD_LAUNCH(dfold_conv_w4_kernel<true>, dim3((unsigned)n_wg, 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
   return dfold_check_launch();
 }

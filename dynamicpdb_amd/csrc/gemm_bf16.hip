@@ -700,7 +700,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.sa0 = d->sa0; p.sa1 = d->sa1; p.sb0 = d->sb0; p.sb1 = d->sb1; p.sc0 = d->sc0; p.sc1 = d->sc1;
   p.M = d->M; p.N = d->N; p.nseg = d->nseg; p.seglen = d->seglen;
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
-  p.ws = nullptr; p.cnt = nullptr;
+  p.ws = nullptr; p.cnt = nullptr; p.sk_per = 0; p.sk_tiles = 0; p.sk_fence = 1;
   p.conv_f0 = (d->conv_frames >> 16) & 0x7fff; p.conv_F = d->conv_frames & 0xffff;
   static int prio_mode = -1;
   if (prio_mode < 0) {
@@ -719,6 +719,27 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   const long tiles320 = (long)((d->M + BM3 - 1) / BM3) * ((d->N + BN3 - 1) / BN3);
   const long a_extent = row_off_host(p.am, d->M - 1) + d->a_rows.ld;   // elements spanned by the A rows of one batch
   int S = 1;
+  // splitk == -1: the stream-K form of the one-wave-per-SIMD conv kernel (conv_fwd_w4.hip) when the launch qualifies for that
+  // kernel, otherwise an ordinary unsplit launch (a performance-only fallback: the caller's cost model assumed the kernel)
+  if (d->splitk == -1 && role == 1 && d->nbatch == 1 && d->splitk_ws && d->splitk_cnt && (d->nseg % 25) == 0 &&
+      !(d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->N % 160) == 0 && d->seglen == BK && d->a_rows.mode == 1 &&
+      (d->a_rows.n % BM3) == 0 && (d->M % BM3) == 0 && d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && p.conv_F == 0 &&
+      d->a_seg_s0 == BK && d->b_seg_s0 == BK && (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 &&
+      a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
+    static int sk_env = -1, n_cu = 0;
+    if (sk_env < 0) {
+      const char* e = getenv("DFOLD_CONV_W4");
+      const char* h = getenv("DFOLD_CONV_HALO");
+      sk_env = (!e || atoi(e) != 0) && (!h || atoi(h) != 0) ? 1 : 0;
+      int dev = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    if (sk_env && n_cu > 0) {
+      p.ws = d->splitk_ws; p.cnt = d->splitk_cnt;
+      return dfold_conv_w4_launch_streamk(p, n_cu, (hipStream_t)stream);
+    }
+  }
   if (d->splitk > 1) {
     const int chunks = d->nseg / 25;
     if (role != 1 || d->nbatch != 1 || !d->splitk_ws || !d->splitk_cnt || (d->nseg % 25) || (chunks % d->splitk) ||

@@ -32,6 +32,8 @@ struct GemmParams {
   int conv_f0, conv_F;   // 5x5 conv: grid frame of logical frame 0 / frames of the grid (conv_F = 0: no tap skipping)
   float* ws;    // split-K partial tiles (nullptr: no split)
   int* cnt;     // split-K arrival counters, one per output tile
+  int sk_per, sk_tiles;   // stream-K form of conv_fwd_w4.hip: (tile, K group) units per workgroup, output tiles
+  int sk_fence;           // conv_fwd_w4.hip: the partial-tile workspace is ordinary (L2-cached) memory: hand-overs need fences
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -193,3 +195,4 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
 
 // conv_fwd_w4.hip: the one-wave-per-SIMD 512 x 160 form of the 5x5 conv launch (dispatched from dfold_gemm_bf16)
 int dfold_conv_w4_launch(const GemmParams& p, int splitk, hipStream_t stream);
+int dfold_conv_w4_launch_streamk(const GemmParams& p, int n_wg, hipStream_t stream);

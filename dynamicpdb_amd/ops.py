@@ -77,7 +77,8 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
     d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
     d.splitk, d.conv_frames = splitk, conv_frames
-    d.splitk_ws, d.splitk_cnt = _p(splitk_ws if splitk > 1 else None), _p(splitk_cnt if splitk > 1 else None)
+    split = splitk > 1 or splitk == -1
+    d.splitk_ws, d.splitk_cnt = _p(splitk_ws if split else None), _p(splitk_cnt if split else None)
     check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
     return C
 
@@ -279,7 +280,20 @@ def conv_splitk(M, CO, CI, device):
         cost = -(-tiles * S // n_cu) * (steps // S + 16 + 2 * S)
         if cost < 0.9 * best_cost:
             best, best_cost = S, cost
+    # stream-K form of the one-wave-per-SIMD kernel (conv_fwd_w4.hip, -1): one persistent workgroup per CU walks an equal share
+    # of the (tile, K step) units.  Measured on the cone launches of config 3 (round 5, same-box A/B): the workgroups of a
+    # stream-K launch sit at different K positions, so the weight slab / halo rows that lock-stepped workgroups share in the
+    # L2 are fetched per workgroup -- K steps run ~1.4 x slower than in a whole-tile launch.  It pays only where the best
+    # whole-tile alternative (by the cost model above) runs at <= 0.70 of the evenly-spread time AND a share is at least ~2/3
+    # of a tile: 288 tiles: 890 -> 780 us, 544: 1268 -> 1221 (and 176 tiles, model 0.77: 918 -> 807, left alone because
+    # 416 tiles, model 0.76, lost: 844 -> 950; 160 tiles, share 0.63: 385 -> 473).
+    if _STREAMK and 2 * n_cu <= _SPLITK_CAP * n_cu and tiles <= _SPLITK_CAP * n_cu:
+        if tiles * steps / n_cu <= 0.70 * best_cost and tiles >= 0.65 * n_cu:
+            return -1
     return best
+
+
+_STREAMK = os.environ.get("DFOLD_CONV_STREAMK", "1") != "0"
 
 
 # DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).
@@ -312,8 +326,9 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         # window -- BASELINE config 1 (16 x 96: 12 / 24 output tiles for 256 CUs) ran its 32 conv launches at 5 % of the chip,
         # 13 of the 15.6 ms of a sampler forward (conv_splitk returns 1 wherever the tiles fill the CUs: the headline shapes)
         S = conv_splitk(M, CO, CI, x.device)
-        if S > 1:
-            tiles = ((M + 255) // 256) * (CO // 320)
+        if S == -1 and not (g.N % 256 == 0 and ck == 64 and out.dtype == BF16):
+            S = 1                     # (the launch would not take the kernel that has the stream-K form)
+        if S > 1 or S == -1:
             sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * _N_CU[x.device] * 256 * 320,), torch.float32),
                       splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * _N_CU[x.device],), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),

@@ -85,7 +85,11 @@ typedef struct {
      splitk = S > 1 splits the channel-chunk axis (nseg / 25 chunks, a multiple of S) over S workgroups per output tile.
      Each writes its fp32 partial tile to splitk_ws, the last one to arrive (splitk_cnt, one int32 per tile, zero before
      and after the call) sums the S partials in fixed order and runs the epilogue -- narrow launches (few output rows,
-     long K) then fill the 256 CUs.  splitk_ws: >= S * tiles * 256 * Ntile fp32 (tiles = ceil(M/256) * N/Ntile, Ntile = 320). */
+     long K) then fill the 256 CUs.  splitk_ws: >= S * tiles * 256 * Ntile fp32 (tiles = ceil(M/256) * N/Ntile, Ntile = 320).
+     splitk = -1 ("stream-K", 5x5 conv launches that take the 512 x 160 one-wave-per-SIMD kernel): one persistent workgroup per
+     CU, each an equal share of the (tile, K group) units in tile-major order; shared tiles are added up by their last arriver in
+     workgroup order (deterministic).  splitk_ws >= 2 * CUs * 512 * 160 fp32, splitk_cnt >= tiles int32 (zero before the first
+     launch, left zero).  A launch that does not qualify for that kernel runs unsplit. */
   int32_t splitk;
   /* 5x5 conv launches (a_rows.mode = 1, seg_div = seg_div_mid = 5) may declare where the frame axis of the grid ends:
      conv_frames = (f_first << 16) | F_total, f_first = grid frame of logical frame 0 of a_rows, F_total = frames of the grid.

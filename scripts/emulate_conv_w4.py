@@ -40,7 +40,8 @@ class Lds:
         return cur
 
 
-def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
+def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False, g_begin=0, g_end=None):
+    """g_begin / g_end: the K-group range of a stream-K piece (default: the whole tile)"""
     Wp, Fp = N + 4, F + 4
     ld = CI                      # a_rows.ld
     ldb = 25 * CI
@@ -49,6 +50,8 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
     b_s0, b_s1, b_s2 = 64, 5 * CI, CI
     nseg = 25 * (CI // 64)
     ngroups = (nseg // 25) * 10
+    g_end = ngroups if g_end is None else g_end
+    assert 0 <= g_begin < g_end <= ngroups
     m0, n0 = m_tile * 512, n_tile * 160
 
     def row_off(m):              # rows_in(): top-left corner of the 5x5 window of GEMM row m
@@ -57,7 +60,7 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
         return ((w_ * Fp + f) * Wp + n) * ld
 
     def grp(g, s0, s1):
-        g = min(g, ngroups - 1)
+        g = min(g, g_end - 1)
         h, t = g & 1, g >> 1
         c, df = divmod(t, 5)
         return c * s0 + df * s1 + h * 32            # elements
@@ -120,7 +123,8 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
     def frag_reads(w, hbuf, stage, dn_addr, kb, tile_u):
         """the nine reads of K16 block kb of tile u (its group / residue tap give the expected operands)"""
         g, dn = divmod(tile_u, 5)
-        if g >= ngroups:
+        g += g_begin
+        if g >= g_end:
             return                                   # reads behind the last tile: never consumed
         assert dn == dn_addr
         ka = grp(g, a_s0, a_s1) + dn * a_s2
@@ -142,8 +146,8 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
             nchecked[0] += 9
 
     # ---------------- prologue ----------------
-    pa_n = {w: grp(0, a_s0, a_s1) for w in range(4)}
-    pb_c, pb_n = grp(0, b_s0, b_s1), grp(1, b_s0, b_s1)
+    pa_n = {w: grp(g_begin, a_s0, a_s1) for w in range(4)}
+    pb_c, pb_n = grp(g_begin, b_s0, b_s1), grp(g_begin + 1, b_s0, b_s1)
     for w in range(4):
         for t in range(9):
             q = w + 4 * t
@@ -154,7 +158,7 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
                 pp = w + 4 * t
                 if pp < BPIECES:
                     b_piece(w, pb_c + v * b_s2, pp, lds_b + v * BT)
-    pa_next = grp(1, a_s0, a_s1)
+    pa_next = grp(g_begin + 1, a_s0, a_s1)
     hb_c, hb_n = lds0, lds0 + HALO
     st = [lds_b, lds_b + BT, lds_b + 2 * BT]          # stages of tiles u, u+1, u+2
     for w in range(4):
@@ -165,7 +169,7 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
 
     HB0 = [0, 9, 18, 26, 34]
     u = 0
-    for g in range(ngroups):
+    for g in range(g_begin, g_end):
         for DN in range(5):
             # first half: reads of block 1 of tile u, halo pieces of group g + 1
             for w in range(4):
@@ -196,6 +200,48 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False):
     if verbose:
         print(f"conv_w4 emulation: CI {CI}, N {N}, F {F}, tile ({m_tile}, {n_tile}): {u} steps, {nchecked[0]} fragment reads checked")
     return nchecked[0]
+
+
+def streamk_plan(tiles, ngroups, n_wg):
+    """The stream-K work split of dfold_conv_w4_kernel<true>, replayed: workgroup s takes units [s per, (s + 1) per) of the
+    tile-major (tile, group) sequence.  Returns (per, pieces) with pieces[s] = [(tile, g_begin, g_end, slot or None)], and checks
+    what the kernel relies on: every (tile, group) covered exactly once; a piece is parked iff it does not cover its whole tile;
+    no slot is written twice; the reducer's formulas (s_lo, s_hi, slot of workgroup sw's piece of the tile) name exactly the
+    parked pieces of that tile, in workgroup order; at most two parked pieces per workgroup."""
+    units = tiles * ngroups
+    per = -(-units // n_wg)
+    pieces, parked, covered = {}, {}, {}
+    for s in range(n_wg):
+        u, u_end = s * per, min(units, s * per + per)
+        first = True
+        pieces[s] = []
+        while u < u_end:
+            tile = u // ngroups
+            gb = u - tile * ngroups
+            ge = min(ngroups, gb + (u_end - u))
+            slot = None
+            if gb != 0 or ge != ngroups:
+                slot = 2 * s + (0 if first else 1)
+                assert slot not in parked, (s, slot)
+                parked[slot] = (tile, s, gb, ge)
+            for g in range(gb, ge):
+                assert (tile, g) not in covered
+                covered[(tile, g)] = s
+            pieces[s].append((tile, gb, ge, slot))
+            u += ge - gb
+            first = False
+        assert sum(1 for pc in pieces[s] if pc[3] is not None) <= 2
+    assert len(covered) == units
+    for tile in range(tiles):
+        mine = sorted((v[1], k, v[2], v[3]) for k, v in parked.items() if v[0] == tile)       # (workgroup, slot, gb, ge)
+        s_lo, s_hi = (tile * ngroups) // per, ((tile + 1) * ngroups - 1) // per
+        if s_lo == s_hi:
+            assert not mine, tile                       # one workgroup covers the tile: straight to the epilogue
+            continue
+        want = [(sw, 2 * sw + (0 if (sw * per) // ngroups == tile else 1)) for sw in range(s_lo, s_hi + 1)]
+        assert [(a, b) for a, b, _, _ in mine] == want, (tile, mine, want)
+        assert mine[0][2] == 0 and mine[-1][3] == ngroups and all(x[3] == y[2] for x, y in zip(mine, mine[1:])), (tile, mine)
+    return per, pieces
 
 
 if __name__ == "__main__":

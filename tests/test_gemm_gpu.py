@@ -405,6 +405,82 @@ def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
     assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
 
 
+def test_conv_stream_k_vs_unsplit_and_fp64(dev, monkeypatch):
+    """Stream-K form of the one-wave-per-SIMD conv kernel (splitk = -1: one persistent workgroup per CU, equal shares of the
+    (tile, K group) units, shared tiles added up by their last arriver in workgroup order).  Shapes: 288 tiles (a share spans
+    two tiles), 544 tiles (a share covers a whole tile between two shared ones), 32 tiles (eight pieces per tile), 12 tiles
+    (twenty pieces per tile, idle workgroups).  Against the unsplit launch and fp64 sums on sampled cells, every epilogue of
+    the tower, bit-reproducible, counters left clean; and the cost model takes this form for the cone shapes of config 3 where it was measured to win."""
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib, ops
+    gen = torch.Generator(device="cpu").manual_seed(22)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    ops.conv_splitk(65536, 1280, 640, dev)           # (fills the CU-count cache the launches below read)
+    if n_cu == 256:
+        for M, CO, CI in ((18432, 1280, 640), (34816, 1280, 640)):          # 288 / 544 tiles: a quarter of the chip idle otherwise
+            assert ops.conv_splitk(M, CO, CI, dev) == -1, (M, CO, CI)
+        for M, CO, CI in ((26624, 1280, 640), (10240, 1280, 640), (22528, 640, 1280)):      # measured: no gain / a loss
+            assert ops.conv_splitk(M, CO, CI, dev) >= 1, (M, CO, CI)
+        assert ops.conv_splitk(65536, 1280, 640, dev) == 1          # whole rounds: nothing to gain
+    ws = ops.Workspace(dev)
+    for (Wn, F, nf, N, CI, CO) in ((8, 11, 9, 256, 640, 1280), (8, 19, 17, 256, 640, 1280), (8, 3, 1, 256, 640, 1280), (2, 5, 3, 256, 1280, 640)):
+        g = ops.Grid(Wn, F, N, dev)
+        w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+        wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+        bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+        x, r, r2 = g.alloc(CI), g.alloc(CO), g.alloc(CO)
+        xs = torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16)
+        g.interior(x).copy_(xs)
+        g.interior(r).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+        g.interior(r2).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+        f_lo = F - nf
+        for kw in (dict(relu=True), dict(relu=True, resid=r, pre_resid_out="c2"), dict(relu=False, relu_mask=r),
+                   dict(relu=False, resid=r, C2="c2", R2=r2)):
+            outs = []
+            for S in (1, -1, -1):
+                monkeypatch.setattr(ops, "conv_splitk", lambda *a, _S=S, **k: _S)
+                o, c2 = g.alloc(CO), g.alloc(CO)
+                k = {a: (c2 if isinstance(b, str) else b) for a, b in kw.items()}
+                ops.conv5x5_fwd(g, x, wf, bias if kw.get("relu") else None, o, f_lo=f_lo, nf=nf, ws=ws, **k)
+                outs.append((o, c2))
+            (o0, c0), (o1, c1), (o2, c2_) = outs
+            assert float(o0[:, 2 + f_lo:2 + F].abs().max()) > 0
+            assert rel_l2(o1, o0) < 4e-3 and rel_l2(c1.float() + 1e-6, c0.float() + 1e-6) < 4e-3, (Wn, nf, CI, CO, sorted(kw))
+            assert torch.equal(o1, o2) and torch.equal(c1, c2_), (Wn, nf, CI, CO, sorted(kw))
+            if f_lo > 0:
+                assert float(o1[:, : 2 + f_lo].abs().max()) == 0
+            if "relu" in kw and kw["relu"] and len(kw) == 1:
+                # sampled output cells against fp64 sums of the same bf16 operands
+                wb = w.to(torch.bfloat16).double()
+                xp = torch.zeros((Wn, F + 4, N + 4, CI), dtype=torch.float64, device=dev)
+                xp[:, 2:-2, 2:-2] = xs.double()
+                pick = torch.Generator(device="cpu").manual_seed(5)
+                for _ in range(24):
+                    b = int(torch.randint(0, Wn, (1,), generator=pick)); f = f_lo + int(torch.randint(0, nf, (1,), generator=pick))
+                    n = int(torch.randint(0, N, (1,), generator=pick))
+                    patch = xp[b, f:f + 5, n:n + 5]                                   # [5,5,CI]
+                    ref = (torch.einsum("fnc,ocfn->o", patch, wb) + bias.double()).clamp_min(0)
+                    got = o1[b, 2 + f, 2 + n].double()
+                    assert float((got - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), (b, f, n)
+    assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
+
+
+def test_conv_split_protocols_with_ordinary_workspace():
+    """DFOLD_CONV_FINE_WS=0: the partial tiles of the split-K / stream-K launches go through the caller's ordinary (L2-cached)
+    workspace with fences instead of the fine-grained one (the fallback when that allocation fails): the same two tests in a
+    fresh process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DFOLD_CONV_FINE_WS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "test_conv_stream_k_vs_unsplit_and_fp64 or test_conv_one_wave_per_simd_kernel_vs_fp64"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_convnet_vs_oracle_golden(dev):
     """ConvNet on the reference-minted capture (F=3, N=16, C=1280; tests/golden/network_F3_N16.npz)."""
     from dynamicpdb_amd import ops, synthetic

@@ -601,6 +601,25 @@ def test_conv_one_wave_per_simd_kernel_addressing_and_pipeline_emulation():
                     assert max(banks.values()) == 1, (w, dn, kb)
 
 
+def test_conv_stream_k_plan_and_piece_emulation():
+    """Stream-K form of csrc/conv_fwd_w4.hip on the host: the work split (every (tile, K group) unit covered once, parked
+    pieces and the reducer's slot / workgroup-range formulas agree, at most two parked pieces per workgroup) for the launch
+    shapes of the step (cone launches of config 3, an eval window, more workgroups than units), and the K loop replayed on tags
+    for pieces that begin / end inside a tile (prologue, ring and halo double buffer start from an arbitrary group)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import emulate_conv_w4 as E
+    for tiles, ng in ((288, 100), (544, 100), (176, 200), (32, 100), (12, 200), (416, 100), (160, 100), (1, 10), (3, 10), (257, 10)):
+        per, pieces = E.streamk_plan(tiles, ng, 256)
+        assert per == -(-tiles * ng // 256)
+    per, pieces = E.streamk_plan(544, 100, 256)
+    assert any(len(pc) == 3 and pc[1][3] is None for pc in pieces.values())      # a whole tile between two shared ones
+    per, pieces = E.streamk_plan(12, 200, 256)
+    assert sum(1 for pc in pieces.values() if not pc) == 16                       # idle workgroups
+    assert E.run(CI=128, F=2, g_begin=3, g_end=11) == 8 * 5 * 4 * 64 * 9 * 2
+    assert E.run(CI=64, F=2, g_begin=9, g_end=10) == 1 * 5 * 4 * 64 * 9 * 2      # a one-group piece at the end of the tile
+    assert E.run(CI=128, F=3, m_tile=1, g_begin=0, g_end=7) > 0
+
+
 def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
     """Regression guard without a GPU (hipcc -S, scripts/isa_audit.py): the kernels whose exposed memory round trips were
     removed in round 4 must not grow them back -- no chains of `global_load .. s_waitcnt vmcnt(0) .. global_load` in the
