@@ -97,9 +97,26 @@ __global__ __launch_bounds__(256) void conv_weight_pack_v8_kernel(const float* _
                                                                   bf16_t* __restrict__ Wd, int CO, int CI) {
   __shared__ bf16_t t[32][32 * 26 + 2];
   const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
-  for (int r = 0; r < 32; ++r) {
-    const float* src = W + ((long)(co0 + r) * CI + ci0) * 25;
-    for (int e = threadIdx.x; e < 800; e += 256) t[r][(e / 25) * 26 + e % 25] = f2bf_hw(src[e]);
+  // the block's 32 rows x 800 floats as 6400 16-byte loads, 25 per thread, all in flight before the first LDS store (one
+  // 4-byte load per thread and round trip ran this kernel at 1.2 TB/s: 133 us per 82 MB weight, 1.06 ms per step)
+  {
+    const f32x4* src4 = (const f32x4*)(W + ((long)co0 * CI + ci0) * 25);
+    const long row4 = (long)CI * 25 / 4;
+    f32x4 v[25];
+#pragma unroll
+    for (int it = 0; it < 25; ++it) {
+      const int e4 = threadIdx.x + it * 256, r = e4 / 200, q = e4 - r * 200;
+      v[it] = src4[r * row4 + q];
+    }
+#pragma unroll
+    for (int it = 0; it < 25; ++it) {
+      const int e4 = threadIdx.x + it * 256, r = e4 / 200, q = e4 - r * 200;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = q * 4 + k;
+        t[r][(e / 25) * 26 + e % 25] = f2bf_hw(v[it][k]);
+      }
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 32 * 25 * 4; e += 256) {       // Wf rows (co, tap): 4 chunks of 8 ci

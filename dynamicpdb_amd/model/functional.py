@@ -226,8 +226,8 @@ class ConvTowerFn(Function):
         padded grid itself -- the producers' outputs are copied once, straight into the grid interior; no torch.cat and no
         second copy), then the conv parameters (only there so that autograd sees the dependency).
         last_frame_only: the caller consumes frame F-1 of the output only (training step): the tower evaluates the
-        dependency cone of that frame (ops.ConvTower.cone); the other output frames are returned as zeros and the
-        incoming gradient is taken from frame F-1 only (it is exactly zero elsewhere for such a caller).
+        dependency cone of that frame (ops.ConvTower.cone) and returns that frame alone, [W,1,N,C] (the incoming gradient has
+        the same shape).
         track (bit 0): a backward will follow (grad mode on and something requires grad, decided by the caller -- inside
         Function.forward grad mode is always off).  Only then are the activations kept and the application counted in
         `tower.pending`; a no_grad pass (sampling, self-conditioning, evaluation) leaves no trace in the tower.
@@ -253,6 +253,10 @@ class ConvTowerFn(Function):
         # dropped / a validation pass without no_grad / an exception between forward and backward cannot leave a stale
         # count behind (the token dies with the graph)
         ctx.token = tower.register_application(new_group) if track else None
+        if last_frame_only:
+            # only frame F-1 of the tower output is defined in this mode: hand back that frame alone ([W,1,N,C]) -- a full-size
+            # tensor of zeros around it cost an 84 MB strided copy here and a zero-filled full-size gradient in autograd
+            return g.interior(h4)[:, -1:].contiguous()
         return g.interior(h4).contiguous()
 
     @staticmethod
@@ -263,7 +267,7 @@ class ConvTowerFn(Function):
         tower.check_slot(ctx.slot, ctx.gen)
         gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]), zero=ctx.last)
         if ctx.last:
-            g.interior(gt)[:, -1:].copy_(gy[:, -1:])
+            g.interior(gt)[:, -1:].copy_(gy)            # (gy is [W,1,N,C] in this mode)
         else:
             g.interior(gt).copy_(gy)
         # The application whose backward runs last delivers the summed gradients.  With a data-parallel reducer registered

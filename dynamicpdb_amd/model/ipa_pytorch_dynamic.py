@@ -72,7 +72,8 @@ class ConvNet(nn.Module):
 
     def run(self, x, last_frame_only=False, first_of_pass=True):
         """x bf16 [W,F,N,C], or a list of channel slices [W,F,N,C_k] that are concatenated inside the padded conv grid
-        (no torch.cat) -> bf16 [W,F,N,C].  last_frame_only: see functional.ConvTowerFn (training-step mode).
+        (no torch.cat) -> bf16 [W,F,N,C]; with last_frame_only (see functional.ConvTowerFn: the caller consumes the last frame
+        alone) -> bf16 [W,1,N,C], that frame.
         first_of_pass: this is the first application of the shared tower in a forward pass of the enclosing model (the
         weight gradients of the applications of one pass are summed inside the tower and delivered together)."""
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
