@@ -594,7 +594,7 @@ def other_config(tag, B, F, N, dev, steps, tlog):
         tr.update_fn(b)
     el, loss = timed_steps(tr, batches[2:], steps, sync)
     ms = el / steps * 1e3
-    fl = 3.0 * synthetic.step_flops_fwd(F, N) * B
+    fl = 3.0 * synthetic.step_flops_fwd(F, N, inner_cone=bool(model.score_model.trunk_dce)) * B      # (the FLOPs the step executes)
     tlog(f"{tag}: {ms:.1f} ms/step")
     res = {"workload": f"{tag}: N_res={N}, {F}-frame windows, {B} windows on one GPU, full update_fn, all frames",
            "windows": B, "frames": F, "n_res": N, "ms_per_step": round(ms, 3), "value": round(B * F / (el / steps), 2),
