@@ -194,3 +194,65 @@ def test_reference_loss_fn_consumes_the_dropin_outputs_of_a_device_step(entry, t
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
     loss.backward()                                    # the reference's loss differentiates through the drop-in's output dict
     assert all(outs[k].grad is not None and torch.isfinite(outs[k].grad).all() for k in ("angles", "rigids", "rot_score"))
+
+
+def test_reference_trunk_ignores_inner_blocks_other_frames(tmp_path):
+    """The premise of the engine's trunk dead-code elimination (DFOLDIpaScore.trunk_dce), shown on the REFERENCE's own model
+    (src/model/ipa_pytorch_dynamic.py:798-907, executed unmodified): the conv-tower output of the inner blocks (1 and 2 of 4)
+    is read on the LAST frame only -- bb_update_b's other frames are multiplied by 0.0 (:869), init_node_feat is block 0's,
+    the angle head reads the last block's (:871-873).  A forward hook replaces `conv_0(...)[:-1]` of those two calls by random
+    numbers: every output of the model on every frame, the reference's loss, and every parameter gradient stay BIT-IDENTICAL
+    -- while the same garbage in block 0's or block 3's output changes the torsion outputs (the hook does bite)."""
+    import random
+    import numpy as np
+    ref_import.install()
+    import train_DFOLD_dynamics as T
+    from openfold.utils.rigid_utils import Rigid
+    from dynamicpdb_amd import synthetic
+    F, N = 5, 12
+    conf = ref_import.make_conf(F, cache_dir=str(tmp_path / "cache"))
+    exp = T.Experiment(conf=conf)
+    model = exp.model
+    model.load_state_dict(synthetic.seeded_state_dict(3), strict=True)
+    model.eval()
+    win = synthetic.synthetic_window(11, F, N, t=0.4, diffuser=exp.diffuser, rigid_cls=Rigid)
+    keys = ("angles", "unorm_angles", "rot_score", "trans_score", "rigids", "atom37", "rigid_update")
+
+    def run(garbage_blocks):
+        calls = []
+
+        def hook(mod, inp, out):
+            b = len(calls)
+            calls.append(b)
+            if b % 4 in garbage_blocks:
+                out = out.clone()
+                out[:-1] = torch.randn(out[:-1].shape, generator=torch.Generator().manual_seed(100 + b)) * 7.0
+                return out
+            return None
+        h = model.score_model.trunk["conv_0"].register_forward_hook(hook)
+        try:
+            with torch.no_grad():
+                out = model({k: v.clone() for k, v in win.items()})
+            outs = {k: out[k].detach().clone() for k in keys}
+            calls.clear()
+            random.seed(0)              # loss_fn flips a coin for its self-conditioning pass
+            np.random.seed(0)
+            model.zero_grad()
+            loss, _ = exp.loss_fn({k: v.clone() for k, v in win.items()})
+            loss.backward()
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            h.remove()
+        return outs, float(loss.detach()), grads
+
+    base = run(())
+    inner = run((1, 2))
+    for k in keys:
+        assert torch.equal(base[0][k], inner[0][k]), k
+    assert base[1] == inner[1]
+    assert set(base[2]) == set(inner[2])
+    for n in base[2]:
+        assert torch.equal(base[2][n], inner[2][n]), n
+    for b in (0, 3):                      # the hook is not a no-op: the blocks whose other frames ARE read
+        outer = run((b,))
+        assert not torch.equal(base[0]["unorm_angles"][:-1], outer[0]["unorm_angles"][:-1]), b
