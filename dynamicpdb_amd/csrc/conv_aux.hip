@@ -289,8 +289,9 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // per CU so that the fp32 atomics per output address stay in the hundreds (same-address atomics serialise in L2).
 template <int TILE>
 __global__ __launch_bounds__(256) void colsum_bf16_v8_kernel(const bf16_t* __restrict__ X, float* __restrict__ out, long R,
-                                                             int C, long ld) {
+                                                             int C, long ld, long bstride) {
   constexpr int RL = 256 / TILE;
+  X += (long)blockIdx.z * bstride;        // batch item (the same frame range of another window of a padded grid)
   __shared__ float part[RL][TILE * 8 + 1];
   const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
   const int cg = blockIdx.x * TILE + tx;
@@ -332,32 +333,43 @@ __global__ __launch_bounds__(256) void colsum_bf16_v8_kernel(const bf16_t* __res
   }
 }
 
-extern "C" int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream) {
-  if (!X || !out || R <= 0 || C <= 0 || ld < C) return DFOLD_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if ((C % 8) == 0 && (ld % 8) == 0 && ((uintptr_t)X % 16) == 0) {
+static int colsum_launch(const void* X, float* out, int64_t R, int32_t C, int64_t ld, int32_t nbatch, int64_t bstride, hipStream_t st) {
+  if ((C % 8) == 0 && (ld % 8) == 0 && (bstride % 8) == 0 && ((uintptr_t)X % 16) == 0) {
     const int cgs = C / 8;
     const int tile = cgs >= 64 ? 64 : cgs >= 32 ? 32 : cgs >= 16 ? 16 : cgs >= 8 ? 8 : 4;
     const int bx = (cgs + tile - 1) / tile;
     const int rl = 256 / tile;
     long by = (R + (long)rl * 16 - 1) / ((long)rl * 16);
-    const long cap = max(1L, 512L / bx);
+    const long cap = max(1L, 512L / ((long)bx * nbatch));
     if (by > cap) by = cap;
-    dim3 grid(bx, (unsigned)by);
+    dim3 grid(bx, (unsigned)by, (unsigned)nbatch);
     switch (tile) {
-      case 64: DFOLD_LAUNCH(colsum_bf16_v8_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
-      case 32: DFOLD_LAUNCH(colsum_bf16_v8_kernel<32>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
-      case 16: DFOLD_LAUNCH(colsum_bf16_v8_kernel<16>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
-      case 8: DFOLD_LAUNCH(colsum_bf16_v8_kernel<8>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
-      default: DFOLD_LAUNCH(colsum_bf16_v8_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld); break;
+      case 64: DFOLD_LAUNCH(colsum_bf16_v8_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld, (long)bstride); break;
+      case 32: DFOLD_LAUNCH(colsum_bf16_v8_kernel<32>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld, (long)bstride); break;
+      case 16: DFOLD_LAUNCH(colsum_bf16_v8_kernel<16>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld, (long)bstride); break;
+      case 8: DFOLD_LAUNCH(colsum_bf16_v8_kernel<8>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld, (long)bstride); break;
+      default: DFOLD_LAUNCH(colsum_bf16_v8_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld, (long)bstride); break;
     }
     return dfold_check_launch();
   }
-  long chunks = (R + 511) / 512;
-  if (chunks > 1024) chunks = 1024;
-  dim3 grid((C + 63) / 64, (unsigned)chunks);
-  DFOLD_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)X, out, (long)R, C, (long)ld);
+  for (int z = 0; z < nbatch; ++z) {      // unaligned shapes: the scalar kernel, one launch per batch item
+    long chunks = (R + 511) / 512;
+    if (chunks > 1024) chunks = 1024;
+    dim3 grid((C + 63) / 64, (unsigned)chunks);
+    DFOLD_LAUNCH(colsum_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)X + (long)z * bstride, out, (long)R, C, (long)ld);
+  }
   return dfold_check_launch();
+}
+
+extern "C" int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream) {
+  if (!X || !out || R <= 0 || C <= 0 || ld < C) return DFOLD_EINVAL;
+  return colsum_launch(X, out, R, C, ld, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int dfold_colsum_bf16_batched(const void* X, float* out, int64_t R, int32_t C, int64_t ld, int32_t nbatch, int64_t bstride,
+                                         void* stream) {
+  if (!X || !out || R <= 0 || C <= 0 || ld < C || nbatch <= 0 || nbatch > 65535 || bstride < 0) return DFOLD_EINVAL;
+  return colsum_launch(X, out, R, C, ld, nbatch, bstride, (hipStream_t)stream);
 }
 
 // out = (v > 0) ? g : 0   (ReLU backward on bf16 tensors; n multiple of 8 fast path)

@@ -146,6 +146,10 @@ int dfold_conv_wgrad_tn(const void* A, const void* B, float* dWg, int32_t CA, in
                         int32_t N, int32_t f0, int32_t nf, int32_t flip, int32_t accumulate, void* stream);
 /* out[c] += sum_r X[r*ld + c]   (X bf16, out fp32, atomics) */
 int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream);
+/* the same over nbatch row blocks of R rows each, block z starting bstride elements after block z - 1 (one frame range of every
+   window of a padded conv grid: the conv bias gradient of a cone launch, reference nn.Conv2d bias autograd) */
+int dfold_colsum_bf16_batched(const void* X, float* out, int64_t R, int32_t C, int64_t ld, int32_t nbatch, int64_t bstride,
+                              void* stream);
 /* out = v > 0 ? g : 0  (bf16) */
 int dfold_relu_mask_bf16(const void* g, const void* v, void* out, int64_t n, void* stream);
 /* batched 2-D transpose dst[z][c][r] = src[z][r][c] (bf16; strides in elements; batch z -> (z / nb1, z % nb1)) */

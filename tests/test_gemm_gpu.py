@@ -139,6 +139,21 @@ def test_colsum(dev, R, C, ld):
     assert (out.double() - 2 * ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_colsum_batched_frame_range_of_a_padded_grid(dev):
+    """dfold_colsum_bf16_batched: the column sums over one frame range of every window of a padded conv grid in one launch (the
+    conv bias gradient of a cone launch), 16-byte and scalar kernels, accumulation."""
+    from ctypes import c_int32, c_int64
+    from dynamicpdb_amd import _lib, ops
+    for Wn, Fp, Wp, C, f0, nf in ((8, 36, 260, 640, 19, 15), (3, 9, 20, 1280, 2, 1), (2, 7, 20, 6, 3, 2)):
+        x = _rand_bf16((Wn, Fp, Wp, C), dev, 13)
+        out = torch.zeros(C, dtype=torch.float32, device=dev)
+        for rep in (1, 2):
+            _lib.check(_lib.lib().dfold_colsum_bf16_batched(ops._p(x, f0 * Wp * C), ops._p(out), c_int64(nf * Wp), c_int32(C), c_int64(C),
+                                                            c_int32(Wn), c_int64(Fp * Wp * C), _lib.stream()), "colsum_batched")
+            ref = rep * x[:, f0:f0 + nf].double().sum((0, 1, 2))
+            assert (out.double() - ref).abs().max().item() < 2e-3 * rep * max(1.0, ref.abs().max().item()), (Wn, C, rep)
+
+
 def test_transpose_and_cast(dev):
     from dynamicpdb_amd import ops
     x = torch.randn(3, 70, 130, device=dev)
