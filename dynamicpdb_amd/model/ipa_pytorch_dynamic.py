@@ -239,8 +239,8 @@ class DFOLDIpaScore(nn.Module):
         # bb_update_b, whose output on every frame but the last is multiplied by 0.0 (:858-869); only blocks 0 and
         # num_blocks - 1 reach the angle head on all frames (:871-873).  So for the inner blocks the shared conv tower is
         # evaluated on the dependency cone of the last frame alone: every output of the forward (all keys, all frames) and
-        # every gradient is the one the all-positions evaluation gives (the conv results inside the cone are bit-identical;
-        # outside it they had no consumer and exactly zero gradient).
+        # every gradient is the one the all-positions evaluation gives (the conv results inside the cone are the same sums --
+        # bit-identical unless a thin cone launch splits K --; outside it they had no consumer and exactly zero gradient).
         self.trunk_dce = os.environ.get("DFOLD_TRUNK_DCE", "1") != "0"
         d = model_conf.node_embed_size
         self.force_embeder = _embedder(3, d)
