@@ -792,7 +792,7 @@ def main():
                 "ms_per_step": round(el2 / args.steps * 1e3, 3), "steps": args.steps,
                 "note": "NOT the headline: same update_fn with Trainer(last_frame_only=True) -- conv tower evaluated on the "
                         "dependency cone of the last frame only (the only frame the live loss terms and frame updates read); "
-                        "loss, gradients and parameter update identical to the all-frames step (bit-exact conv results), "
+                        "loss, gradients and parameter update identical to the all-frames step (the same conv sums: bit-exact with DFOLD_CONV_SPLITK=0, fp32-reassociated where a thin launch splits K), "
                         "4x fewer conv FLOPs at F=32"},
         }
         if waits is not None:
