@@ -294,6 +294,7 @@ def conv_splitk(M, CO, CI, device):
 
 
 _STREAMK = os.environ.get("DFOLD_CONV_STREAMK", "1") != "0"
+_TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
 
 
 # DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).
@@ -321,6 +322,18 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     ck = 64 if CI % 64 == 0 else CI            # K chunk per segment (one MFMA K step when channels allow)
     nf = g.F - f_lo if nf is None else nf
     M = g.Wn * nf * g.N
+    if ws is not None and _TAIL_SPLIT and g.N % 256 == 0 and CO % 160 == 0 and x.device in _N_CU and conv_splitk(M, CO, CI, x.device) != 1:
+        # a launch of whole rounds of tiles plus a small remainder (288 = 256 + 32 tiles, 544 = 512 + 32 for 256 CUs): the
+        # remainder's FRAMES go into a launch of their own, which splits K; the whole rounds run unsplit and in lock-step
+        n_cu, per_frame = _N_CU[x.device], (g.Wn * g.N // 512) * (CO // 160)
+        tiles = nf * per_frame
+        rem = tiles % n_cu
+        if per_frame and tiles > n_cu and rem and rem % per_frame == 0 and 4 * rem <= n_cu:
+            nf_b = rem // per_frame
+            kw = dict(relu=relu, resid=resid, pre_resid_out=pre_resid_out, relu_mask=relu_mask,
+                      C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws)
+            conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo, nf=nf - nf_b, **kw)
+            return conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo + nf - nf_b, nf=nf_b, **kw)
     S, sk = 1, {}
     if ws is not None:        # thin grids split K: the frame sub-range launches of the last-frame mode, and every launch of a small
         # window -- BASELINE config 1 (16 x 96: 12 / 24 output tiles for 256 CUs) ran its 32 conv launches at 5 % of the chip,

@@ -438,6 +438,8 @@ def test_conv_stream_k_vs_unsplit_and_fp64(dev, monkeypatch):
             assert ops.conv_splitk(M, CO, CI, dev) >= 1, (M, CO, CI)
         assert ops.conv_splitk(65536, 1280, 640, dev) == 1          # whole rounds: nothing to gain
     ws = ops.Workspace(dev)
+    real_splitk = ops.conv_splitk
+    monkeypatch.setattr(ops, "_TAIL_SPLIT", False)        # (these launches are to take the stream-K form whole)
     for (Wn, F, nf, N, CI, CO) in ((8, 11, 9, 256, 640, 1280), (8, 19, 17, 256, 640, 1280), (8, 3, 1, 256, 640, 1280), (2, 5, 3, 256, 1280, 640)):
         g = ops.Grid(Wn, F, N, dev)
         w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
@@ -480,6 +482,29 @@ def test_conv_stream_k_vs_unsplit_and_fp64(dev, monkeypatch):
                     got = o1[b, 2 + f, 2 + n].double()
                     assert float((got - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), (b, f, n)
     assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
+    # the default policy on the same kind of launch (whole rounds of tiles + a small remainder): the remainder's frames become a
+    # launch of their own that splits K, the whole rounds run unsplit -- same results as one unsplit launch
+    if n_cu == 256:
+        monkeypatch.setattr(ops, "_TAIL_SPLIT", True)
+        Wn, F, nf, N, CI, CO = 8, 11, 9, 256, 640, 1280
+        g = ops.Grid(Wn, F, N, dev)
+        w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+        wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+        wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+        x, r = g.alloc(CI), g.alloc(CO)
+        g.interior(x).copy_(torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16))
+        g.interior(r).copy_(torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16))
+        outs = []
+        for policy in (lambda *a, **k: 1, real_splitk):
+            monkeypatch.setattr(ops, "conv_splitk", policy)
+            o, c2 = g.alloc(CO), g.alloc(CO)
+            ops.conv5x5_fwd(g, x, wf, None, o, relu=False, resid=r, pre_resid_out=c2, f_lo=F - nf, nf=nf, ws=ws)
+            outs.append((o, c2))
+        assert rel_l2(outs[1][0], outs[0][0]) < 4e-3 and rel_l2(outs[1][1], outs[0][1]) < 4e-3
+        # eight of the nine frames are bit-identical to the unsplit launch (whole tiles, same K order), the ninth went through split-K
+        assert torch.equal(outs[1][0][:, 2 + F - nf:2 + F - 1], outs[0][0][:, 2 + F - nf:2 + F - 1])
+        assert not torch.equal(outs[1][0][:, 2 + F - 1], outs[0][0][:, 2 + F - 1])
 
 
 def test_conv_split_protocols_with_ordinary_workspace():
