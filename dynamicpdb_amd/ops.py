@@ -297,6 +297,17 @@ _STREAMK = os.environ.get("DFOLD_CONV_STREAMK", "1") != "0"
 _TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
 
 
+def conv_tail_frames(nf, tiles_per_frame, n_cu):
+    """Frames to cut off the end of a thin conv launch of nf frames (512 x 160 tiles, tiles_per_frame of them per frame) so that
+    what stays is whole rounds of n_cu tiles: the remainder must be whole frames and at most a quarter of a round (a larger
+    remainder fills the chip well enough on its own).  0: leave the launch alone."""
+    tiles = nf * tiles_per_frame
+    rem = tiles % n_cu if n_cu > 0 else 0
+    if tiles_per_frame <= 0 or tiles <= n_cu or rem == 0 or rem % tiles_per_frame or 4 * rem > n_cu:
+        return 0
+    return rem // tiles_per_frame
+
+
 # DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).
 # Off by default: the skipped K steps (3.75 %) are exact zeros and the results are bit-identical, but the edge tiles then
 # fall out of step with the other workgroups of their XCD, which all stream the same weight K-slab at the same time -- the
@@ -325,11 +336,8 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     if ws is not None and _TAIL_SPLIT and g.N % 256 == 0 and CO % 160 == 0 and x.device in _N_CU and conv_splitk(M, CO, CI, x.device) != 1:
         # a launch of whole rounds of tiles plus a small remainder (288 = 256 + 32 tiles, 544 = 512 + 32 for 256 CUs): the
         # remainder's FRAMES go into a launch of their own, which splits K; the whole rounds run unsplit and in lock-step
-        n_cu, per_frame = _N_CU[x.device], (g.Wn * g.N // 512) * (CO // 160)
-        tiles = nf * per_frame
-        rem = tiles % n_cu
-        if per_frame and tiles > n_cu and rem and rem % per_frame == 0 and 4 * rem <= n_cu:
-            nf_b = rem // per_frame
+        nf_b = conv_tail_frames(nf, (g.Wn * g.N // 512) * (CO // 160), _N_CU[x.device])
+        if nf_b:
             kw = dict(relu=relu, resid=resid, pre_resid_out=pre_resid_out, relu_mask=relu_mask,
                       C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws)
             conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo, nf=nf - nf_b, **kw)

@@ -620,6 +620,23 @@ def test_conv_stream_k_plan_and_piece_emulation():
     assert E.run(CI=128, F=3, m_tile=1, g_begin=0, g_end=7) > 0
 
 
+def test_conv_tail_split_policy():
+    """ops.conv_tail_frames: which frames of a thin conv launch get a split-K launch of their own (whole rounds of tiles stay)."""
+    from dynamicpdb_amd import ops
+    assert ops.conv_tail_frames(9, 32, 256) == 1          # 288 tiles = 256 + one frame
+    assert ops.conv_tail_frames(17, 32, 256) == 1         # 544 = 512 + 32
+    assert ops.conv_tail_frames(13, 32, 256) == 0         # 416 = 256 + 160: the remainder is most of a round
+    assert ops.conv_tail_frames(11, 16, 256) == 0         # 176 tiles: less than a round
+    assert ops.conv_tail_frames(32, 32, 256) == 0         # 1024: whole rounds
+    assert ops.conv_tail_frames(15, 16, 256) == 0 and ops.conv_tail_frames(5, 32, 256) == 0
+    assert ops.conv_tail_frames(18, 16, 256) == 2         # 288 tiles at 16 per frame: two frames
+    assert ops.conv_tail_frames(9, 0, 256) == 0 and ops.conv_tail_frames(9, 32, 0) == 0
+    for nf in range(1, 70):
+        for tpf in (4, 8, 16, 32, 64):
+            k = ops.conv_tail_frames(nf, tpf, 256)
+            assert 0 <= k < nf and ((nf - k) * tpf) % 256 == 0 or k == 0
+
+
 def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
     """Regression guard without a GPU (hipcc -S, scripts/isa_audit.py): the kernels whose exposed memory round trips were
     removed in round 4 must not grow them back -- no chains of `global_load .. s_waitcnt vmcnt(0) .. global_load` in the
