@@ -10,7 +10,10 @@ loss, backward, gradient all-reduce, Adam/amsgrad step) on one batch of syntheti
   cpu_baseline = the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample;
   last_frame_mode = extra, NOT the headline: the same update_fn in the engine's training-step mode (conv tower evaluated
                     on the dependency cone of the last frame only; identical loss / gradients).
-The headline `value` always runs every frame through the conv tower, i.e. the work the reference does.
+The headline `value` is the product's default step: every frame through the model, every output of every frame produced;
+the conv tower of the trunk's two inner blocks -- whose output the reference's own forward multiplies by 0.0 off the last
+frame -- runs on that frame's dependency cone (config.trunk_dead_code_elimination; `all_positions_mode` times the step
+without it), and the backward launches skip, on the device, the frames whose incoming gradient is zero (config.zero_frame_skipping).
 """
 import argparse
 import json
@@ -39,6 +42,13 @@ def parse():
     ap.add_argument("--windows", type=int, default=8, help="trajectory windows per GPU (BASELINE config 3: 8)")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--nres", type=int, default=256)
+    ap.add_argument("--lr", type=float, default=1e-6,
+                    help="Adam learning rate of the timed steps.  The reference trains with 1e-4 (config/train_DFOLDv2.yaml); on "
+                         "random-init weights and synthetic frames that rate pushes the frame update past the reference's "
+                         "`trans_loss < 100` gate (train_DFOLD_dynamics.py:1338-1340) within a few steps, after which the rot / "
+                         "trans terms are zeroed and the timed steps would run a torsion-only loss.  The default keeps the gate "
+                         "open for the whole run (same arithmetic per step: the rate is one scalar of the fused Adam launch); "
+                         "`loss.terms_*` on the line show which regime was timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-frames", type=int, default=32, help="window length of the CPU leg (default: the bench's own 32 "
                     "frames: one warm-up + 2 timed iterations, about 4 minutes of host time)")
@@ -82,9 +92,96 @@ def make_batches(synthetic, diffuser, B, F, N, rank, dev, count, same):
     return out
 
 
-def conv_kernel_roofline(model, trainer, batch, B, F, N):
-    """Average duration of the 5x5 conv implicit-GEMM launches (forward + dgrad: kernel dfold_conv_w4_kernel)
-    of ONE extra, instrumented step, measured with HIP events on the stream the kernels are launched on."""
+def dense_conv_launches(dev, B, F, N, reps=6):
+    """The three conv launch types of the tower at the bench's grid on DENSE random operands (every cell of every frame
+    non-zero, nothing for the zero-frame skipping to skip), each alone, HIP events on the launch stream: forward
+    (1280 -> 640, bias + ReLU), data gradient (640 -> 1280, residual add + ReLU-masked second output: the epilogue the
+    backward chain uses) and the weight gradient.  Returns average ms per launch."""
+    from dynamicpdb_amd import ops
+    g = ops.Grid(B, F, N, dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda C: torch.randn(B, F, N, C, device=dev, generator=gen).to(torch.bfloat16)
+    x, y, r, r2 = g.alloc(1280), g.alloc(640), g.alloc(1280), g.alloc(1280)
+    g.interior(x).copy_(rnd(1280))
+    g.interior(y).copy_(rnd(640))
+    g.interior(r).copy_(rnd(1280))
+    g.interior(r2).copy_(rnd(1280))
+    wf = (torch.randn(640, 25, 1280, device=dev, generator=gen) / (25 * 1280) ** 0.5).to(torch.bfloat16)
+    wd = (torch.randn(1280, 25, 640, device=dev, generator=gen) / (25 * 640) ** 0.5).to(torch.bfloat16)
+    bias = torch.zeros(640, device=dev)
+    o1, o2, o3 = g.alloc(640), g.alloc(1280), g.alloc(1280)
+    dw = torch.zeros((1280, 25, 640), dtype=torch.float32, device=dev)
+    runs = {"forward": lambda: ops.conv5x5_fwd(g, x, wf, bias, o1, relu=True),
+            "dgrad": lambda: ops.conv5x5_fwd(g, y, wd, None, o2, relu=False, resid=r, C2=o3, R2=r2),
+            "wgrad": lambda: ops.conv5x5_wgrad_tn(g, y, x, dw, accumulate=True)}
+    out = {}
+    for k, fn in runs.items():
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[k] = e0.elapsed_time(e1) / reps
+    del x, y, r, r2, o1, o2, o3, dw
+    torch.cuda.empty_cache()
+    return out
+
+
+def collect_conv_traffic(tlog):
+    """HBM-side bytes per full-size conv launch from the PMC counters, collected IN THIS RUN when rocprofv3 is on the PATH:
+    two separate --pmc passes (FETCH_SIZE | WRITE_SIZE; /opt/skills/guides/MI355X_MICROARCH.md, HBM section: the two do not fit
+    one pass) over scripts/conv_launches.py (the two production launches on dense operands, ten times each) in a child
+    process; FETCH_SIZE (KiB) is doubled (the guide's gfx950 correction for wide coalesced reads), WRITE_SIZE taken as reported.
+    Returns (bytes per launch, source string) or (None, reason).  DFOLD_BENCH_PMC=0 skips it."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("DFOLD_BENCH_PMC", "1") == "0":
+        return None, "DFOLD_BENCH_PMC=0"
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dfold_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "scripts", "conv_launches.py")], cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=150)
+            tot, n = 0.0, 0
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "dfold_conv_w4_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            tot += float(row["Counter_Value"])
+                            n += 1
+            if n == 0:
+                return None, f"rocprofv3 --pmc {counter}: no rows for the conv kernel (rc {r.returncode})"
+            vals[counter] = tot / n
+        except Exception as exc:      # noqa: BLE001
+            return None, f"rocprofv3 --pmc {counter} failed: {type(exc).__name__}: {exc}"[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    tlog("PMC passes: FETCH_SIZE %.0f KiB, WRITE_SIZE %.0f KiB per conv launch" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        "collected in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two passes) over scripts/conv_launches.py "
+        "(both production launches, dense operands, average per launch); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB")
+
+
+def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
+    """Durations of the 5x5 conv implicit-GEMM launches (kernel dfold_conv_w4_kernel) and of the weight-gradient launches of
+    ONE extra, instrumented step, measured with HIP events on the stream the kernels are launched on.  `achieved` is quoted on
+    the full-size FORWARD launches (dense activations; 16 per step with the trunk's dead-code elimination, 32 without): the
+    backward launches of the same kernel meet gradients that are zero on most frames and skip them on the device (round 6), so
+    their duration says how much they skipped, not how fast the kernel is -- they are listed beside it, together with all
+    three launch types on dense random operands (`dense_operands`)."""
     from dynamicpdb_amd import ops
     events = []
     orig = ops.gemm
@@ -98,7 +195,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
         e0.record()
         r = orig(*a, **kw)
         e1.record()
-        events.append((e0, e1, int(a[3])))          # a[3] = M (output positions of the launch)
+        events.append((e0, e1, int(a[3]), kw.get("bias") is not None))    # a[3] = M (output positions); forward launches carry a bias
         return r
 
     ops.gemm = timed_gemm
@@ -124,50 +221,64 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N):
     finally:
         ops.gemm = orig
         del L.dfold_conv_wgrad_tn        # the exported function is visible again
-    # the roofline is quoted on the FULL-SIZE launches (every position of the batch: blocks 0 and 3 of the trunk, and all four
-    # with DFOLD_TRUNK_DCE=0); the inner blocks' launches cover the last frame's dependency cone only and are listed beside it
-    m_full, nf_full = max(m for _, _, m in events), max(n for _, _, n in wg_events) if wg_events else 0
-    ms_cone = [e0.elapsed_time(e1) for e0, e1, m in events if m != m_full]
+    m_full, nf_full = max(m for _, _, m, _ in events), max(n for _, _, n in wg_events) if wg_events else 0
+    ms_cone = [e0.elapsed_time(e1) for e0, e1, m, _ in events if m != m_full]
     wg_cone = [e0.elapsed_time(e1) for e0, e1, n in wg_events if n != nf_full]
     wg_ms = [e0.elapsed_time(e1) for e0, e1, n in wg_events if n == nf_full]
-    ms = [e0.elapsed_time(e1) for e0, e1, m in events if m == m_full]
+    ms = [e0.elapsed_time(e1) for e0, e1, m, fwd in events if m == m_full and fwd]
+    ms_bwd = [e0.elapsed_time(e1) for e0, e1, m, fwd in events if m == m_full and not fwd]
     avg_s = sum(ms) / len(ms) * 1e-3
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
+    dev = batch["t"].device
+    dense = dense_conv_launches(dev, B, F, N)
+    frac_of = lambda t_ms: round(flops / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
     traffic, traffic_source = None, None
-    # HBM-side bytes per launch: NOT measured in this run (rocprofv3 counter passes cannot ride on a timed run) but read
-    # from the newest committed PMC pass of the same kernel at the same shape; `traffic_source` names the file
-    for tag in ("r5", "r4", "r3"):
-        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_conv.json")
-        if os.path.exists(pmc) and (B, F, N) == (8, 32, 256):
-            with open(pmc) as fh:
-                c = json.load(fh)
-            traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
-            traffic_source = f"profiles/{tag}_pmc_conv.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, scripts/gpu_pmc.sh; not collected in this run)"
-            break
+    wt, c = None, None
+    if (B, F, N) == (8, 32, 256):
+        traffic, traffic_source = collect_conv_traffic(tlog or (lambda m: None)) if pmc else (None, "multi-rank run")
+        for tag in ("r6", "r5", "r4", "r3"):         # the newest committed PMC pass: the fallback, and the weight gradient's bytes
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_conv.json")
+            if os.path.exists(pmc):
+                with open(pmc) as fh:
+                    c = json.load(fh)
+                if traffic is None:
+                    why = traffic_source
+                    traffic = int((2.0 * c["FETCH_SIZE_kb"] + c["WRITE_SIZE_kb"]) * 1024)
+                    traffic_source = (f"profiles/{tag}_pmc_conv.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, scripts/gpu_pmc.sh); "
+                                      f"not collected in this run: {why}")
+                if "wgrad_tn" in c:
+                    wt = int((2.0 * c["wgrad_tn"]["FETCH_SIZE_kb"] + c["wgrad_tn"]["WRITE_SIZE_kb"]) * 1024)
+                break
     second = None
     if wg_ms:      # the second-largest kernel of the step: the conv weight gradient (same algorithmic FLOPs per launch)
-        wavg = sum(wg_ms) / len(wg_ms) * 1e-3
-        wt = None
-        if traffic is not None and "wgrad_tn" in c:
-            wt = int((2.0 * c["wgrad_tn"]["FETCH_SIZE_kb"] + c["wgrad_tn"]["WRITE_SIZE_kb"]) * 1024)
         second = {"kernel": "conv_wgrad_tn_kernel (5x5 conv weight gradient straight from the channels-last grids)", "bound": "mfma",
-                  "achieved": round(flops / wavg / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(flops / wavg / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": wt, "launches": len(wg_ms),
-                  "avg_launch_ms": round(wavg * 1e3, 4), "flop_per_launch": flops}
+                  "achieved": round(flops / (dense["wgrad"] * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": frac_of(dense["wgrad"]), "traffic": wt, "avg_launch_ms": round(dense["wgrad"], 4), "flop_per_launch": flops,
+                  "measured_on": "dense random operands, the launch alone (`dense_operands`): inside the step every full-size "
+                                 "weight-gradient launch meets a gradient that is zero on most frames and skips them",
+                  "in_step": {"full_size_launches": len(wg_ms), "total_ms": round(sum(wg_ms), 3),
+                              "per_launch_ms": [round(v, 3) for v in wg_ms]}}
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "dfold_conv_w4_kernel (5x5 conv implicit GEMM, one wave per SIMD, 512 x 160 tile, 32-channel halo groups; "
-                      "forward + dgrad launches; DFOLD_CONV_W4=0: dfold_mfma_gemm320_kernel<1, 5, true>)", "launches": len(ms),
-            "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
+            "kernel": "dfold_conv_w4_kernel (5x5 conv implicit GEMM, one wave per SIMD, 512 x 160 tile, 32-channel halo groups); "
+                      "`achieved` = the full-size FORWARD launches of the step (ReLU-sparse activations, every tile computed)",
+            "launches": len(ms), "avg_launch_ms": round(avg_s * 1e3, 4), "flop_per_launch": flops, "second_kernel": second,
+            "dense_operands": {"what": "each launch type alone on dense random operands at the same grid (nothing to skip): ms per "
+                                       "launch and fraction of the bf16 MFMA peak",
+                               "forward_ms": round(dense["forward"], 4), "forward_frac": frac_of(dense["forward"]),
+                               "dgrad_ms": round(dense["dgrad"], 4), "dgrad_frac": frac_of(dense["dgrad"]),
+                               "wgrad_ms": round(dense["wgrad"], 4), "wgrad_frac": frac_of(dense["wgrad"])},
+            "backward_launches": {"what": "full-size data-gradient launches of the step (same kernel, NZ instantiation): tiles whose "
+                                          "input frames are zero by the frame flags skip their K walk, so a launch costs what its "
+                                          "live tiles cost (DFOLD_CONV_NZ=0: every tile)",
+                                  "launches": len(ms_bwd), "total_ms": round(sum(ms_bwd), 3),
+                                  "per_launch_ms": [round(v, 3) for v in ms_bwd]},
             "cone_launches": {"what": "launches of the trunk's inner blocks (dependency cone of the last frame: 1 ... 15 of the "
                                       "frames per layer, split-K when thin): same kernels, not part of `achieved`",
                               "conv_fwd_dgrad": len(ms_cone), "conv_fwd_dgrad_total_ms": round(sum(ms_cone), 3),
                               "wgrad": len(wg_cone), "wgrad_total_ms": round(sum(wg_cone), 3)},
-            "full_launches_total_ms": {"conv_fwd_dgrad": round(sum(ms), 3), "wgrad": round(sum(wg_ms), 3)},
-            # what a rocprofv3 --stats row of the same step averages over (full-size and cone launches of one kernel name)
-            "all_launches_avg_ms": {"dfold_conv_w4_kernel": round((sum(ms) + sum(ms_cone)) / max(1, len(ms) + len(ms_cone)), 4),
-                                    "conv_wgrad_tn_kernel": round((sum(wg_ms) + sum(wg_cone)) / max(1, len(wg_ms) + len(wg_cone)), 4)},
+            "full_launches_total_ms": {"conv_fwd": round(sum(ms), 3), "conv_dgrad": round(sum(ms_bwd), 3), "wgrad": round(sum(wg_ms), 3)},
             "note": "peak = nominal dense bf16 MFMA rate at 2.4 GHz; the launch is power-limited on real operands: the same "
                     "binary on all-zero operands runs 2.13 PFLOP/s = 0.85 of the peak, on dense random operands 1.44-1.46 "
                     "(scripts/exp_conv_dvfs.py); hipBLASLt on the materialised GEMM of the same size 1.08 / 1.51 PFLOP/s "
@@ -564,14 +675,17 @@ def selftest_dist(args, world, rank):
     dist.destroy_process_group()
 
 
-def timed_steps(trainer, batches, steps, sync):
+def timed_steps(trainer, batches, steps, sync, terms=None):
     """`steps` update_fn calls on successive pre-staged batches between two (barrier + device sync)s; returns seconds
-    (this rank) and the last loss (device scalar)."""
+    (this rank) and the last loss (device scalar).  terms (a list): receives the (loss, aux) device scalars of the first and
+    the last timed step (read by the caller after the region)."""
     sync()
     t0 = time.perf_counter()
     loss = None
     for i in range(steps):
-        loss, _ = trainer.update_fn(batches[i % len(batches)])     # device scalars: no host sync inside the timed region
+        loss, aux = trainer.update_fn(batches[i % len(batches)])     # device scalars: no host sync inside the timed region
+        if terms is not None and i in (0, steps - 1):
+            terms.append((loss, aux))
     sync()
     return time.perf_counter() - t0, loss
 
@@ -638,6 +752,7 @@ def main():
     if world > 1:
         dist.barrier()
     from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd import ops as ops_mod
     from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
     from dynamicpdb_amd.model.Dfold_network_dynamic import FullScoreNetwork
     B, F, N = args.windows, args.frames, args.nres
@@ -650,7 +765,7 @@ def main():
     model.load_state_dict(synthetic.seeded_state_dict(rank), strict=True)
     model.to(dev)
     # headline: every frame through the conv tower, the work the reference does (SURVEY 8d FLOP model)
-    trainer = experiment.Trainer(model, lr=1e-4, last_frame_only=(args.mode == "last_frame"))
+    trainer = experiment.Trainer(model, lr=args.lr, last_frame_only=(args.mode == "last_frame"))
     trainer.reducer.timing = world > 1
     # the benchmark step runs one and the same autograd graph on every rank and in every step (like the reference under
     # DistributedDataParallel without find_unused_parameters): after two clean steps the reducer drops its per-step flag
@@ -680,7 +795,10 @@ def main():
         first_loss = float(l0) if first_loss is None else first_loss
         tlog("warm-up step done")
     trainer.reducer.wait_ms.clear()
-    elapsed, loss = timed_steps(trainer, batches[args.warmup:args.warmup + args.steps], args.steps, sync)
+    terms = []
+    elapsed, loss = timed_steps(trainer, batches[args.warmup:args.warmup + args.steps], args.steps, sync, terms)
+    fmt_terms = lambda la: dict({"loss": round(float(la[0]), 5)}, **{k: round(float(v), 5) for k, v in la[1].items()})
+    terms = [fmt_terms(t) for t in terms]
     if first_loss is None:
         first_loss = float(loss)
     tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -690,7 +808,7 @@ def main():
     tlog(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     # the instrumented extra step contains the gradient all-reduce: EVERY rank runs it (a collective issued by rank 0
     # alone would pair with the other ranks' next step and hang the job at the end); rank 0 reports its own timings
-    roof = conv_kernel_roofline(model, trainer, batches[-1], B, F, N) if args.mode == "all_frames" else None
+    roof = conv_kernel_roofline(model, trainer, batches[-1], B, F, N, tlog if rank == 0 else None, pmc=(world == 1)) if args.mode == "all_frames" else None
     waits, dp_info = None, None
     if world > 1:        # how long each rank's stream sat in finish() waiting for the gradient collectives, per step
         w = torch.tensor([sum(trainer.reducer.wait_ms) / max(1, len(trainer.reducer.wait_ms))], device=dev, dtype=torch.float64)
@@ -767,6 +885,13 @@ def main():
                                       "a fresh synthetic batch every step (staged in HBM before the timed region)"),
                        "windows_per_gpu": B, "frames": F, "n_res": N, "parallelism": "dp%d" % world, "mode": args.mode,
                        "trunk_dead_code_elimination": dce,
+                       "zero_frame_skipping": bool(ops_mod.CONV_NZ),
+                       "zero_frame_skipping_note":
+                           "on (product default, DFOLD_CONV_NZ=0 turns it off): the gradient entering the conv tower's backward is "
+                           "scanned for all-zero frames while it is copied into the padded grid; the data- and weight-gradient "
+                           "launches skip, on the device and per tile, what is zero by those flags (no contract with the loss, no "
+                           "host sync; results bit-identical).  With the reference's loss (last frame only) the full-size backward "
+                           "launches of blocks 0 and 3 meet gradients that live on 1 ... 17 of the 32 frames",
                        "trunk_dead_code_elimination_note":
                            "on (product default): the node features of trunk blocks 1 and 2 feed only bb_update, whose output is "
                            "multiplied by 0.0 on every frame but the last (reference ipa_pytorch_dynamic.py:858-869), so their conv "
@@ -774,7 +899,12 @@ def main():
                            "every gradient equal the all-positions evaluation (`all_positions_mode` below times that one; "
                            "DFOLD_TRUNK_DCE=0 makes it the default)"},
             "loss": {"first_step": round(first_loss, 5), "last_step": round(float(loss), 5),
-                     "steps_between": args.warmup + args.steps - 1},
+                     "steps_between": args.warmup + args.steps - 1, "lr": args.lr,
+                     "terms_first_timed_step": terms[0], "terms_last_timed_step": terms[-1],
+                     "gate_open_in_timed_region": bool(terms[0]["trans_loss"] > 0 and terms[-1]["trans_loss"] > 0),
+                     "note": "the reference zeroes the rot / trans terms of a window whose trans_loss reaches 100 "
+                             "(train_DFOLD_dynamics.py:1338-1340); gate_open: both terms were live in the first and the last "
+                             "timed step (mean over the windows > 0)"},
             # whole step against the MFMA peak: algorithmic fwd+bwd FLOPs of the step / step time / 2.5 PF
             "step_tflop_per_gpu": round(step_flop / 1e12, 2),
             "step_mfma_frac": round(step_flop / (elapsed / args.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),

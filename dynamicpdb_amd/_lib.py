@@ -27,7 +27,8 @@ class GemmDesc(Structure):
                 ("sa0", c_int64), ("sa1", c_int64), ("sb0", c_int64), ("sb1", c_int64), ("sc0", c_int64),
                 ("sc1", c_int64), ("M", c_int32), ("N", c_int32), ("nseg", c_int32), ("seglen", c_int32),
                 ("nbatch", c_int32), ("nb1", c_int32), ("flags", c_int32), ("alpha", c_float),
-                ("splitk", c_int32), ("conv_frames", c_int32), ("splitk_ws", c_void_p), ("splitk_cnt", c_void_p)]
+                ("splitk", c_int32), ("conv_frames", c_int32), ("splitk_ws", c_void_p), ("splitk_cnt", c_void_p),
+                ("nz_ps", c_void_p), ("nz_radius", c_int32), ("nz_f0", c_int32)]
 
 
 GEMM_BIAS, GEMM_RELU, GEMM_RESID, GEMM_RELUMASK, GEMM_OUT_BF16, GEMM_ACCUM, GEMM_ATOMIC = 1, 2, 4, 8, 16, 32, 64

@@ -478,4 +478,69 @@ extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32
   return dfold_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// dense [W][nf][N][C] -> interior of the padded grid, plus the non-zero frame flags of the tower's backward (round 6)
+// ---------------------------------------------------------------------------------------------
+// One frame row of the interior is ONE contiguous run of N*C elements in both tensors.  A block copies 8 KiB pieces of a row
+// (16-byte vectors, 8 loads in flight per thread), ORs what it saw and raises the row's flag with one device-scope atomic per
+// wave that met a non-zero; the last block to arrive turns the flags into per-window prefix sums and leaves the scratch zero.
+#define GLF_VPT 8
+__global__ __launch_bounds__(256) void grid_load_flags_kernel(const uint4* __restrict__ src, uint4* __restrict__ grid, int* __restrict__ ps,
+                                                              int* __restrict__ scratch, int W, int F, int N, int C, int f_off, int nf,
+                                                              long nvec_row) {
+  const int Fp = F + 4, Wp = N + 4;
+  const int f = blockIdx.y, w = blockIdx.z;
+  const long row_g = (((long)w * Fp + f_off + f + 2) * Wp + 2) * C / 8;         // vector offset of the row's interior in the grid
+  const uint4* s = src ? src + ((long)w * nf + f) * nvec_row : grid + row_g;
+  uint4* d = grid + row_g;
+  const long v0 = (long)blockIdx.x * (256 * GLF_VPT) + threadIdx.x;
+  uint4 v[GLF_VPT];
+#pragma unroll
+  for (int k = 0; k < GLF_VPT; ++k) {
+    const long i = v0 + k * 256;
+    v[k] = i < nvec_row ? s[i] : make_uint4(0, 0, 0, 0);
+  }
+  unsigned any = 0;
+#pragma unroll
+  for (int k = 0; k < GLF_VPT; ++k) {
+    const long i = v0 + k * 256;
+    // (-0.0 counts as zero: the products it would enter are zeros either way)
+    any |= (v[k].x | v[k].y | v[k].z | v[k].w) & 0x7fff7fffu;
+    if (src && i < nvec_row) d[i] = v[k];
+  }
+  if (__ballot(any != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(scratch + w * Fp + f_off + f + 2, 1);
+  __shared__ int s_last;
+  __syncthreads();
+  const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+  int* counter = scratch + W * Fp;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(counter, 1) == nblocks - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int ww = threadIdx.x; ww < W; ww += 256) {
+    int run = 0;
+    int* o = ps + (long)ww * (Fp + 1);
+    o[0] = 0;
+    for (int j = 0; j < Fp; ++j) {
+      run += atomicExch(scratch + ww * Fp + j, 0) != 0 ? 1 : 0;
+      o[j + 1] = run;
+    }
+  }
+  if (threadIdx.x == 0) atomicExch(counter, 0);
+}
+
+extern "C" int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, int32_t* scratch, int32_t W, int32_t F, int32_t N,
+                                     int32_t C, int32_t f_off, int32_t nf, void* stream) {
+  if (!grid || !ps || !scratch || W <= 0 || F <= 0 || N <= 0 || C <= 0 || f_off < 0 || nf <= 0 || f_off + nf > F) return DFOLD_EINVAL;
+  if (((long)N * C) % 8 || (C % 8) || (((uintptr_t)src | (uintptr_t)grid) & 15) || W > 65535 || nf > 65535) return DFOLD_EINVAL;
+  const long nvec = (long)N * C / 8;
+  const unsigned bx = (unsigned)((nvec + 256 * GLF_VPT - 1) / (256 * GLF_VPT));
+  DFOLD_LAUNCH(grid_load_flags_kernel, dim3(bx, (unsigned)nf, (unsigned)W), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+               (uint4*)grid, ps, scratch, W, F, N, C, f_off, nf, nvec);
+  return dfold_check_launch();
+}
+
 extern "C" int dfold_abi_version(void) { return DFOLD_ABI_VERSION; }

@@ -56,7 +56,14 @@ __device__ __forceinline__ void w4_dma(const char* base, unsigned voff, unsigned
 // whole tile goes straight to the epilogue; the pieces of a shared tile park their fp32 partial tiles and the last one to arrive
 // adds them in the fixed order of the workgroup ids (deterministic: the association of the sums depends on the launch shape
 // only) -- the chip is busy for ceil(tiles x groups / CUs) group times instead of whole rounds of whole (or 1/S) tiles.
-template <bool SK>
+//
+// NZ = true (round 6, zero-frame skipping; dfold_gemm_desc.nz_ps): before anything else a workgroup asks the frame flags whether
+// any of the input frame rows of its two runs can hold a non-zero.  If not, the K walk is left out: the accumulators stay zero
+// and the epilogue runs as it would have (the products left out are exact zeros -- same bits).  The data-gradient launches of
+// the tower's backward meet gradients that are zero outside the dependency cone of the frames the loss read (a quarter of the
+// tiles at 32 frames when the loss reads the last frame); nothing about the loss is known to the host, the decision is made
+// per tile on the device.
+template <bool SK, bool NZ = false>
 __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char wl[];
   __shared__ int s_last;
@@ -82,6 +89,25 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   const int g_begin = SK ? u - tile * ngroups : 0;
   const int g_end = SK ? (g_begin + (u_end - u) < ngroups ? g_begin + (u_end - u) : ngroups) : ngroups;
   const int m0 = (tile / tiles_n) * W4_BM, n0 = (tile % tiles_n) * W4_BN;
+  bool live = true;
+  if (NZ) {
+    live = false;
+    const int fp1 = p.am.fp + 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int m = m0 + 256 * r;
+      if (m < M) {
+        const unsigned wf = (unsigned)m / (unsigned)p.am.n;
+        const unsigned ww = wf / (unsigned)p.am.f, ff = wf - ww * (unsigned)p.am.f;
+        int a = p.nz_f0 + (int)ff - p.nz_radius, b = p.nz_f0 + (int)ff + 4 + p.nz_radius;
+        a = a < 0 ? 0 : a;
+        b = b > p.am.fp - 1 ? p.am.fp - 1 : b;
+        const int* row = p.nz_ps + (long)ww * fp1;
+        live = live || row[b + 1] - row[a] > 0;
+      }
+    }
+    if (!live && blockIdx.y != 0) return;     // (split-K: part 0 alone writes the zero tile)
+  }
   // (split-K launches: part blockIdx.y walks its own range of channel chunks -- p.nseg, p.sa0, p.sb0 are per part)
   const char* A = (const char*)p.A + (long)blockIdx.y * p.sa0 * 2;
   const char* B = (const char*)p.B + (long)blockIdx.y * p.sb0 * 2;
@@ -179,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
     if ((k) == 8) W4_READ(fb[S][4], baddr, 8192);                   \
   } while (0)
 
+  if (live) {
   // ---- prologue: halo tile of group 0, weight tiles 0 .. 2 ----
   const char* pa_n = grp_a(g_begin);      // halo source of the group being prefetched
   const char* pb_c = grp_b(g_begin);      // weight base of the current group (dn = 0)
@@ -273,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
     pb_n = grp_b(g + 2);
     pa_n = grp_a(g + 2);
   }
+  }   // live
 #undef W4_BLOCK
 #undef W4_FRAG
 
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
         if (tid == 0) p.cnt[tile] = 0;   // counters are left clean for the next launch
       }
     }
-  } else if (p.ws != nullptr) {
+  } else if (p.ws != nullptr && live) {
     // Deterministic split-K, as in the 256 x 320 kernel: every part parks its fp32 partial tile in the workspace, the last part
     // to arrive adds them in the fixed order z = 0 .. S-1 and runs the epilogue.  The 512 x 160 tile has as many elements as a
     // 256 x 320 one.
@@ -387,67 +415,92 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
 }
 
 // host side: called by dfold_gemm_bf16 for the conv launches that qualify (see there)
-// Fine-grained workspace for the partial tiles (see the kernel), one per device, grown on demand and kept for the life of the
-// process.  nullptr: the allocation failed -- the caller's ordinary workspace is used with fences (DFOLD_CONV_FINE_WS=0 forces
-// that path: A/B measurements and the parity test of the two protocols).
-static float* w4_partials(size_t bytes) {
-  static float* ptr[16] = {nullptr};
-  static size_t cap[16] = {0};
+// Fine-grained workspace for the partial tiles (see the kernel): one buffer per (device, stream), grown on demand and kept for
+// the life of the process -- launches in flight on two streams of a device (two towers, a side-stream data gradient, callers on
+// several threads) never share slots (round-5 review: one buffer per device did).  The table is guarded by a mutex.  Growing
+// waits for the launches of THAT stream which still read the old buffer; while the stream is being captured into a graph nothing
+// may be synchronised or freed, so a capture that needs more than the stream already has falls back to the caller's ordinary
+// workspace with fences (nullptr), as does a failed allocation or a full table.  DFOLD_CONV_FINE_WS=0 forces that path (A/B
+// measurements and the parity test of the two protocols).
+#include <mutex>
+static float* w4_partials(size_t bytes, hipStream_t stream) {
+  struct Entry { int dev; hipStream_t stream; float* ptr; size_t cap; };
+  static Entry tab[64];
+  static int n_tab = 0;
   static int mode = -1;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   if (mode < 0) {
     const char* e = getenv("DFOLD_CONV_FINE_WS");
     mode = e ? atoi(e) : 1;
   }
   int dev = 0;
-  if (!mode || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (cap[dev] < bytes) {
-    if (ptr[dev]) {
-      (void)hipDeviceSynchronize();      // (growing: launches that still read the old buffer)
-      (void)hipFree(ptr[dev]);
-    }
-    ptr[dev] = nullptr;
-    cap[dev] = 0;
-    void* q = nullptr;
-    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    ptr[dev] = (float*)q;
-    cap[dev] = bytes;
+  if (!mode || hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Entry* en = nullptr;
+  for (int i = 0; i < n_tab; ++i)
+    if (tab[i].dev == dev && tab[i].stream == stream) en = &tab[i];
+  if (en && en->cap >= bytes) return en->ptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone) return nullptr;
+  if (!en) {
+    if (n_tab == 64) return nullptr;
+    en = &tab[n_tab++];
+    en->dev = dev; en->stream = stream; en->ptr = nullptr; en->cap = 0;
   }
-  return ptr[dev];
+  if (en->ptr) {
+    if (hipStreamSynchronize(stream) != hipSuccess || hipFree(en->ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;                     // (the old buffer stays: too small for this launch, still right for smaller ones)
+    }
+    en->ptr = nullptr;
+    en->cap = 0;
+  }
+  void* q = nullptr;
+  if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  en->ptr = (float*)q;
+  en->cap = bytes;
+  return en->ptr;
 }
 
 int dfold_conv_w4_launch(const GemmParams& p0, int splitk, hipStream_t stream) {
-  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel<false>, W4_LDS_BYTES);
   GemmParams p = p0;
   const unsigned tiles = (unsigned)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
   p.sk_fence = 1;
   if (splitk > 1) {
-    float* fine = w4_partials((size_t)splitk * tiles * W4_BM * W4_BN * sizeof(float));
+    float* fine = w4_partials((size_t)splitk * tiles * W4_BM * W4_BN * sizeof(float), stream);
     if (fine) {
       p.ws = fine;
       p.sk_fence = 0;
     }
   }
-  DFOLD_LAUNCH(dfold_conv_w4_kernel<false>, dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  if (p.nz_ps) {
+    DFOLD_MAX_LDS_ONCE((dfold_conv_w4_kernel<false, true>), W4_LDS_BYTES);
+    DFOLD_LAUNCH((dfold_conv_w4_kernel<false, true>), dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  } else {
+    DFOLD_MAX_LDS_ONCE((dfold_conv_w4_kernel<false, false>), W4_LDS_BYTES);
+    DFOLD_LAUNCH((dfold_conv_w4_kernel<false, false>), dim3(tiles, splitk > 1 ? splitk : 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  }
   return dfold_check_launch();
 }
 
 // stream-K form: `p` describes the UNSPLIT launch plus workspace (>= 2 n_wg partial tiles) and counters (>= tiles)
 int dfold_conv_w4_launch_streamk(const GemmParams& p0, int n_wg, hipStream_t stream) {
-  DFOLD_MAX_LDS_ONCE(dfold_conv_w4_kernel<true>, W4_LDS_BYTES);
+  DFOLD_MAX_LDS_ONCE((dfold_conv_w4_kernel<true, false>), W4_LDS_BYTES);
   GemmParams p = p0;
   const int tiles = (int)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
   const long units = (long)tiles * ((p.nseg / 25) * 10);
   p.sk_tiles = tiles;
   p.sk_per = (int)((units + n_wg - 1) / n_wg);
   p.sk_fence = 1;
-  float* fine = w4_partials((size_t)2 * n_wg * W4_BM * W4_BN * sizeof(float));
+  float* fine = w4_partials((size_t)2 * n_wg * W4_BM * W4_BN * sizeof(float), stream);
   if (fine) {
     p.ws = fine;
     p.sk_fence = 0;
   }
-  DFOLD_LAUNCH(dfold_conv_w4_kernel<true>, dim3((unsigned)n_wg, 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
+  DFOLD_LAUNCH((dfold_conv_w4_kernel<true, false>), dim3((unsigned)n_wg, 1), dim3(256), (size_t)W4_LDS_BYTES, stream, p);
   return dfold_check_launch();
 }

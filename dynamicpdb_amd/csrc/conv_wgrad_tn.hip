@@ -59,6 +59,8 @@ struct WgradTnParams {
   long winA, winB;     // bytes from one window to the next
   int nchunk, nF, nW;  // K walk: 64-cell chunks per frame row, frame rows, windows
   int flip, accumulate;
+  const int* nz_ps;    // NZ: frame flags of the gradient operand (prefix sums [window][Fp + 1]), see dfold_conv_wgrad_tn
+  int nz_radius, nz_f0, Fp;   // nz_f0: padded frame row of the gradient cell that K row (w, 0) pairs with at frame shift 0
 };
 
 // One MFMA operand fragment: cells (k) 0-3 and 4-7 of this lane's K-half, its own channel.  The reads are inline assembly on
@@ -102,6 +104,13 @@ __device__ __forceinline__ void tn_pin() {
                : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfr[set][0]), "+v"(bfr[set][1]), "+v"(bfr[set][2]),        \
                  "+v"(bfr[set][3]), "+v"(bfr[set][4]))
 
+// NZ = true (round 6, zero-frame skipping): the K walk visits only the frame rows whose gradient cells can be non-zero by the
+// frame flags.  Every wave builds the same per-window 64-bit masks with ballots (lane = frame) and walks them on the scalar unit
+// (lowest set bit = next frame row; the masks of the following windows wait in a shift register of SGPR pairs) -- no memory
+// operation inside the hand-counted K loop.  The rows left out contribute exact zeros: the sum is unchanged bit for bit.  With
+// the flipped operand order the gradient frame of a K row depends on the workgroup's frame shift z0, so workgroups of different
+// shifts skip different rows (their counts differ by at most the shift at the edges of the non-zero band).
+template <bool NZ>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnParams p) {
   extern __shared__ __attribute__((aligned(16))) char tl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -139,12 +148,62 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
   const long dA = TBK * pitchA, dB = TBK * pitchB;
   const long eA1 = p.rowA - (long)p.nchunk * dA, eB1 = p.rowB - (long)p.nchunk * dB;
   const long eA2 = p.winA - (long)p.nF * p.rowA, eB2 = p.winB - (long)p.nF * p.rowB;
-  const int nsteps = p.nchunk * p.nF * p.nW;
+  int nsteps = p.nchunk * p.nF * p.nW;
+  // NZ: live frame rows of the current window (bit f) and of the windows behind it; wa / wb: frame row 0 of the current window
+  unsigned long cur = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0;
+  const char *wa = pa, *wb = pb;
+  auto next_row = [&]() {                // (a live row remains: the caller counted)
+    while (cur == 0) {
+      cur = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = q6; q6 = q7; q7 = 0;
+      wa += p.winA;
+      wb += p.winB;
+    }
+    const int f = __builtin_ctzl(cur);
+    cur &= cur - 1;
+    pa = wa + (long)f * p.rowA;
+    pb = wb + (long)f * p.rowB;
+  };
+  if (NZ) {
+    unsigned long m[8];
+    int rows = 0;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) {
+      bool lv = false;
+      if (ww < p.nW && lane < p.nF) {
+        const int fr = p.nz_f0 + lane + (p.flip ? z0 : 0);
+        int a = fr - p.nz_radius, b = fr + p.nz_radius;
+        a = a < 0 ? 0 : a;
+        b = b > p.Fp - 1 ? p.Fp - 1 : b;
+        const int* row = p.nz_ps + (long)ww * (p.Fp + 1);
+        lv = row[b + 1] - row[a] > 0;
+      }
+      m[ww] = __ballot(lv);
+      rows += __builtin_popcountl(m[ww]);
+    }
+    cur = m[0]; q1 = m[1]; q2 = m[2]; q3 = m[3]; q4 = m[4]; q5 = m[5]; q6 = m[6]; q7 = m[7];
+    nsteps = p.nchunk * rows;
+    if (nsteps == 0 && p.accumulate) return;      // nothing to add
+    if (nsteps > 0) next_row();
+  }
   int st_c = 0, st_f = 0, st_left = nsteps;
   const char* sa_keep = pa;
   auto stage_1 = [&](int soff) {         // advance the K walk; the two B pieces and the first A piece of the tile
     sa_keep = pa;
     const char* sb = pb;
+    if (NZ) {
+      if (st_left > 1) {                 // a tile after this one exists
+        --st_left;
+        const int c = st_c + 1;
+        if (c < p.nchunk) {
+          st_c = c;
+          pa += dA;
+          pb += dB;
+        } else {
+          st_c = 0;
+          next_row();
+        }
+      }
+    } else {
     const unsigned adv = (unsigned)(1 - st_left) >> 31;        // a tile after this one exists
     st_left -= (int)adv;
     int c = st_c + 1;
@@ -158,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     const long k0 = -(long)w0, k1 = -(long)w1, ka = -(long)adv;
     pa += (dA + (eA1 & k0) + (eA2 & k1)) & ka;
     pb += (dB + (eB1 & k0) + (eB2 & k1)) & ka;
+    }
     char* la = tl + soff;
     char* lb = la + TA_BYTES;
     __builtin_amdgcn_global_load_lds((const void*)(sb + boff0), (tn_lds_ptr_t)(lb + w * 1024), 16, 0, 0);
@@ -213,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     wr = wr == (TNSTAGE - 1) * TSTAGE ? 0 : wr + TSTAGE;
   };
 
+  if (!NZ || nsteps > 0) {
   stage_1(0);
   stage_2(0);
   stage_1(TSTAGE);
@@ -291,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
     TN_WAIT(0, 1);
     mma(1);
   }
+  }   // nsteps > 0
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus prefetches must have landed before the LDS allocation goes away
   // ---- epilogue: fp32 accumulators [CA][25][CB]; every element belongs to exactly one workgroup (plain read-modify-write)
@@ -315,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tn_kernel(const WgradTnPara
 
 extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float* dwg, int32_t CA, int32_t CB, int32_t W,
                                    int32_t Fp, int32_t Wp, int32_t N, int32_t f0, int32_t nf, int32_t flip,
-                                   int32_t accumulate, void* stream) {
+                                   int32_t accumulate, const int32_t* nz_ps, int32_t nz_radius, void* stream) {
   if (!a_grid || !b_grid || !dwg) return DFOLD_EINVAL;
   if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBC) || W <= 0 || N <= 0 || (N % TBK) || N + 4 > Wp) return DFOLD_EINVAL;
   if (f0 < 0 || nf <= 0 || f0 + nf + 4 > Fp) return DFOLD_EINVAL;
@@ -330,8 +392,15 @@ extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float
   p.winA = (long)Fp * p.rowA; p.winB = (long)Fp * p.rowB;
   p.nchunk = N / TBK; p.nF = nf; p.nW = W;
   p.flip = flip ? 1 : 0; p.accumulate = accumulate ? 1 : 0;
+  p.nz_ps = nz_ps; p.nz_radius = nz_radius; p.nz_f0 = flip ? f0 : f0 + 2; p.Fp = Fp;
   const unsigned nwg = (unsigned)((CA / TBM) * 5 * (CB / TBC));
-  DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel, TNSTAGE * TSTAGE);
-  DFOLD_LAUNCH(conv_wgrad_tn_kernel, dim3(nwg), dim3(512), (size_t)(TNSTAGE * TSTAGE), (hipStream_t)stream, p);
+  if (nz_ps) {
+    if (nz_radius < 0 || nf > 64 || W > 8) return DFOLD_EINVAL;
+    DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel<true>, TNSTAGE * TSTAGE);
+    DFOLD_LAUNCH(conv_wgrad_tn_kernel<true>, dim3(nwg), dim3(512), (size_t)(TNSTAGE * TSTAGE), (hipStream_t)stream, p);
+  } else {
+    DFOLD_MAX_LDS_ONCE(conv_wgrad_tn_kernel<false>, TNSTAGE * TSTAGE);
+    DFOLD_LAUNCH(conv_wgrad_tn_kernel<false>, dim3(nwg), dim3(512), (size_t)(TNSTAGE * TSTAGE), (hipStream_t)stream, p);
+  }
   return dfold_check_launch();
 }

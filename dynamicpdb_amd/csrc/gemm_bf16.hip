@@ -702,6 +702,8 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.nb1 = d->nb1 > 0 ? d->nb1 : 1; p.flags = d->flags; p.alpha = d->alpha;
   p.ws = nullptr; p.cnt = nullptr; p.sk_per = 0; p.sk_tiles = 0; p.sk_fence = 1;
   p.conv_f0 = (d->conv_frames >> 16) & 0x7fff; p.conv_F = d->conv_frames & 0xffff;
+  p.nz_ps = d->nz_ps; p.nz_radius = d->nz_radius; p.nz_f0 = d->nz_f0;
+  if (p.nz_ps && (d->a_rows.mode != 1 || p.nz_radius < 0 || p.nz_f0 < 0)) return DFOLD_EINVAL;
   static int prio_mode = -1;
   if (prio_mode < 0) {
     const char* e = getenv("DFOLD_GEMM_PRIO");
@@ -726,14 +728,17 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       (d->a_rows.n % BM3) == 0 && (d->M % BM3) == 0 && d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && p.conv_F == 0 &&
       d->a_seg_s0 == BK && d->b_seg_s0 == BK && (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 &&
       a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
-    static int sk_env = -1, n_cu = 0;
+    static int sk_env = -1;
+    static int n_cus[64] = {0};             // per device (0: not asked yet)
     if (sk_env < 0) {
       const char* e = getenv("DFOLD_CONV_W4");
       const char* h = getenv("DFOLD_CONV_HALO");
       sk_env = (!e || atoi(e) != 0) && (!h || atoi(h) != 0) ? 1 : 0;
-      int dev = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (n_cus[dev] == 0 && hipDeviceGetAttribute(&n_cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus[dev] = 0;
+      n_cu = n_cus[dev];
     }
     if (sk_env && n_cu > 0) {
       p.ws = d->splitk_ws; p.cnt = d->splitk_cnt;

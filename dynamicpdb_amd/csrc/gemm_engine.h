@@ -34,6 +34,8 @@ struct GemmParams {
   int* cnt;     // split-K arrival counters, one per output tile
   int sk_per, sk_tiles;   // stream-K form of conv_fwd_w4.hip: (tile, K group) units per workgroup, output tiles
   int sk_fence;           // conv_fwd_w4.hip: the partial-tile workspace is ordinary (L2-cached) memory: hand-overs need fences
+  const int* nz_ps;       // zero-frame skipping (dfold_gemm_desc.nz_ps; nullptr: none): prefix sums [window][fp + 1]
+  int nz_radius, nz_f0;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -266,8 +266,15 @@ class ConvTowerFn(Function):
             raise RuntimeError("ConvTowerFn.backward: forward ran without activation tracking (no_grad) or twice")
         tower.check_slot(ctx.slot, ctx.gen)
         gt = tower.ws.get("gtop", (g.Wn, g.Fp, g.Wp, gy.shape[-1]), zero=ctx.last)
+        nz_ps = None
         if ctx.last:
             g.interior(gt)[:, -1:].copy_(gy)            # (gy is [W,1,N,C] in this mode)
+        elif ops.CONV_NZ and gy.dtype == ops.BF16 and gy.is_contiguous():
+            # one pass: the copy into the padded grid + which frames of the incoming gradient hold a non-zero at all.  The
+            # reference's loss reads the last frame (train_DFOLD_dynamics.py:1219-1340), a loss that reads every frame flags
+            # every frame: the launches below decide on the device, per tile, what is left to compute (ops.ConvTower.backward)
+            nz_ps = ops.grid_load_flags(g, gy, gt, tower.ws.get("nz_ps", (g.Wn, g.Fp + 1), torch.int32),
+                                        tower.ws.get("nz_scratch", (g.Wn * g.Fp + 1,), torch.int32))
         else:
             g.interior(gt).copy_(gy)
         # The application whose backward runs last delivers the summed gradients.  With a data-parallel reducer registered
@@ -276,7 +283,7 @@ class ConvTowerFn(Function):
         # compute; otherwise the gradients are returned through autograd like any other node's.
         last = tower.pending_in_group(ctx.token) <= 1
         early = last and tower.on_final is not None
-        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=early)
+        g0 = tower.backward(g, ctx.saved, gt, last_frame_only=ctx.last, finalize=early, nz_ps=nz_ps)
         ctx.saved = None
         tower.complete_application(ctx.token)
         ctx.token = None

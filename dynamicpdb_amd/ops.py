@@ -49,7 +49,7 @@ def seg_table(values, device):
 
 def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=None, C2=None, R2=None,
          a_seg=None, b_seg=None, seg_div=1, seg_div_mid=0, nbatch=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), flags=0, alpha=1.0,
-         a_off=0, b_off=0, c_off=0, splitk=1, splitk_ws=None, splitk_cnt=None, conv_frames=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, splitk_ws=None, splitk_cnt=None, conv_frames=0, nz=None):
     """C = epi(alpha * A @ B^T) on the bf16 MFMA engine; see dfold_gemm_desc in include/dfold_hip.h."""
     assert A.dtype == BF16 and B.dtype == BF16
     if C.dtype == BF16:
@@ -79,6 +79,8 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.splitk, d.conv_frames = splitk, conv_frames
     split = splitk > 1 or splitk == -1
     d.splitk_ws, d.splitk_cnt = _p(splitk_ws if split else None), _p(splitk_cnt if split else None)
+    if nz is not None:           # (frame-flag prefix sums, radius, padded frame row of logical frame 0): dfold_gemm_desc.nz_ps
+        d.nz_ps, d.nz_radius, d.nz_f0 = _p(nz[0]), nz[1], nz[2]
     check(_lib.lib().dfold_gemm_bf16(byref(d), stream()), "dfold_gemm_bf16")
     return C
 
@@ -294,6 +296,8 @@ def conv_splitk(M, CO, CI, device):
 
 
 _STREAMK = os.environ.get("DFOLD_CONV_STREAMK", "1") != "0"
+# zero-frame skipping in the tower's backward (ConvTower.backward, functional.ConvTowerFn.backward); 0: every launch walks all of K
+CONV_NZ = os.environ.get("DFOLD_CONV_NZ", "1") != "0"
 _TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
 
 
@@ -316,9 +320,11 @@ _SKIP_PAD_TAPS = os.environ.get("DFOLD_CONV_SKIP_PAD", "0") == "1"
 
 
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
-                f_lo=0, nf=None, ws=None):
+                f_lo=0, nf=None, ws=None, nz=None):
     """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO].
-    f_lo / nf: only the output cells of frames [f_lo, f_lo + nf) are computed (they read x frames f_lo-2 .. f_lo+nf+1)."""
+    f_lo / nf: only the output cells of frames [f_lo, f_lo + nf) are computed (they read x frames f_lo-2 .. f_lo+nf+1).
+    nz = (ps, radius): frame flags of grid_load_flags and the distance within which x can be non-zero around the flagged
+    frames; output tiles whose input frames are all zero by that statement skip their K walk on the device."""
     CO, _, CI = wf.shape
     flags = GEMM_RELU if relu else 0
     R = None
@@ -339,7 +345,7 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         nf_b = conv_tail_frames(nf, (g.Wn * g.N // 512) * (CO // 160), _N_CU[x.device])
         if nf_b:
             kw = dict(relu=relu, resid=resid, pre_resid_out=pre_resid_out, relu_mask=relu_mask,
-                      C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws)
+                      C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws, nz=nz)
             conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo, nf=nf - nf_b, **kw)
             return conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo + nf - nf_b, nf=nf_b, **kw)
     S, sk = 1, {}
@@ -354,7 +360,8 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
                       splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * _N_CU[x.device],), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
                 c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
-                seg_div=5, seg_div_mid=5, flags=flags, conv_frames=(f_lo << 16) | g.F if _SKIP_PAD_TAPS else 0)
+                seg_div=5, seg_div_mid=5, flags=flags, conv_frames=(f_lo << 16) | g.F if _SKIP_PAD_TAPS else 0,
+                nz=None if nz is None else (nz[0], nz[1], f_lo))
 
 
 def grid_transpose_shift(g, x, C, d0, nd, out, colsum=None, f0=0, nf=None):
@@ -378,8 +385,19 @@ def wgrad_tn_ok(g, CI, CO):
     return g.N % 64 == 0 and max(CI, CO) % 256 == 0 and min(CI, CO) % 64 == 0
 
 
-def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=None):
-    """conv5x5_wgrad without operand copies (same accumulator layouts, same frame-range semantics)."""
+def grid_load_flags(g, src, grid, ps, scratch, f_off=0):
+    """src bf16 [Wn,nf,N,C] (None: read the grid) -> interior frames [f_off, f_off+nf) of the padded grid; ps int32 [Wn, F+5]:
+    prefix sums of the non-zero frame flags (dfold_grid_load_flags).  scratch int32 [Wn*(F+4)+1], zero on entry and exit."""
+    C = grid.shape[-1]
+    nf = g.F - f_off if src is None else src.shape[1]
+    check(_lib.lib().dfold_grid_load_flags(_p(src), _p(grid), _p(ps), _p(scratch), c_int32(g.Wn), c_int32(g.F), c_int32(g.N),
+                                           c_int32(C), c_int32(f_off), c_int32(nf), stream()), "dfold_grid_load_flags")
+    return ps
+
+
+def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=None, nz=None):
+    """conv5x5_wgrad without operand copies (same accumulator layouts, same frame-range semantics).
+    nz = (ps, radius): frame flags for gy (grid_load_flags): frame rows in which gy is zero by them leave the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
     F = g.F - f_lo if nf is None else nf
     if bias_grad is not None:      # the bias gradient used to ride on the transposing copy of gy: one column-sum pass now
@@ -396,13 +414,22 @@ def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=
         F = min(g.F, f_lo + F + 2) - lo
         f_lo = lo
         a, b, flip = x, gy, 1
-    check(_lib.lib().dfold_conv_wgrad_tn(_p(a), _p(b), _p(dwg), c_int32(a.shape[-1]), c_int32(b.shape[-1]), c_int32(g.Wn),
-                                         c_int32(g.Fp), c_int32(g.Wp), c_int32(g.N), c_int32(f_lo), c_int32(F), c_int32(flip),
-                                         c_int32(1 if accumulate else 0), stream()), "dfold_conv_wgrad_tn")
+    if nz is not None and F > 64:
+        nz = None                    # (the kernel's frame masks are 64 bits per window)
+    # with frame flags the kernel takes at most 8 windows per call (its masks live in scalar registers)
+    step = g.Wn if nz is None else 8
+    for w0 in range(0, g.Wn, step):
+        wn = min(step, g.Wn - w0)
+        check(_lib.lib().dfold_conv_wgrad_tn(_p(a, w0 * g.Fp * g.Wp * a.shape[-1]), _p(b, w0 * g.Fp * g.Wp * b.shape[-1]), _p(dwg),
+                                             c_int32(a.shape[-1]), c_int32(b.shape[-1]), c_int32(wn), c_int32(g.Fp), c_int32(g.Wp),
+                                             c_int32(g.N), c_int32(f_lo), c_int32(F), c_int32(flip),
+                                             c_int32(1 if (accumulate or w0 > 0) else 0),
+                                             _p(None if nz is None else nz[0], w0 * (g.Fp + 1)), c_int32(0 if nz is None else nz[1]),
+                                             stream()), "dfold_conv_wgrad_tn")
     return dwg
 
 
-def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf=None, tn=None):
+def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf=None, tn=None, nz=None):
     """dW (+)= sum_cells gy[cell] (x) x[cell+tap].  x [.., CI], gy [.., CO] padded grids.  The narrower operand gets the 5
     column-shifted transposed copies, the wider one a single copy; the WIDER operand is always the GEMM's M side
     (1280 = 5 x 256 rows, the narrow 640 = 2 x 320 columns: both tile exactly), so
@@ -412,7 +439,7 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
     f_lo / nf: gy is zero outside frames [f_lo, f_lo + nf): only those cells enter the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
     if (_WGRAD_TN if tn is None else tn) and wgrad_tn_ok(g, CI, CO):
-        return conv5x5_wgrad_tn(g, x, gy, dwg, accumulate, bias_grad, f_lo, nf)
+        return conv5x5_wgrad_tn(g, x, gy, dwg, accumulate, bias_grad, f_lo, nf, nz)
     plane, N = g.plane, g.NP        # N: K-run length of one frame row in the transposed copies
     tag = "" if g.N == g.NP else "_n%d" % g.N   # ragged N: own scratch (its pad columns must never have been written)
     F = g.F - f_lo if nf is None else nf
@@ -657,14 +684,19 @@ class ConvTower:
             h = hn
         return h, saved
 
-    def _wgrad(self, g, j, x, gy, f_lo, nf, finalize):
-        conv5x5_wgrad(g, x, gy, self.dwg[j], self.ws, accumulate=not self.fresh[j], bias_grad=self.db[j], f_lo=f_lo, nf=nf)
+    def _wgrad(self, g, j, x, gy, f_lo, nf, finalize, nz=None):
+        conv5x5_wgrad(g, x, gy, self.dwg[j], self.ws, accumulate=not self.fresh[j], bias_grad=self.db[j], f_lo=f_lo, nf=nf, nz=nz)
         self.fresh[j] = False
         if finalize:
             self.finalize_layer(j)
 
-    def backward(self, g, saved, gtop, last_frame_only=False, finalize=False):
+    def backward(self, g, saved, gtop, last_frame_only=False, finalize=False, nz_ps=None):
         """gtop: dL/dh4 on the padded grid (border zero).  Accumulates dwg/db, returns dL/dh0.
+        nz_ps (all-frames mode): the frame flags of gtop (grid_load_flags).  The gradient of stage k of the chain below can
+        only be non-zero within 2k frames of a flagged frame (each 5x5 conv widens the set by two frames, masks and residual
+        sums do not widen it): every launch is handed the flags with its radius and skips, on the device, the output tiles
+        (data gradient) / reduction rows (weight gradient) that are zero by that statement -- loss-agnostic, no host sync,
+        results bit-identical to the full launches (the skipped terms are exact zeros).
         finalize: this is the last application of the step whose backward runs (ConvTowerFn counts them): every layer's
         gradient is handed to .grad right after its weight-gradient product here (finalize_layer).
         last_frame_only: gtop is nonzero on frame F-1 only (see cone()); gradients are propagated inside the cone,
@@ -685,17 +717,20 @@ class ConvTower:
             if last_frame_only and i == 0:
                 n0 = min(g.F, 17)
                 l0 = g.F - n0
-            self._wgrad(g, 2 * i + 1, u, dv, l2, n2, finalize)
+            r0 = 4 * (3 - i)            # gi and dv: within r0 frames of a flagged frame of gtop; du: r0 + 2
+            nz0 = None if (nz_ps is None or last_frame_only) else (nz_ps, r0)
+            nz2 = None if nz0 is None else (nz_ps, r0 + 2)
+            self._wgrad(g, 2 * i + 1, u, dv, l2, n2, finalize, nz0)
             du = ws.get("du", tuple(u.shape))
             sws = ws
-            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws)
-            self._wgrad(g, 2 * i, hprev, du, l1, n1, finalize)
+            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws, nz=nz0)
+            self._wgrad(g, 2 * i, hprev, du, l1, n1, finalize, nz2)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
                 conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2],
-                            f_lo=l0, nf=n0, ws=sws)
+                            f_lo=l0, nf=n0, ws=sws, nz=nz2)
             else:
-                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0, ws=sws)
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0, ws=sws, nz=nz2)
             gi = gn
         return gi
 

@@ -31,9 +31,10 @@ extern "C" {
 
 /* Bumped whenever a signature, a pointer's element type or a struct layout changes (2: round-3 changes of
  * dfold_ipa_softmax_bwd / dfold_ipa_col_bwd (bf16 probabilities, `ctr`) and dfold_ipa_bias_grad (`nh_pitch`); the
- * round-4 additions).  The Python binding reads the number from THIS header and refuses a library that reports
+ * round-4 additions; 3: round 6, the zero-frame fields at the end of dfold_gemm_desc, the two extra arguments of
+ * dfold_conv_wgrad_tn, dfold_grid_load_flags).  The Python binding reads the number from THIS header and refuses a library that reports
  * another one (dynamicpdb_amd/_lib.py), so a stale or variant .so cannot be called with shifted arguments. */
-#define DFOLD_ABI_VERSION 2
+#define DFOLD_ABI_VERSION 3
 int dfold_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -102,6 +103,17 @@ typedef struct {
   int32_t conv_frames;
   float* splitk_ws;
   int32_t* splitk_cnt;
+  /* Zero-frame skipping of a 5x5 conv launch (optional; round 6).  nz_ps = the per-window prefix sums that
+     dfold_grid_load_flags writes for some grid G0: int32 [windows][fp + 1], nz_ps[w][i] = number of padded frame rows j < i of
+     window w in which G0 holds a non-zero.  The caller asserts that A is exactly zero on every padded frame row that is more
+     than nz_radius rows away from all non-zero rows of G0 (true by construction when A was produced from G0 by nz_radius / 2
+     5x5 convolutions, element-wise masks and sums with grids of the same property: the data-gradient chain of the tower).
+     An output tile all of whose input frame rows are zero by that statement does not walk K: its accumulators are zero and
+     the epilogue runs as usual (results identical to the full walk: the skipped products are exact zeros).  Decided on the
+     device per tile; no host synchronisation.  nz_f0 = padded frame row of the first tap row of logical frame 0 of a_rows.
+     Launches that do not take the 512 x 160 kernel, and stream-K launches, ignore the fields (same results). */
+  const int32_t* nz_ps;
+  int32_t nz_radius, nz_f0;
 } dfold_gemm_desc;
 
 int dfold_gemm_bf16(const dfold_gemm_desc* desc, void* stream);
@@ -141,9 +153,22 @@ int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t
      tap = 5 z0 + z1, or 24 - (5 z0 + z1) when flip != 0
    A bf16 [W][Fp][Wp][CA], B bf16 [W][Fp][Wp][CB], dWg fp32 [CA][25][CB] (overwritten unless accumulate != 0).
    With A = dL/dy (CA = CO), B = x: dWg = dW in the [CO][25][CI] layout of dfold_conv_wgrad_unpack; with A = x, B = dL/dy and
-   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 64 == 0, N % 64 == 0, grids 16-byte aligned. */
+   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 64 == 0, N % 64 == 0, grids 16-byte aligned.
+   nz_ps / nz_radius (optional, NULL / 0 = none): the frame flags of dfold_grid_load_flags for the GRADIENT operand (A, or B
+   when flip != 0), as in dfold_gemm_desc: frame rows of the reduction whose gradient cells are zero by that statement are
+   left out of the K walk (exact zeros: the sum is unchanged bit for bit); needs nf <= 64, at most 8 windows per call. */
 int dfold_conv_wgrad_tn(const void* A, const void* B, float* dWg, int32_t CA, int32_t CB, int32_t W, int32_t Fp, int32_t Wp,
-                        int32_t N, int32_t f0, int32_t nf, int32_t flip, int32_t accumulate, void* stream);
+                        int32_t N, int32_t f0, int32_t nf, int32_t flip, int32_t accumulate, const int32_t* nz_ps,
+                        int32_t nz_radius, void* stream);
+/* Copies src bf16 [W][nf][N][C] (dense) into the interior cells of frames [f_off, f_off + nf) of the zero-padded grid
+   bf16 [W][F+4][N+4][C] (src NULL: the grid is read as it lies, nothing is written) and records which of those frame rows
+   hold a non-zero: ps int32 [W][F+5], ps[w][i] = number of padded frame rows j < i of window w with a non-zero cell (rows
+   outside the range count as zero -- the caller's statement).  scratch: (F+4) * W + 1 int32, zero before the call and left
+   zero.  The gradient that enters the tower's backward (aten convolution_backward of ConvNet, ipa_pytorch_dynamic.py:692-706)
+   is zero on every frame no loss term reads; the flags let the data / weight gradient launches skip those frames without a
+   contract with the loss and without a device -> host copy.  N * C a multiple of 8, 16-byte aligned pointers. */
+int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, int32_t* scratch, int32_t W, int32_t F, int32_t N,
+                          int32_t C, int32_t f_off, int32_t nf, void* stream);
 /* out[c] += sum_r X[r*ld + c]   (X bf16, out fp32, atomics) */
 int dfold_colsum_bf16(const void* X, float* out, int64_t R, int32_t C, int64_t ld, void* stream);
 /* the same over nbatch row blocks of R rows each, block z starting bstride elements after block z - 1 (one frame range of every

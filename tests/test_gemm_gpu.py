@@ -342,6 +342,79 @@ def test_conv_splitk_matches_unsplit(dev):
         assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
 
 
+@pytest.mark.parametrize("Wn,dense", [(8, False), (9, False), (8, True)])
+def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense):
+    """Round 6: the tower's backward with the frame flags of the incoming gradient (dfold_grid_load_flags -> nz_ps / radius on
+    every data- and weight-gradient launch) against the same backward without them: bit-identical data gradient, weight and
+    bias gradients -- the tiles / reduction rows left out are exact zeros.  Sparse case: a gradient that lives on a few frames
+    (one window all zero, one with two separate frames); dense case (a loss that reads every frame): nothing can be skipped and
+    nothing changes.  9 windows: the weight-gradient kernel takes 8 windows per call.  Also: the flags are what the gradient
+    says, and a launch handed all-zero flags computes nothing (the kernels do honour them)."""
+    from dynamicpdb_amd import ops
+    F, N, C = 8, 256, 1280
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    ws = [(torch.randn(co, ci, 5, 5, generator=gen) * (2.0 / (25 * ci)) ** 0.5).to(dev)
+          for _ in range(4) for (co, ci) in ((C // 2, C), (C, C // 2))]
+    bs = [(torch.randn(w.shape[0], generator=gen) * 0.1).to(dev) for w in ws]
+    x = torch.randn(Wn, F, N, C, generator=gen).to(torch.bfloat16).to(dev)
+    gy = torch.zeros(Wn, F, N, C, dtype=torch.bfloat16, device=dev)
+    if dense:
+        gy.copy_(torch.randn(Wn, F, N, C, generator=gen).to(torch.bfloat16))
+    else:
+        for w in range(Wn):
+            if w == 5:
+                continue                                       # a window without any gradient
+            gy[w, F - 1, :, :] = torch.randn(N, C, generator=gen).to(torch.bfloat16).to(dev)
+        gy[3, 0, 7, 100] = 0.5                                  # a second, separate frame in one window: a single element
+        gy[2, F - 1] = 0
+        gy[2, 4, 200:, :64] = -0.0                              # negative zeros are zeros
+    g = ops.Grid(Wn, F, N, dev)
+    tower = ops.ConvTower(ws, bs)
+    tower.pack()
+    h0 = g.alloc(C)
+    g.interior(h0).copy_(x)
+    _, saved = tower.forward(g, h0)
+    res = []
+    ps = torch.full((Wn, g.Fp + 1), -1, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(Wn * g.Fp + 1, dtype=torch.int32, device=dev)
+    for use in (False, True, True):
+        tower.zero_grad()
+        gt = torch.full((Wn, g.Fp, g.Wp, C), 0, dtype=torch.bfloat16, device=dev)
+        if use:
+            ops.grid_load_flags(g, gy, gt, ps, scratch)
+            assert torch.equal(g.interior(gt), gy) and int(scratch.abs().max()) == 0
+            flags = torch.zeros(Wn, g.Fp, dtype=torch.int32, device=dev)
+            flags[:, 2:-2] = ((gy.view(torch.int16) & 0x7fff) != 0).flatten(2).any(-1).int()
+            want = torch.cat([flags.new_zeros(Wn, 1), flags.cumsum(1)], 1).int()
+            assert torch.equal(ps, want)
+        else:
+            g.interior(gt).copy_(gy)
+        g0 = tower.backward(g, saved, gt, nz_ps=ps if use else None)
+        res.append((g0.clone(), [d.clone() for d in tower.dwg], [d.clone() for d in tower.db]))
+    for k in (1, 2):
+        assert torch.equal(res[k][0], res[0][0])
+        for a, b in zip(res[k][1], res[0][1]):
+            assert torch.equal(a, b)
+        for a, b in zip(res[k][2], res[0][2]):      # (the bias gradients are column sums with fp32 atomics: not flag-dependent,
+            assert rel_l2(a, b) < 1e-5              #  and not bit-reproducible from run to run either)
+    assert float(res[0][0].float().abs().max()) > 0 and float(res[0][1][0].abs().max()) > 0
+    # the flags are honoured: all-zero flags -> the data-gradient launch writes the epilogue of a zero product, the weight
+    # gradient adds nothing / stores zeros
+    zero_ps = torch.zeros_like(ps)
+    gt = g.alloc(C)
+    g.interior(gt).copy_(torch.randn(Wn, F, N, C, generator=gen).to(torch.bfloat16))
+    du = torch.full((Wn, g.Fp, g.Wp, C // 2), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.conv5x5_fwd(g, gt, tower.wd[7], None, du, relu=False, nz=(zero_ps, 0))
+    assert float(g.interior(du).float().abs().max()) == 0
+    dw = torch.full_like(tower.dwg[7], 3.0)
+    ops.conv5x5_wgrad_tn(g, saved[10], gt, dw, accumulate=True, nz=(zero_ps, 0))
+    assert float((dw - 3.0).abs().max()) == 0
+    ops.conv5x5_wgrad_tn(g, saved[10], gt, dw, accumulate=False, nz=(zero_ps, 0))
+    assert float(dw.abs().max()) == 0
+    ops.conv5x5_wgrad_tn(g, saved[10], gt, dw, accumulate=False)
+    assert float(dw.abs().max()) > 0
+
+
 def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
     """csrc/conv_fwd_w4.hip (512 x 160 tile, one wave per SIMD, 32-channel halo groups): unsplit conv launches whose tiles are
     runs of 256 consecutive residues.  Whole outputs against fp64 conv2d on the same bf16 operands for every epilogue of the
