@@ -481,11 +481,13 @@ extern "C" int dfold_transpose_bf16(const void* src, void* dst, int32_t R, int32
 // ---------------------------------------------------------------------------------------------
 // dense [W][nf][N][C] -> interior of the padded grid, plus the non-zero frame flags of the tower's backward (round 6)
 // ---------------------------------------------------------------------------------------------
-// One frame row of the interior is ONE contiguous run of N*C elements in both tensors.  A block copies 8 KiB pieces of a row
+// One frame row of the interior is ONE contiguous run of N*C elements in both tensors.  A block copies 32 KiB pieces of a row
 // (16-byte vectors, 8 loads in flight per thread), ORs what it saw and raises the row's flag with one device-scope atomic per
-// wave that met a non-zero; the last block to arrive turns the flags into per-window prefix sums and leaves the scratch zero.
+// wave that met a non-zero (none at all on a zero frame); a second, single-block launch turns the flags into per-window prefix
+// sums and leaves the scratch zero.  (First version: the last block to arrive did that -- 5120 blocks taking a ticket from ONE
+// counter serialised the launch at 0.29 ms for 336 MB; profiles/r6_kernel_stats.csv.)
 #define GLF_VPT 8
-__global__ __launch_bounds__(256) void grid_load_flags_kernel(const uint4* __restrict__ src, uint4* __restrict__ grid, int* __restrict__ ps,
+__global__ __launch_bounds__(256) void grid_load_flags_kernel(const uint4* __restrict__ src, uint4* __restrict__ grid,
                                                               int* __restrict__ scratch, int W, int F, int N, int C, int f_off, int nf,
                                                               long nvec_row) {
   const int Fp = F + 4, Wp = N + 4;
@@ -509,27 +511,19 @@ __global__ __launch_bounds__(256) void grid_load_flags_kernel(const uint4* __res
     if (src && i < nvec_row) d[i] = v[k];
   }
   if (__ballot(any != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(scratch + w * Fp + f_off + f + 2, 1);
-  __shared__ int s_last;
-  __syncthreads();
-  const int nblocks = gridDim.x * gridDim.y * gridDim.z;
-  int* counter = scratch + W * Fp;
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(counter, 1) == nblocks - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
+}
+
+__global__ __launch_bounds__(256) void frame_flags_prefix_kernel(int* __restrict__ ps, int* __restrict__ scratch, int W, int Fp) {
   for (int ww = threadIdx.x; ww < W; ww += 256) {
     int run = 0;
     int* o = ps + (long)ww * (Fp + 1);
     o[0] = 0;
     for (int j = 0; j < Fp; ++j) {
-      run += atomicExch(scratch + ww * Fp + j, 0) != 0 ? 1 : 0;
+      run += scratch[ww * Fp + j] != 0 ? 1 : 0;
+      scratch[ww * Fp + j] = 0;
       o[j + 1] = run;
     }
   }
-  if (threadIdx.x == 0) atomicExch(counter, 0);
 }
 
 extern "C" int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, int32_t* scratch, int32_t W, int32_t F, int32_t N,
@@ -539,7 +533,9 @@ extern "C" int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, i
   const long nvec = (long)N * C / 8;
   const unsigned bx = (unsigned)((nvec + 256 * GLF_VPT - 1) / (256 * GLF_VPT));
   DFOLD_LAUNCH(grid_load_flags_kernel, dim3(bx, (unsigned)nf, (unsigned)W), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
-               (uint4*)grid, ps, scratch, W, F, N, C, f_off, nf, nvec);
+               (uint4*)grid, scratch, W, F, N, C, f_off, nf, nvec);
+  if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
+  DFOLD_LAUNCH(frame_flags_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ps, scratch, W, F + 4);
   return dfold_check_launch();
 }
 

@@ -97,9 +97,20 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
     for (int r = 0; r < 2; ++r) {
       const int m = m0 + 256 * r;
       if (m < M) {
-        const unsigned wf = (unsigned)m / (unsigned)p.am.n;
-        const unsigned ww = wf / (unsigned)p.am.f, ff = wf - ww * (unsigned)p.am.f;
-        int a = p.nz_f0 + (int)ff - p.nz_radius, b = p.nz_f0 + (int)ff + 4 + p.nz_radius;
+        unsigned ww, ff, fl;          // window, first and last logical frame of the run's output cells
+        if (p.am.mode == 2) {
+          const unsigned vw = row_vw(p.am), v = (unsigned)m - ((unsigned)m / vw) * vw;
+          ww = (unsigned)m / vw;
+          ff = v / (unsigned)p.am.wp;
+          fl = (v + 255u) / (unsigned)p.am.wp;
+          if (ff >= (unsigned)p.am.f) continue;             // a run behind the last frame: nothing of it is stored
+          fl = fl < (unsigned)p.am.f ? fl : (unsigned)p.am.f - 1u;
+        } else {
+          const unsigned wf = (unsigned)m / (unsigned)p.am.n;
+          ww = wf / (unsigned)p.am.f;
+          ff = fl = wf - ww * (unsigned)p.am.f;
+        }
+        int a = p.nz_f0 + (int)ff - p.nz_radius, b = p.nz_f0 + (int)fl + 4 + p.nz_radius;
         a = a < 0 ? 0 : a;
         b = b > p.am.fp - 1 ? p.am.fp - 1 : b;
         const int* row = p.nz_ps + (long)ww * fp1;

@@ -379,7 +379,12 @@ extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float
                                    int32_t Fp, int32_t Wp, int32_t N, int32_t f0, int32_t nf, int32_t flip,
                                    int32_t accumulate, const int32_t* nz_ps, int32_t nz_radius, void* stream) {
   if (!a_grid || !b_grid || !dwg) return DFOLD_EINVAL;
-  if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBC) || W <= 0 || N <= 0 || (N % TBK) || N + 4 > Wp) return DFOLD_EINVAL;
+  if (CA <= 0 || CB <= 0 || (CA % TBM) || (CB % TBC) || W <= 0 || N <= 0 || N + 4 > Wp) return DFOLD_EINVAL;
+  // N_res that is not a multiple of the 64-cell K chunk: the frame range of a window is walked as ONE line of nf * Wp cells (pad
+  // columns included: the gradient grid is zero there, and behind its last frame) in ceil(nf * Wp / 64) chunks.  The last chunk
+  // of the last window reads up to 67 cells past the end of the shifted operand: the caller keeps them readable and finite.
+  const bool linear = (N % TBK) != 0;
+  if (linear && nz_ps) return DFOLD_EINVAL;
   if (f0 < 0 || nf <= 0 || f0 + nf + 4 > Fp) return DFOLD_EINVAL;
   if (((uintptr_t)a_grid | (uintptr_t)b_grid) & 15) return DFOLD_EINVAL;
   if ((long)(TBK + 8) * CA * 2 >= (1L << 31) || (long)(TBK + 8) * CB * 2 >= (1L << 31)) return DFOLD_EINVAL;   // 32-bit lane offsets
@@ -390,7 +395,7 @@ extern "C" int dfold_conv_wgrad_tn(const void* a_grid, const void* b_grid, float
   p.CA = CA; p.CB = CB;
   p.rowA = (long)Wp * CA * 2; p.rowB = (long)Wp * CB * 2;
   p.winA = (long)Fp * p.rowA; p.winB = (long)Fp * p.rowB;
-  p.nchunk = N / TBK; p.nF = nf; p.nW = W;
+  p.nchunk = linear ? (nf * Wp + TBK - 1) / TBK : N / TBK; p.nF = linear ? 1 : nf; p.nW = W;
   p.flip = flip ? 1 : 0; p.accumulate = accumulate ? 1 : 0;
   p.nz_ps = nz_ps; p.nz_radius = nz_radius; p.nz_f0 = flip ? f0 : f0 + 2; p.Fp = Fp;
   const unsigned nwg = (unsigned)((CA / TBM) * 5 * (CB / TBC));

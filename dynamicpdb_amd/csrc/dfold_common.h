@@ -73,13 +73,30 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 //   mode 0: base + m*ld
 //   mode 1: frame x residue grid stored zero-padded for the 5x5 conv tower:
 //           m = (w*F + f)*N + n  ->  base + (((w*Fp + f)*Wp) + n)*ld   (ld = channels)
+//   mode 2 (round 6, any N_res): the same grid walked as ONE line of cells per window -- row m = (w, v), v < VW =
+//           f*wp rounded up to whole 256-row runs, is cell v of window w counted along the padded frame rows (pad columns
+//           included): base + ((w*fp*wp) + v)*ld.  A run of 256 consecutive rows is 256 consecutive cells whatever N is (the conv
+//           taps stay constant offsets); rows that fall on a pad column (v % wp >= n) or behind the last frame (v >= f*wp) are
+//           computed and never stored (row_valid).
 struct RowMap {
   long base;
   long ld;
   int mode, n, f, fp, wp;
 };
+__device__ __forceinline__ unsigned row_vw(const RowMap& r) { return ((unsigned)(r.f * r.wp) + 255u) & ~255u; }
+__device__ __forceinline__ bool row_valid(const RowMap& r, long m) {
+  if (r.mode != 2) return true;
+  const unsigned vw = row_vw(r), um = (unsigned)m;
+  const unsigned v = um - (um / vw) * vw;
+  return v < (unsigned)(r.f * r.wp) && v - (v / (unsigned)r.wp) * (unsigned)r.wp < (unsigned)r.n;
+}
 __device__ __forceinline__ long row_off(const RowMap& r, long m) {
   if (r.mode == 0) return r.base + m * r.ld;
+  if (r.mode == 2) {
+    const unsigned vw = row_vw(r), um = (unsigned)m;
+    const unsigned w = um / vw, v = um - w * vw;
+    return r.base + ((long)w * (r.fp * r.wp) + v) * r.ld;
+  }
   // logical row counts are < 2^31 (int32 M at the ABI): 32-bit divisions (a 64-bit one costs ~10x more VALU)
   const unsigned um = (unsigned)m;
   const unsigned wf = um / (unsigned)r.n;

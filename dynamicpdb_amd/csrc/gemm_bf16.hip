@@ -666,8 +666,13 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
 
 
 
+static long row_vw_host(const RowMap& r) { return ((long)r.f * r.wp + 255) / 256 * 256; }
 static long row_off_host(const RowMap& r, long m) {
   if (r.mode == 0) return r.base + m * r.ld;
+  if (r.mode == 2) {
+    const long vw = row_vw_host(r), w = m / vw, v = m - w * vw;
+    return r.base + (w * ((long)r.fp * r.wp) + v) * r.ld;
+  }
   const long wf = m / r.n, n = m - wf * r.n, w = wf / r.f, f = wf - w * r.f;
   return r.base + (((w * r.fp + f) * r.wp) + n) * r.ld;
 }
@@ -686,8 +691,14 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   if ((d->flags & DFOLD_GEMM_BIAS) && !d->bias) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) && !d->R) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
-  if (d->a_rows.mode == 1 && (d->a_rows.n <= 0 || d->a_rows.f <= 0)) return DFOLD_EINVAL;
-  if (d->c_rows.mode == 1 && (d->c_rows.n <= 0 || d->c_rows.f <= 0)) return DFOLD_EINVAL;
+  if (d->a_rows.mode != 0 && (d->a_rows.n <= 0 || d->a_rows.f <= 0 || d->a_rows.mode > 2 || d->a_rows.mode < 0)) return DFOLD_EINVAL;
+  if (d->c_rows.mode != 0 && (d->c_rows.n <= 0 || d->c_rows.f <= 0 || d->c_rows.mode > 2 || d->c_rows.mode < 0)) return DFOLD_EINVAL;
+  // mode 2 (cells of a window as one line, any N_res): conv launches of the 512 x 160 kernel only, both maps over the same grid
+  const bool lin = d->a_rows.mode == 2 || d->c_rows.mode == 2;
+  if (lin && (d->a_rows.mode != 2 || d->c_rows.mode != 2 || d->a_rows.n != d->c_rows.n || d->a_rows.f != d->c_rows.f ||
+              d->a_rows.fp != d->c_rows.fp || d->a_rows.wp != d->c_rows.wp || d->a_rows.wp < d->a_rows.n + 4 ||
+              d->a_rows.fp < d->a_rows.f + 4 || (long)d->a_rows.f * d->a_rows.wp >= (1L << 30)))
+    return DFOLD_EINVAL;
   GemmParams p;
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.C2 = d->C2;
   p.bias = d->bias; p.R = (const bf16_t*)d->R; p.R2 = (const bf16_t*)d->R2; p.zeros = (const bf16_t*)d->zeros;
@@ -703,14 +714,15 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.ws = nullptr; p.cnt = nullptr; p.sk_per = 0; p.sk_tiles = 0; p.sk_fence = 1;
   p.conv_f0 = (d->conv_frames >> 16) & 0x7fff; p.conv_F = d->conv_frames & 0xffff;
   p.nz_ps = d->nz_ps; p.nz_radius = d->nz_radius; p.nz_f0 = d->nz_f0;
-  if (p.nz_ps && (d->a_rows.mode != 1 || p.nz_radius < 0 || p.nz_f0 < 0)) return DFOLD_EINVAL;
+  if (p.nz_ps && (d->a_rows.mode == 0 || p.nz_radius < 0 || p.nz_f0 < 0)) return DFOLD_EINVAL;
+  if (lin && (d->M % (int)row_vw_host(p.am))) return DFOLD_EINVAL;
   static int prio_mode = -1;
   if (prio_mode < 0) {
     const char* e = getenv("DFOLD_GEMM_PRIO");
     prio_mode = e ? atoi(e) : 1;
   }
   p.prio = prio_mode;
-  const int role = (d->a_rows.mode == 1 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
+  const int role = (d->a_rows.mode != 0 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
   const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
   const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);
   static int variant = -1;   // DFOLD_GEMM_VARIANT=128 forces the 128x128 kernel (A/B measurements)
@@ -724,8 +736,8 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   // splitk == -1: the stream-K form of the one-wave-per-SIMD conv kernel (conv_fwd_w4.hip) when the launch qualifies for that
   // kernel, otherwise an ordinary unsplit launch (a performance-only fallback: the caller's cost model assumed the kernel)
   if (d->splitk == -1 && role == 1 && d->nbatch == 1 && d->splitk_ws && d->splitk_cnt && (d->nseg % 25) == 0 &&
-      !(d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->N % 160) == 0 && d->seglen == BK && d->a_rows.mode == 1 &&
-      (d->a_rows.n % BM3) == 0 && (d->M % BM3) == 0 && d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && p.conv_F == 0 &&
+      !(d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->N % 160) == 0 && d->seglen == BK && d->a_rows.mode != 0 &&
+      (lin || (d->a_rows.n % BM3) == 0) && (d->M % BM3) == 0 && d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && p.conv_F == 0 &&
       d->a_seg_s0 == BK && d->b_seg_s0 == BK && (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 &&
       a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31)) {
     static int sk_env = -1;
@@ -748,7 +760,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   if (d->splitk > 1) {
     const int chunks = d->nseg / 25;
     if (role != 1 || d->nbatch != 1 || !d->splitk_ws || !d->splitk_cnt || (d->nseg % 25) || (chunks % d->splitk) ||
-        (d->N % BN3) || (d->seglen % BK) || (d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)))
+        (lin ? (d->N % 160) : (d->N % BN3)) || (d->seglen % BK) || (d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)))
       return DFOLD_EINVAL;
     S = d->splitk;
     p.nseg = d->nseg / S;                                 // every part walks chunks/S channel chunks x 25 taps
@@ -758,6 +770,15 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     p.ws = d->splitk_ws; p.cnt = d->splitk_cnt;
   }
   if (S > 1 && !(a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31) && steps / S >= 2)) return DFOLD_EINVAL;
+  if (lin) {
+    // mode-2 row maps: the 512 x 160 kernel is the only reader (any launch size; split-K workspace: S x ceil(M / 512) x N / 160
+    // tiles of 512 x 160 fp32, as many counters as tiles)
+    if (role != 1 || d->nbatch != 1 || (d->N % 160) || d->seglen != BK || d->seg_div != 5 || d->a_seg_s2 != d->a_rows.ld ||
+        (d->nseg % (25 * S)) || p.conv_F != 0 || d->a_seg_s0 != BK || d->b_seg_s0 != BK || !(d->flags & DFOLD_GEMM_OUT_BF16) ||
+        ((p.cm.ld | p.cm.base) & 7) || !(a_extent < (1L << 31)) || !((long)d->N * d->ldb < (1L << 31)))
+      return DFOLD_EINVAL;
+    return dfold_conv_w4_launch(p, S, (hipStream_t)stream);
+  }
   if (S > 1 || (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && (d->M >= 2048 || role == 2) && steps >= 4 &&
       tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31))) {
     static bool attr3_done = false;
@@ -777,7 +798,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       const char* e = getenv("DFOLD_CONV_HALO");
       halo_mode = e ? atoi(e) : 1;
     }
-    const bool halo = halo_mode && role == 1 && d->a_rows.mode == 1 && (d->a_rows.n % BM3) == 0 && (d->M % BM3) == 0 && d->seglen == BK &&
+    const bool halo = halo_mode && role == 1 && d->a_rows.mode != 0 && (lin || (d->a_rows.n % BM3) == 0) && (d->M % BM3) == 0 && d->seglen == BK &&
                       d->seg_div == 5 && d->a_seg_s2 == d->a_rows.ld && (d->nseg % (25 * S)) == 0 && p.conv_F == 0;
     // one-wave-per-SIMD 512 x 160 form (conv_fwd_w4.hip; DFOLD_CONV_W4=0 keeps the 256 x 320 halo kernel): unsplit launches
     // with a bf16 LDS-staged epilogue
@@ -790,8 +811,9 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     //  the caller sized the workspace for: an odd number of 256-row runs stays on the kernel below)
     const long tiles_w4 = (long)((d->M + 511) / 512) * (d->N / 160);
     if (halo && w4_mode && d->nbatch == 1 && (d->N % 160) == 0 && d->a_seg_s0 == BK && d->b_seg_s0 == BK &&
-        (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 && (S == 1 || tiles_w4 <= tiles320 || w4_mode == 2))
+        (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 && (S == 1 || tiles_w4 <= tiles320 || w4_mode == 2 || lin))
       return dfold_conv_w4_launch(p, S, (hipStream_t)stream);
+
     if (halo)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5, true>), grid3, dim3(512), (size_t)HALO_LDS, (hipStream_t)stream, p);
     else if (role == 1)

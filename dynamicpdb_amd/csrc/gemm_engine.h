@@ -67,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const long m = mbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-      const bool mok = m < p.M;
+      const bool mok = m < p.M && row_valid(p.cm, m);
       const long ro = row_off(p.cm, mok ? m : 0) + coff + nbase + frow;
       float rv[NJ], r2v[NJ], cv[NJ];
 #pragma unroll
@@ -130,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
   for (int i = 0; i < 2; ++i) {
     if (lane < 32) {
       const long m = mbase + i * 32 + lane;
-      rowtab[lane] = m < p.M ? row_off(p.cm, m) + coff + nbase : -1;
+      rowtab[lane] = (m < p.M && row_valid(p.cm, m)) ? row_off(p.cm, m) + coff + nbase : -1;
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {

@@ -27,6 +27,43 @@ def _require_cuda(t):
                            "the CPU restatement lives in oracle/ and is test-only")
 
 
+_TRUNC_UNIT_STD = None      # standard deviation of a unit normal truncated at +-2 (scipy, computed once)
+
+
+class Linear(nn.Linear):
+    """nn.Linear with the reference's initialisers (src/model/ipa_pytorch_dynamic.py:107-172 and the identical
+    openfold/model/primitives.py:115-175 that AngleResnet uses): zero bias; weight by `init` --
+      "default": fan-in scaled normal truncated at two standard deviations (variance 1 / fan_in after truncation),
+      "relu": the same with variance 2 / fan_in, "final": zeros.
+    A fresh drop-in model therefore starts from the reference's distribution -- and from the reference's very numbers under
+    the same seeds: like the reference the constructor first runs nn.Linear's own initialisation (it consumes torch's
+    generator) and then draws the truncated normals with scipy from numpy's global generator, in the reference's module
+    order (tests/test_reference_experiment.py::test_fresh_model_equals_the_reference_fresh_model)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, init="default"):
+        super().__init__(in_dim, out_dim, bias=bias)
+        with torch.no_grad():
+            if bias:
+                self.bias.zero_()
+            if init == "final":
+                self.weight.zero_()
+            elif init in ("default", "relu"):
+                self.weight.copy_(self._truncated_normal(self.weight.shape, 2.0 if init == "relu" else 1.0))
+            else:
+                raise ValueError(f"dynamicpdb_amd Linear: init must be 'default', 'relu' or 'final' (the ones the DFOLDv2 path "
+                                 f"uses), got {init!r}")
+
+    @staticmethod
+    def _truncated_normal(shape, gain):
+        global _TRUNC_UNIT_STD
+        from scipy.stats import truncnorm
+        if _TRUNC_UNIT_STD is None:
+            _TRUNC_UNIT_STD = float(truncnorm.std(a=-2, b=2, loc=0, scale=1))
+        sigma = math.sqrt(gain / max(1, shape[1])) / _TRUNC_UNIT_STD
+        draws = truncnorm.rvs(a=-2, b=2, loc=0, scale=sigma, size=int(np.prod(shape)))
+        return torch.tensor(draws.reshape(tuple(shape)))
+
+
 class MyLayerNorm(nn.Module):
     """(x - mean_all) / sqrt(var_all_unbiased + 1e-4) over one window's whole [F,N,C] tensor."""
 
@@ -95,10 +132,7 @@ class BackboneUpdate(nn.Module):
     def __init__(self, c_s):
         super().__init__()
         self.c_s = c_s
-        self.linear = nn.Linear(c_s, 6)
-        with torch.no_grad():
-            self.linear.weight.zero_()
-            self.linear.bias.zero_()
+        self.linear = Linear(c_s, 6, init="final")                       # :590
 
     def forward(self, s):
         _require_cuda(s)
@@ -111,8 +145,8 @@ _relu = torch.relu
 class AngleResnetBlock(nn.Module):
     def __init__(self, c_hidden):
         super().__init__()
-        self.linear_1 = nn.Linear(c_hidden, c_hidden)
-        self.linear_2 = nn.Linear(c_hidden, c_hidden)
+        self.linear_1 = Linear(c_hidden, c_hidden, init="relu")          # openfold/model/structure_module.py:58-59
+        self.linear_2 = Linear(c_hidden, c_hidden, init="final")
 
 
 class AngleResnet(nn.Module):
@@ -121,10 +155,10 @@ class AngleResnet(nn.Module):
     def __init__(self, c_in, c_hidden, no_blocks, no_angles, epsilon):
         super().__init__()
         self.c_in, self.c_hidden, self.no_blocks, self.no_angles, self.eps = c_in, c_hidden, no_blocks, no_angles, epsilon
-        self.linear_in = nn.Linear(c_in, c_hidden)
-        self.linear_initial = nn.Linear(c_in, c_hidden)
+        self.linear_in = Linear(c_in, c_hidden)                          # structure_module.py:100-108
+        self.linear_initial = Linear(c_in, c_hidden)
         self.layers = nn.ModuleList([AngleResnetBlock(c_hidden) for _ in range(no_blocks)])
-        self.linear_out = nn.Linear(c_hidden, no_angles * 2)
+        self.linear_out = Linear(c_hidden, no_angles * 2)
 
     def forward(self, s, s_initial):
         _require_cuda(s)
@@ -154,19 +188,16 @@ class InvariantPointAttention(nn.Module):
                              f"with inf=1e5; got no_qk_points={self.no_qk_points}, no_v_points={self.no_v_points}, inf={inf}: "
                              "the point tables of csrc/ipa_attn.hip are sized for 8 query / 12 value points")
         hc = self.c_hidden * self.no_heads
-        self.linear_q = nn.Linear(self.c_s, hc)
-        self.linear_kv = nn.Linear(self.c_s, 2 * hc)
-        self.linear_q_points = nn.Linear(self.c_s, self.no_heads * self.no_qk_points * 3)
-        self.linear_kv_points = nn.Linear(self.c_s, self.no_heads * (self.no_qk_points + self.no_v_points) * 3)
-        self.linear_b = nn.Linear(self.c_z, self.no_heads)
-        self.down_z = nn.Linear(self.c_z, self.c_z // 4)
+        self.linear_q = Linear(self.c_s, hc)                             # :284-311, the reference's order and initialisers
+        self.linear_kv = Linear(self.c_s, 2 * hc)
+        self.linear_q_points = Linear(self.c_s, self.no_heads * self.no_qk_points * 3)
+        self.linear_kv_points = Linear(self.c_s, self.no_heads * (self.no_qk_points + self.no_v_points) * 3)
+        self.linear_b = Linear(self.c_z, self.no_heads)
+        self.down_z = Linear(self.c_z, self.c_z // 4)
         self.head_weights = nn.Parameter(torch.full((self.no_heads,), 0.541324854612918))
         concat_out_dim = self.c_z // 4 + self.c_hidden + self.no_v_points * 4
-        self.linear_out = nn.Linear(self.no_heads * (concat_out_dim + self.no_v_points * 4), self.c_s)
-        self.linear_rbf = nn.Linear(20, 1)      # unused in the reference forward (:311); kept for state_dict parity
-        with torch.no_grad():
-            self.linear_out.weight.zero_()
-            self.linear_out.bias.zero_()
+        self.linear_out = Linear(self.no_heads * (concat_out_dim + self.no_v_points * 4), self.c_s, init="final")
+        self.linear_rbf = Linear(20, 1)         # unused in the reference forward (:311); kept for state_dict parity
 
     def features(self, s, z, t7, mask):
         """s bf16 [B,F,N,c_s], z bf16 [B,N,N,c_z], t7 fp32 [B,F,N,7], mask [B,F,N] -> bf16 [B,F,N,H*(...)]  (:350-504).

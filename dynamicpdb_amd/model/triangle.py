@@ -234,9 +234,23 @@ def _ws_get(ws, key, shape, dtype, dev):
     return t
 
 
+def _trimul_sub_batch(B, N):
+    """Items per sub-batch of the fused forward.  The three launches hand a|b planes, gate and x planes (4 bf16 copies of the pair
+    tensor: 67 MB per item at N_res 256) to each other through HBM; run over the whole batch each stage writes more than the
+    256 MB Infinity Cache holds before the next one reads it (profiles/r5_triangle_pmc_*: 216 MB of HBM-side traffic per item
+    against 67 MB algorithmic).  Sub-batches whose intermediates fit the cache keep the hand-overs on the die.
+    DFOLD_TRIMUL_SUB = items per sub-batch (0: whole batch); default: as many items as fit 140 MB of intermediates."""
+    e = os.environ.get("DFOLD_TRIMUL_SUB", "")
+    if e:
+        return B if int(e) <= 0 else min(B, int(e))
+    per_item = N * _np64(N) * 128 * 2 * 4
+    return max(1, min(B, (140 << 20) // per_item))
+
+
 def _trimul_fused(z, mask, outgoing, pack, ws=None, stages_out=None):
-    """Fused forward (csrc/pair_fused.hip), three launches: LayerNorm + 640-wide projection + gates -> a|b planes and the
-    output gate; x_c = a_c b_c^T batched over (B, channel) on the MFMA engine; LayerNorm_out + linear_z + gate.
+    """Fused forward (csrc/pair_fused.hip), three launches per sub-batch of items (_trimul_sub_batch): LayerNorm + 640-wide
+    projection + gates -> a|b planes and the output gate; x_c = a_c b_c^T batched over (item, channel) on the MFMA engine;
+    LayerNorm_out + linear_z + gate.
     z [B,N,N,128] fp32|bf16, mask [B,N,N]; pack = TriangleMultiplicativeUpdate._packed().  Returns (out, z used, mask used)."""
     L = _lib.lib()
     wcat, bcat, wz, g_in, b_in, g_out, b_out, b_z = pack
@@ -247,21 +261,28 @@ def _trimul_fused(z, mask, outgoing, pack, ws=None, stages_out=None):
     if zc.dtype not in (torch.float32, BF16):
         zc = zc.float()
     maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
-    planes = _ws_get(ws, "planes", (B, N, 256, NP), BF16, dev)      # [line][channel][pos]: line-major planes
-    gate = _ws_get(ws, "gate", (B, N, N, 128), BF16, dev)
-    xpl = _ws_get(ws, "xpl", (B, N, 128, NP), BF16, dev)
-    st = stream()
-    check(L.dfold_trimul_proj_fwd(_p(zc), c_int32(1 if zc.dtype == BF16 else 0), _p(maskf), _p(g_in), _p(b_in), _p(wcat),
-                                  _p(bcat), _p(planes), _p(gate), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP),
-                                  c_int32(0 if outgoing else 1), ctypes_float(1e-5), st), "dfold_trimul_proj_fwd")
-    # x_c = a_c b_c^T  (:113-118): batch (b, c); rows i / j of channel c are 256 NP (a, b) resp. 128 NP (x) elements apart
-    gemm(planes, planes, xpl, N, N, NP, a_rows=rows_plain(256 * NP), c_rows=rows_plain(128 * NP), ldb=256 * NP,
-         nbatch=B * 128, nb1=128, sa=(N * 256 * NP, NP), sb=(N * 256 * NP, NP), sc=(N * 128 * NP, NP), b_off=128 * NP)
+    sub = _trimul_sub_batch(B, N)
+    keep = stages_out is not None          # the backward wants the stage tensors of every item: full-size, written slice by slice
+    Bw = B if keep else sub
+    planes = _ws_get(None if keep else ws, "planes", (Bw, N, 256, NP), BF16, dev)      # [line][channel][pos]: line-major planes
+    gate = _ws_get(None if keep else ws, "gate", (Bw, N, N, 128), BF16, dev)
+    xpl = _ws_get(None if keep else ws, "xpl", (Bw, N, 128, NP), BF16, dev)
     out = torch.empty((B, N, N, 128), dtype=zc.dtype, device=dev)
-    check(L.dfold_trimul_out_fwd(_p(xpl), _p(gate), _p(g_out), _p(b_out), _p(wz), _p(b_z), _p(out),
-                                 c_int32(1 if out.dtype == BF16 else 0), c_int32(B), c_int32(N), c_int32(NP),
-                                 ctypes_float(1e-5), st), "dfold_trimul_out_fwd")
-    if stages_out is not None:
+    st = stream()
+    zbf, obf = c_int32(1 if zc.dtype == BF16 else 0), c_int32(1 if out.dtype == BF16 else 0)
+    for b0 in range(0, B, sub):
+        nb = min(sub, B - b0)
+        w0 = b0 if keep else 0
+        pl, gt, xp = planes[w0:w0 + nb], gate[w0:w0 + nb], xpl[w0:w0 + nb]
+        check(L.dfold_trimul_proj_fwd(_p(zc[b0:b0 + nb]), zbf, _p(maskf[b0:b0 + nb]), _p(g_in), _p(b_in), _p(wcat),
+                                      _p(bcat), _p(pl), _p(gt), c_void_p(0), c_int32(nb), c_int32(N), c_int32(NP),
+                                      c_int32(0 if outgoing else 1), ctypes_float(1e-5), st), "dfold_trimul_proj_fwd")
+        # x_c = a_c b_c^T  (:113-118): batch (b, c); rows i / j of channel c are 256 NP (a, b) resp. 128 NP (x) elements apart
+        gemm(pl, pl, xp, N, N, NP, a_rows=rows_plain(256 * NP), c_rows=rows_plain(128 * NP), ldb=256 * NP,
+             nbatch=nb * 128, nb1=128, sa=(N * 256 * NP, NP), sb=(N * 256 * NP, NP), sc=(N * 128 * NP, NP), b_off=128 * NP)
+        check(L.dfold_trimul_out_fwd(_p(xp), _p(gt), _p(g_out), _p(b_out), _p(wz), _p(b_z), _p(out[b0:b0 + nb]),
+                                     obf, c_int32(nb), c_int32(N), c_int32(NP), ctypes_float(1e-5), st), "dfold_trimul_out_fwd")
+    if keep:
         stages_out.extend((planes, gate, xpl))
     return out, zc, maskf
 

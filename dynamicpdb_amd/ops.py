@@ -38,6 +38,17 @@ def rows_grid(C, N, F, Fp, Wp, base=0):
     return RowMap(base, C, 1, N, F, Fp, Wp)
 
 
+def rows_lin(C, N, F, Fp, Wp, base=0):
+    """RowMap mode 2: the cells of a window as one line (dfold_common.h): any N_res on the 512 x 160 conv kernel"""
+    return RowMap(base, C, 2, N, F, Fp, Wp)
+
+
+def grid_slack(Wp, C):
+    """elements kept readable (and zero) behind a padded conv grid: the mode-2 conv launches and the linear weight-gradient walk
+    read up to 272 cells + 4 frame rows past the last window's end for rows they never store / products with zero gradients"""
+    return (4 * Wp + 288) * C
+
+
 def seg_table(values, device):
     key = (tuple(values), device)
     t = _seg_tables.get(key)
@@ -230,7 +241,18 @@ class Grid:
         self.plane = Wn * self.Fp * self.NP
 
     def alloc(self, C):
-        return torch.zeros((self.Wn, self.Fp, self.Wp, C), dtype=BF16, device=self.device)
+        n = self.Wn * self.Fp * self.Wp * C
+        return torch.zeros(n + grid_slack(self.Wp, C), dtype=BF16, device=self.device)[:n].view(self.Wn, self.Fp, self.Wp, C)
+
+    def vw(self, nf):
+        """mode-2 rows per window: the nf * Wp cells of the frame range rounded up to whole 256-row runs"""
+        return (nf * self.Wp + 255) // 256 * 256
+
+    def rows_in_lin(self, C, f_lo=0, nf=None):
+        return rows_lin(C, self.N, self.F if nf is None else nf, self.Fp, self.Wp, f_lo * self.Wp * C)
+
+    def rows_center_lin(self, C, f_lo=0, nf=None):
+        return rows_lin(C, self.N, self.F if nf is None else nf, self.Fp, self.Wp, ((2 + f_lo) * self.Wp + 2) * C)
 
     def interior(self, t):
         return t[:, 2:-2, 2:-2, :]
@@ -260,19 +282,25 @@ class Grid:
 _N_CU = {}
 
 
+def cu_count(device):
+    """compute units of `device` (asked once per device)"""
+    n = _N_CU.get(device)
+    if n is None:
+        n = _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
+    return n
+
+
 _SPLITK_CAP = int(os.environ.get("DFOLD_SPLITK_CAP", "4"))      # partial tiles in flight per CU the workspace is sized for
 
 
-def conv_splitk(M, CO, CI, device):
+def conv_splitk(M, CO, CI, device, tiles=None):
     """Split factor S for a narrow conv launch (few output rows, long K = 25 taps x CI): the 256x320 tile kernel runs
     one workgroup per CU, so tiles x S should fill the CUs in whole rounds.  Cost model in K steps: rounds x (steps/S + a
     fixed ~16 steps for prologue, partial-tile store and the reduction).  S divides the number of 64-channel chunks."""
-    if CO % 320 or CI % 64 or os.environ.get("DFOLD_CONV_SPLITK", "1") == "0":
+    if (CO % 320 and tiles is None) or CI % 64 or os.environ.get("DFOLD_CONV_SPLITK", "1") == "0":
         return 1
-    n_cu = _N_CU.get(device)
-    if n_cu is None:
-        n_cu = _N_CU[device] = torch.cuda.get_device_properties(device).multi_processor_count
-    tiles = ((M + 255) // 256) * (CO // 320)
+    n_cu = cu_count(device)
+    tiles = ((M + 255) // 256) * (CO // 320) if tiles is None else tiles
     chunks, steps = CI // 64, 25 * (CI // 64)
     best, best_cost = 1, -(-tiles // n_cu) * (steps + 16)
     for S in (2, 4, 5, 10, 20):
@@ -298,18 +326,25 @@ def conv_splitk(M, CO, CI, device):
 _STREAMK = os.environ.get("DFOLD_CONV_STREAMK", "1") != "0"
 # zero-frame skipping in the tower's backward (ConvTower.backward, functional.ConvTowerFn.backward); 0: every launch walks all of K
 CONV_NZ = os.environ.get("DFOLD_CONV_NZ", "1") != "0"
-_TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
+# RowMap mode 2 for N_res % 256 != 0 (conv5x5_fwd, conv5x5_wgrad_tn): 0 never, 1 by conv_lin_wins(), 2 always
+_CONV_LIN = int(os.environ.get("DFOLD_CONV_LIN", "1"))
 
 
-def conv_tail_frames(nf, tiles_per_frame, n_cu):
-    """Frames to cut off the end of a thin conv launch of nf frames (512 x 160 tiles, tiles_per_frame of them per frame) so that
-    what stays is whole rounds of n_cu tiles: the remainder must be whole frames and at most a quarter of a round (a larger
-    remainder fills the chip well enough on its own).  0: leave the launch alone."""
-    tiles = nf * tiles_per_frame
-    rem = tiles % n_cu if n_cu > 0 else 0
-    if tiles_per_frame <= 0 or tiles <= n_cu or rem == 0 or rem % tiles_per_frame or 4 * rem > n_cu:
-        return 0
-    return rem // tiles_per_frame
+def conv_lin_wins(Wn, nf, N, CO, n_cu, nz=False):
+    """Does a conv launch at an N_res that is not a multiple of 256 go to the 512 x 160 kernel through the mode-2 row map?
+    Measured (same-box A/B, profiles/r6_conv_lin_ab.txt): sending EVERY launch there loses -- BASELINE config 2 (4 x 32 x 128)
+    51.6 -> 58.1 ms per step, a config-1 sampler forward (16 x 96) 8.1 -> 12.6 ms.  The line of cells has (N + 4) / N more rows
+    than the launch has cells plus a ragged run per window, and what decides at these sizes is the tile count against the 256
+    CUs, not the kernel's 6 % per FLOP: config 2 with 1280 output channels is exactly 256 tiles of 256 x 320 -- one round -- and
+    272 tiles of 512 x 160: a second, almost empty round; the thin launches of small windows split K either way and the 512-row
+    tile wastes up to a run per launch on top.  So the new path takes: launches that carry zero-frame flags (only this kernel
+    can skip tiles; the backward of blocks 0 and 3), output widths the 256 x 320 kernel cannot tile (CO % 320), and dense
+    launches that fill at least half the chip in the same number of rounds."""
+    if nz or CO % 320:
+        return True
+    t_old = -(-(Wn * nf * N) // 256) * (CO // 320)
+    t_new = -(-(Wn * (-(-(nf * (N + 4)) // 256))) // 2) * (CO // 160)
+    return t_old >= n_cu // 2 and -(-t_new // n_cu) <= -(-t_old // n_cu)
 
 
 # DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).
@@ -339,10 +374,31 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     ck = 64 if CI % 64 == 0 else CI            # K chunk per segment (one MFMA K step when channels allow)
     nf = g.F - f_lo if nf is None else nf
     M = g.Wn * nf * g.N
-    if ws is not None and _TAIL_SPLIT and g.N % 256 == 0 and CO % 160 == 0 and x.device in _N_CU and conv_splitk(M, CO, CI, x.device) != 1:
+    # N_res that is not a multiple of 256 (every real protein; BASELINE configs 1 and 2): the window's cells as one line (RowMap
+    # mode 2) so that the 512 x 160 one-wave-per-SIMD kernel takes the launch -- 256-row runs of consecutive cells, pad columns
+    # computed and not stored ((N + 4) / N of the FLOPs).  DFOLD_CONV_LIN=0: the per-tap 256 x 320 kernel of rounds 2-5.
+    lin = _CONV_LIN and g.N % 256 != 0 and CO % 160 == 0 and ck == 64 and out.dtype == BF16 and x.dtype == BF16
+    if lin and _CONV_LIN == 1:
+        lin = conv_lin_wins(g.Wn, nf, g.N, CO, cu_count(x.device), nz is not None)
+    if lin:
+        Ml = g.Wn * g.vw(nf)
+        tiles = ((Ml + 511) // 512) * (CO // 160)
+        S, sk = 1, {}
+        if ws is not None:
+            S = conv_splitk(Ml, CO, CI, x.device, tiles=tiles)
+            if S != 1:
+                sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
+                          splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
+        return gemm(x, wf, out, Ml, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in_lin(CI, f_lo, nf),
+                    c_rows=g.rows_center_lin(CO, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2,
+                    a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI), seg_div=5, seg_div_mid=5, flags=flags,
+                    nz=None if nz is None else (nz[0], nz[1], f_lo))
+    if ws is not None and _TAIL_SPLIT and g.N % 256 == 0 and (g.Wn * g.N) % 512 == 0 and CO % 160 == 0 and conv_splitk(M, CO, CI, x.device) != 1:
         # a launch of whole rounds of tiles plus a small remainder (288 = 256 + 32 tiles, 544 = 512 + 32 for 256 CUs): the
-        # remainder's FRAMES go into a launch of their own, which splits K; the whole rounds run unsplit and in lock-step
-        nf_b = conv_tail_frames(nf, (g.Wn * g.N // 512) * (CO // 160), _N_CU[x.device])
+        # remainder's FRAMES go into a launch of their own, which splits K; the whole rounds run unsplit and in lock-step.
+        # (The policy is a function of the launch shape alone -- not of which launches came before it in the process: step 1
+        #  takes the same routes, i.e. the same fp32 association, as every later step.)
+        nf_b = conv_tail_frames(nf, (g.Wn * g.N // 512) * (CO // 160), cu_count(x.device))
         if nf_b:
             kw = dict(relu=relu, resid=resid, pre_resid_out=pre_resid_out, relu_mask=relu_mask,
                       C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws, nz=nz)
@@ -356,8 +412,8 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         if S == -1 and not (g.N % 256 == 0 and ck == 64 and out.dtype == BF16):
             S = 1                     # (the launch would not take the kernel that has the stream-K form)
         if S > 1 or S == -1:
-            sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * _N_CU[x.device] * 256 * 320,), torch.float32),
-                      splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * _N_CU[x.device],), torch.int32))
+            sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
+                      splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
                 c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),
                 seg_div=5, seg_div_mid=5, flags=flags, conv_frames=(f_lo << 16) | g.F if _SKIP_PAD_TAPS else 0,
@@ -382,7 +438,7 @@ _WGRAD_TN = os.environ.get("DFOLD_WGRAD_TN", "1") != "0"
 def wgrad_tn_ok(g, CI, CO):
     """shapes the direct (transpose-read) weight-gradient kernel covers: frame rows of whole 64-cell K chunks, the wider
     channel count a multiple of the 256-row tile, the narrower of the 64-channel column tile"""
-    return g.N % 64 == 0 and max(CI, CO) % 256 == 0 and min(CI, CO) % 64 == 0
+    return (g.N % 64 == 0 or _CONV_LIN) and max(CI, CO) % 256 == 0 and min(CI, CO) % 64 == 0
 
 
 def grid_load_flags(g, src, grid, ps, scratch, f_off=0):
@@ -414,8 +470,8 @@ def conv5x5_wgrad_tn(g, x, gy, dwg, accumulate=True, bias_grad=None, f_lo=0, nf=
         F = min(g.F, f_lo + F + 2) - lo
         f_lo = lo
         a, b, flip = x, gy, 1
-    if nz is not None and F > 64:
-        nz = None                    # (the kernel's frame masks are 64 bits per window)
+    if nz is not None and (F > 64 or g.N % 64):
+        nz = None                    # (the kernel's frame masks are 64 bits per window; the linear walk of a ragged N_res has no frames)
     # with frame flags the kernel takes at most 8 windows per call (its masks live in scalar registers)
     step = g.Wn if nz is None else 8
     for w0 in range(0, g.Wn, step):
@@ -479,11 +535,13 @@ class Workspace:
         key = (name, tuple(shape), dtype)
         b = self.bufs.get(key)
         if b is None:
-            b = torch.zeros(n, dtype=dtype, device=self.device)
+            # (padded conv grids [Wn, Fp, Wp, C] get the zero slack behind them that grid_slack() describes)
+            slack = grid_slack(shape[2], shape[3]) if (len(shape) == 4 and dtype == BF16) else 0
+            b = torch.zeros(n + slack, dtype=dtype, device=self.device)
             self.bufs[key] = b
         elif zero:
-            b.zero_()
-        return b.view(*shape)
+            b[:n].zero_()
+        return b[:n].view(*shape)
 
 
 class ConvTower:

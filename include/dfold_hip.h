@@ -49,9 +49,14 @@ int dfold_abi_version(void);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t base; /* element offset of logical row 0 */
-  int64_t ld;   /* mode 0: row stride; mode 1: channels per grid cell */
+  int64_t ld;   /* mode 0: row stride; mode 1 / 2: channels per grid cell */
   int32_t mode; /* 0: off = base + m*ld
-                   1: m = (w*f + fr)*n + res  ->  off = base + (((w*fp + fr)*wp) + res)*ld */
+                   1: m = (w*f + fr)*n + res  ->  off = base + (((w*fp + fr)*wp) + res)*ld
+                   2 (round 6; 5x5 conv launches, any N_res): m = w*VW + v, VW = f*wp rounded up to a multiple of 256; row v is
+                      cell v of window w counted along the padded frame rows, pad columns included:
+                      off = base + (w*fp*wp + v)*ld.  Rows with v >= f*wp or v % wp >= n are computed and not stored.  Both maps
+                      of a launch must be mode 2 over the same grid geometry, M = windows * VW; the A tensor must stay readable
+                      (finite values) for 272 cells + 4 frame rows behind its last window (rows that are never stored read there) */
   int32_t n, f, fp, wp;
 } dfold_rowmap;
 
@@ -153,7 +158,9 @@ int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t
      tap = 5 z0 + z1, or 24 - (5 z0 + z1) when flip != 0
    A bf16 [W][Fp][Wp][CA], B bf16 [W][Fp][Wp][CB], dWg fp32 [CA][25][CB] (overwritten unless accumulate != 0).
    With A = dL/dy (CA = CO), B = x: dWg = dW in the [CO][25][CI] layout of dfold_conv_wgrad_unpack; with A = x, B = dL/dy and
-   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 64 == 0, N % 64 == 0, grids 16-byte aligned.
+   flip: its transposed [CI][25][CO] form.  CA % 256 == 0, CB % 64 == 0, grids 16-byte aligned.  N % 64 != 0 (round 6): the frame
+   range of a window is walked as one line of nf * Wp cells -- both grids must have zero pad columns / border rows (they do when
+   the engine wrote them) and B must stay readable (finite values) for 68 cells behind its last window.
    nz_ps / nz_radius (optional, NULL / 0 = none): the frame flags of dfold_grid_load_flags for the GRADIENT operand (A, or B
    when flip != 0), as in dfold_gemm_desc: frame rows of the reduction whose gradient cells are zero by that statement are
    left out of the K walk (exact zeros: the sum is unchanged bit for bit); needs nf <= 64, at most 8 windows per call. */
@@ -164,7 +171,7 @@ int dfold_conv_wgrad_tn(const void* A, const void* B, float* dWg, int32_t CA, in
    bf16 [W][F+4][N+4][C] (src NULL: the grid is read as it lies, nothing is written) and records which of those frame rows
    hold a non-zero: ps int32 [W][F+5], ps[w][i] = number of padded frame rows j < i of window w with a non-zero cell (rows
    outside the range count as zero -- the caller's statement).  scratch: (F+4) * W + 1 int32, zero before the call and left
-   zero.  The gradient that enters the tower's backward (aten convolution_backward of ConvNet, ipa_pytorch_dynamic.py:692-706)
+   zero (two launches: copy + flags, then one block of prefix sums).  The gradient that enters the tower's backward (aten convolution_backward of ConvNet, ipa_pytorch_dynamic.py:692-706)
    is zero on every frame no loss term reads; the flags let the data / weight gradient launches skip those frames without a
    contract with the loss and without a device -> host copy.  N * C a multiple of 8, 16-byte aligned pointers. */
 int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, int32_t* scratch, int32_t W, int32_t F, int32_t N,

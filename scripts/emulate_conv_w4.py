@@ -40,12 +40,44 @@ class Lds:
         return cur
 
 
-def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False, g_begin=0, g_end=None):
-    """g_begin / g_end: the K-group range of a stream-K piece (default: the whole tile)"""
+def lin_vw(N, F):
+    """RowMap mode 2 (dfold_common.h): rows per window = the F * (N + 4) cells of the frame range in whole 256-row runs"""
+    return (F * (N + 4) + 255) // 256 * 256
+
+
+def lin_rows_check(N, F, W, C=8):
+    """The mode-2 row map on the host: every interior cell (w, f, n) is the image of exactly one valid row, its input offset is the
+    top-left corner of its 5 x 5 window and its output offset the cell itself; all other rows are invalid (pad columns, the ragged
+    end of the last run); rows of one 256-row run are consecutive cells."""
+    Wp, Fp, vw = N + 4, F + 4, lin_vw(N, F)
+    seen = set()
+    for m in range(W * vw):
+        w_, v = divmod(m, vw)
+        off_in = (w_ * Fp * Wp + v) * C
+        off_out = ((2 * Wp + 2) + w_ * Fp * Wp + v) * C
+        if m % 256:
+            assert off_in == prev + C            # a run is a run of consecutive cells
+        prev = off_in
+        valid = v < F * Wp and v % Wp < N
+        if not valid:
+            continue
+        f, n = divmod(v, Wp)
+        assert off_in == ((w_ * Fp + f) * Wp + n) * C and off_out == ((w_ * Fp + f + 2) * Wp + n + 2) * C
+        seen.add((w_, f, n))
+    assert len(seen) == W * F * N
+    # what a run reads: at most 272 cells + 4 frame rows from its first cell -- behind the last window that is the slack
+    # ops.grid_slack() keeps readable
+    last_read = (W - 1) * Fp * Wp + (vw - 256) + 4 * Wp + 272
+    assert last_read - W * Fp * Wp <= 4 * Wp + 288
+    return len(seen)
+
+
+def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False, g_begin=0, g_end=None, lin=False):
+    """g_begin / g_end: the K-group range of a stream-K piece (default: the whole tile).  lin: RowMap mode 2 (any N_res)"""
     Wp, Fp = N + 4, F + 4
     ld = CI                      # a_rows.ld
     ldb = 25 * CI
-    M = W * F * N
+    M = W * lin_vw(N, F) if lin else W * F * N
     a_s0, a_s1, a_s2 = 64, Wp * CI, CI
     b_s0, b_s1, b_s2 = 64, 5 * CI, CI
     nseg = 25 * (CI // 64)
@@ -55,6 +87,9 @@ def run(CI=128, CO=160, N=256, F=2, W=1, m_tile=0, n_tile=0, verbose=False, g_be
     m0, n0 = m_tile * 512, n_tile * 160
 
     def row_off(m):              # rows_in(): top-left corner of the 5x5 window of GEMM row m
+        if lin:
+            w_, v = divmod(m, lin_vw(N, F))
+            return (w_ * Fp * Wp + v) * ld
         wf, n = divmod(m, N)
         w_, f = divmod(wf, F)
         return ((w_ * Fp + f) * Wp + n) * ld

@@ -394,7 +394,10 @@ def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense):
     for k in (1, 2):
         assert torch.equal(res[k][0], res[0][0])
         for a, b in zip(res[k][1], res[0][1]):
-            assert torch.equal(a, b)
+            if Wn <= 8:
+                assert torch.equal(a, b)
+            else:       # with flags the kernel takes 8 windows per call: the ninth window's sum is added as a whole (fp32 association)
+                assert rel_l2(a, b) < 1e-6
         for a, b in zip(res[k][2], res[0][2]):      # (the bias gradients are column sums with fp32 atomics: not flag-dependent,
             assert rel_l2(a, b) < 1e-5              #  and not bit-reproducible from run to run either)
     assert float(res[0][0].float().abs().max()) > 0 and float(res[0][1][0].abs().max()) > 0
@@ -491,6 +494,101 @@ def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
         assert torch.equal(o1, o2) and torch.equal(c1, c2_)
         assert float(o1[:, : 2 + F - 2].abs().max()) == 0
     assert int(ws.get("splitk_cnt", (4 * ops._N_CU[dev],), torch.int32).abs().max()) == 0
+
+
+@pytest.mark.parametrize("Wn,F,N,CI,CO", [(1, 16, 96, 128, 640), (4, 8, 128, 192, 1280), (2, 5, 200, 64, 640), (3, 3, 27, 128, 160),
+                                          (2, 6, 96, 64, 1280), (1, 4, 40, 1280, 640)])
+def test_conv_any_nres_on_the_one_wave_per_simd_kernel(dev, monkeypatch, Wn, F, N, CI, CO):
+    """Round 6: N_res that is not a multiple of 256 (BASELINE config 1: 96, config 2: 128, any real protein) on the 512 x 160
+    kernel through RowMap mode 2 -- the cells of a window as one line, 256-row runs that straddle frame rows, pad columns
+    computed and never stored, a ragged last run per window.  Whole outputs of every epilogue against fp64 conv2d on the same
+    bf16 operands; the border of the output grid stays zero; frame sub-range; split-K of a thin launch; zero-frame flags; and
+    agreement with the per-tap 256 x 320 kernel of rounds 2-5 (DFOLD_CONV_LIN=0) up to fp32 summation order.  The weight gradient
+    of the same shapes (linear K walk of csrc/conv_wgrad_tn.hip when N_res % 64 != 0) against fp64 on sampled taps."""
+    from ctypes import c_int32
+    from dynamicpdb_amd import _lib, ops
+    gen = torch.Generator(device="cpu").manual_seed(31 + N)
+    g = ops.Grid(Wn, F, N, dev)
+    w = (torch.randn(CO, CI, 5, 5, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(dev)
+    wf = torch.empty((CO, 25, CI), dtype=torch.bfloat16, device=dev)
+    wd = torch.empty((CI, 25, CO), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().dfold_conv_weight_pack(ops._p(w), ops._p(wf), ops._p(wd), c_int32(CO), c_int32(CI), _lib.stream()), "pack")
+    bias = (0.1 * torch.randn(CO, generator=gen)).to(dev)
+    xs = torch.randn(Wn, F, N, CI, generator=gen).to(dev).to(torch.bfloat16)
+    rs = torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16)
+    r2s = torch.randn(Wn, F, N, CO, generator=gen).to(dev).to(torch.bfloat16)
+    x, r, r2 = g.alloc(CI), g.alloc(CO), g.alloc(CO)
+    g.interior(x).copy_(xs); g.interior(r).copy_(rs); g.interior(r2).copy_(r2s)
+    lin = torch.nn.functional.conv2d(xs.double().permute(0, 3, 1, 2), w.to(torch.bfloat16).double(), None, padding=2).permute(0, 2, 3, 1)
+    rd, r2d = rs.double(), r2s.double()
+    bf = lambda t: t.to(torch.bfloat16).double()
+
+    def border_zero(t):
+        return (float(t[:, :2].abs().max()) == 0 and float(t[:, -2:].abs().max()) == 0 and float(t[:, :, :2].abs().max()) == 0
+                and float(t[:, :, -2:].abs().max()) == 0)
+
+    monkeypatch.setattr(ops, "_CONV_LIN", 2)             # (every launch on the new path, whatever the tile-count policy says)
+    seen = []
+    orig = ops.gemm
+    monkeypatch.setattr(ops, "gemm", lambda *a, **k: (seen.append(k["a_rows"].mode), orig(*a, **k))[1])
+    o = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, o, relu=True)
+    assert seen == [2]                                                   # the launch went through the mode-2 row map
+    ref = (lin + bias.double()).clamp_min(0)
+    assert rel_l2(g.interior(o), ref) < 4e-3 and border_zero(o)
+    o2 = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, o2, relu=True)
+    assert torch.equal(o, o2)
+    o, c2 = g.alloc(CO), g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, o, relu=True, resid=r, pre_resid_out=c2)
+    assert rel_l2(g.interior(c2), ref) < 4e-3 and rel_l2(g.interior(o), bf(ref) + rd) < 4e-3 and border_zero(o) and border_zero(c2)
+    o = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, None, o, relu=False, relu_mask=r)
+    assert rel_l2(g.interior(o), lin * (rd > 0)) < 4e-3 and border_zero(o)
+    o, c2 = g.alloc(CO), g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, None, o, relu=False, resid=r, C2=c2, R2=r2)
+    assert rel_l2(g.interior(o), bf(lin) + rd) < 4e-3 and rel_l2(g.interior(c2), (bf(lin) + rd) * (r2d > 0)) < 4e-3
+    assert border_zero(o) and border_zero(c2)
+    # frame sub-range, unsplit and with the thin-launch split (workspace given)
+    nfs = min(3, F)
+    ws = ops.Workspace(dev)
+    for use_ws in (None, ws):
+        o = g.alloc(CO)
+        ops.conv5x5_fwd(g, x, wf, bias, o, relu=True, f_lo=F - nfs, nf=nfs, ws=use_ws)
+        assert rel_l2(g.interior(o)[:, F - nfs:], ref[:, F - nfs:]) < 4e-3 and border_zero(o)
+        assert float(o[:, : 2 + F - nfs].abs().max()) == 0
+    # zero-frame flags: a gradient that lives on the last frame only; tiles of other frames are skipped, same bits
+    gz = torch.zeros(Wn, F, N, CI, dtype=torch.bfloat16, device=dev)
+    gz[:, -1] = xs[:, -1]
+    gt = g.alloc(CI)
+    ps = torch.empty((Wn, g.Fp + 1), dtype=torch.int32, device=dev)
+    ops.grid_load_flags(g, gz, gt, ps, torch.zeros(Wn * g.Fp + 1, dtype=torch.int32, device=dev))
+    oa, ob = g.alloc(CO), g.alloc(CO)
+    ops.conv5x5_fwd(g, gt, wf, None, oa, relu=False)
+    ops.conv5x5_fwd(g, gt, wf, None, ob, relu=False, nz=(ps, 0))
+    assert torch.equal(oa, ob) and float(oa.float().abs().max()) > 0
+    # the per-tap kernel of rounds 2-5 on the same launch (fp32 summation order differs)
+    monkeypatch.setattr(ops, "_CONV_LIN", 0)
+    seen.clear()
+    o_old = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, o_old, relu=True)
+    assert seen == [1]
+    monkeypatch.setattr(ops, "_CONV_LIN", 2)
+    o_new = g.alloc(CO)
+    ops.conv5x5_fwd(g, x, wf, bias, o_new, relu=True)
+    assert rel_l2(o_new, o_old) < 4e-3
+    # weight gradient (needs max(CI, CO) % 256 == 0 and min % 64 == 0): the direct kernel with its linear K walk vs fp64
+    if ops.wgrad_tn_ok(g, CI, CO):
+        gy = g.alloc(CO)
+        g.interior(gy).copy_(rs)
+        dw = torch.zeros((max(CI, CO), 25, min(CI, CO)), dtype=torch.float32, device=dev)
+        ops.conv5x5_wgrad_tn(g, x, gy, dw, accumulate=False)
+        xp = torch.nn.functional.pad(xs.double().permute(0, 3, 1, 2), (2, 2, 2, 2))         # [W, CI, F+4, N+4]
+        gd = rs.double().permute(0, 3, 1, 2)                                                 # [W, CO, F, N]
+        for (z0, z1) in ((0, 0), (2, 2), (4, 1), (1, 4)):
+            want = torch.einsum("wofn,wifn->oi", gd, xp[:, :, z0:z0 + F, z1:z1 + N])       # dW[co][ci] of tap (z0, z1)
+            got = dw[:, 5 * z0 + z1, :] if CI <= CO else dw[:, 5 * z0 + z1, :].t()
+            assert rel_l2(got, want) < 2e-3, (z0, z1)
 
 
 def test_conv_stream_k_vs_unsplit_and_fp64(dev, monkeypatch):

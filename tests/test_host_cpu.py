@@ -585,6 +585,14 @@ def test_conv_one_wave_per_simd_kernel_addressing_and_pipeline_emulation():
     assert E.run(CI=64, F=2) == 50 * 4 * 64 * 9 * 2           # steps x waves x lanes x reads per K16 block x blocks
     assert E.run(CI=128, F=3, m_tile=1) > 0                   # the last tile's second run repeats its first
     assert E.run(CI=64, N=512, F=1, W=2, m_tile=1, n_tile=1) > 0
+    # round 6, RowMap mode 2 (any N_res): runs that straddle frame rows (N_res 96: 2.56 frame rows per run), a tile whose two runs
+    # lie in different windows, the ragged last run; and the row map itself (every interior cell exactly once, pad columns and
+    # the ragged end invalid, reads of the last run within the slack the Python layer keeps behind a grid)
+    assert E.run(CI=64, N=96, F=3, W=2, lin=True) > 0
+    assert E.run(CI=64, N=96, F=3, W=2, m_tile=1, lin=True) > 0          # runs 2 (window 0, ragged end) and 3 (window 1)
+    assert E.run(CI=64, N=40, F=5, W=3, m_tile=1, lin=True) > 0          # an odd number of runs: the second run repeats the first
+    for (N, F, W) in ((96, 16, 1), (128, 32, 4), (200, 5, 2), (27, 3, 3), (255, 2, 2), (257, 2, 1)):
+        assert E.lin_rows_check(N, F, W) == N * F * W
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
     groups += [[lane + 32 for lane in grp] for grp in groups]
     for w in range(4):

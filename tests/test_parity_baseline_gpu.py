@@ -105,7 +105,7 @@ def _step_vs_golden(name, keep=None):
             assert gr is not None, n
             ref = torch.tensor(g[k]).double()
             mine = (gr.reshape(-1)[::stride] if gr.numel() > 70000 else gr).double().cpu().reshape(ref.shape)
-            stats[n] = (abs(float(gr.double().norm()) - ref_norm) / ref_norm, float((mine - ref).norm() / (ref.norm() + 1e-30)))
+            stats[n] = (abs(float(gr.double().norm()) - ref_norm) / ref_norm, float((mine - ref).norm() / (ref.norm() + 1e-30)), ref_norm)
         return stats
 
     stats = grad_stats("gsub_", "gnorm_")
@@ -129,8 +129,32 @@ def _report(stats, tag):
     nrm = sorted(v[0] for v in stats.values())
     worst = max(stats.items(), key=lambda kv: kv[1][1])
     print(f"[{tag}] grad rel-L2 median {rel[len(rel) // 2]:.4f} max {rel[-1]:.4f} ({worst[0]}); "
-          f"norm err median {nrm[len(nrm) // 2]:.4f} max {nrm[-1]:.4f}")
+          f"norm err median {nrm[len(nrm) // 2]:.4f} max {nrm[-1]:.4f}; whole gradient {_whole(stats):.4f}")
     return rel, nrm
+
+
+def _whole(stats):
+    """relative L2 error of the WHOLE parameter gradient (all tensors as one vector; per-tensor errors weighted by the reference
+    norms): cosine with the reference's gradient = 1 - e^2 / 2 + O(e^4)"""
+    num = sum((v[1] * v[2]) ** 2 for v in stats.values())
+    den = sum(v[2] ** 2 for v in stats.values())
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def _class_spread(ytag):
+    """The per-tensor MAXIMUM of the full-loss gradient distance is a noise-dominated statistic at the BASELINE-sized windows: it
+    sits on AngleResnet / ipa_0 tensors whose gradient is a heavily cancelling sum over the last frame's rows of terms ~ 1/|raw|
+    (the torsion normalisation, openfold/utils/loss.py:58-59).  tests/golden/emulation_spread.json holds what the ORACLE itself
+    gives when it merely rounds where the engine's storage class rounds (oracle.EMULATE_BF16_OPERANDS, no mask feed, real loss),
+    over four realisations of the rounding noise (operands perturbed by 1e-6 before each bf16 rounding;
+    scripts/diag_emulation_spread.py, CPU, run in the build container): e.g. at 8 x 512 medians 0.073 .. 0.081, maxima
+    1.25 .. 2.25.  Returns the largest maximum of those realisations (None if the window was not measured)."""
+    import json
+    import os
+    from util import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "emulation_spread.json")) as fh:
+        d = json.load(fh)
+    return max(r["max"] for r in d[ytag]) if ytag in d else None
 
 
 def _yardstick(ytag, which):
@@ -147,27 +171,36 @@ def _yardstick(ytag, which):
     raise KeyError(ytag)
 
 
-def _check_big(full, frames, tag, ytag, full_max=True):
-    """Raw parameter gradients (no mask feeding, every ReLU / min() branch free to differ) against the reference's fp32 run,
-    measured against the YARDSTICK of the storage class: the reference's own code with bf16 parameters and bf16-rounded
-    Linear / Conv outputs moves by median 0.02 .. 0.08 / max 0.07 .. 0.46 per tensor from its fp32 self (`_yardstick`).  SURVEY
-    8c's proposed "3e-2 for bf16 paths" is not attainable by the reference either; the engine has to be in the reference's
-    own bf16 class: median within 1.5 x and maximum within 2 x (3 x with the torsion term) of the yardstick -- for the torsion-free run at every size, for
-    the full loss where the torsion normalisation is not yet ill-conditioned (up to 32 x 128).  At 32 x 256 and 8 x 512 the
-    full-loss gradient ~ 1 / |raw| of the few short raw torsion vectors amplifies the engine's larger forward difference (it
-    also rounds the attention internals): only the typical tensor is asserted there (measured median 0.19 vs 0.076, maximum
-    3.9 vs 0.46 at 32 x 256), the tight statement at that size being test_gradients_mask_aligned_oracle (<= 3e-2 per tensor)."""
+def _check_big(full, frames, tag, ytag):
+    """Raw parameter gradients (no mask feeding, every ReLU / min() branch free to differ, the REAL loss) against the reference's
+    fp32 run -- at EVERY golden, the benchmarked 32 x 256 window and 8 x 512 included (round 6; rounds 4-5 asserted the median only
+    there):
+      * the whole gradient: relative L2 error of all tensors as one vector <= 2e-2 (cosine >= 0.9998; measured 2e-3 .. 5e-3);
+      * the typical tensor: median per-tensor rel-L2 within 1.5 x of the YARDSTICK of the storage class -- the reference's own code
+        with bf16 parameters and bf16-rounded Linear / Conv outputs against its fp32 self (`_yardstick`: median 0.02 .. 0.08, max
+        0.07 .. 0.46; SURVEY 8c's proposed 3e-2 is not attainable by the reference either);
+      * the worst tensor: within 3 x of the yardstick's maximum, or -- where the oracle restatement of the engine's storage class
+        itself lands further out -- within 1.25 x of the worst realisation of that class (`_class_spread`).  Round 6 measured
+        what the maximum is made of (profiles/r6_grad_split_*.txt, r6_emulation_*.json): with the REFERENCE's output gradients
+        injected into the engine's backward it barely moves (32 x 256: 1.20 -> 0.71; 8 x 512: 0.42 -> 0.21), i.e. it is not the
+        forward difference amplified by the torsion normalisation but bf16 rounding inside cancelling row sums, present in every
+        implementation of the class; and it moves by 2 x between realisations of the rounding noise (and did between engine
+        revisions that only re-associated fp32 sums: 3.9 / 1.9 / 1.2 at 32 x 256 in rounds 4 / 5 / 6).
+    The tight per-tensor statement (<= 3e-2) stays test_gradients_mask_aligned_oracle; the torsion-free run is bounded at 1.5 x /
+    2 x of its yardstick at every size."""
     rel, nrm = _report(full, tag + ", full loss")
     ym, yx = _yardstick(ytag, "full")
-    print(f"[{tag}] yardstick (reference, bf16 storage vs fp32), full loss: median {ym:.4f} max {yx:.4f}")
+    spread = _class_spread(ytag)
+    print(f"[{tag}] yardstick (reference, bf16 storage vs fp32), full loss: median {ym:.4f} max {yx:.4f}; "
+          f"storage class as restated by the oracle, worst realisation: {spread}")
     assert nrm[len(nrm) // 2] < 5e-2
-    if full_max:
-        assert rel[len(rel) // 2] < 1.5 * ym + 5e-3 and rel[-1] < 3.0 * yx, (rel[len(rel) // 2], ym, rel[-1], yx)
-    else:
-        assert rel[len(rel) // 2] < 3.5 * ym, (rel[len(rel) // 2], ym)
+    assert _whole(full) < 2e-2, _whole(full)
+    bound = max(3.0 * yx, 1.25 * spread if spread is not None else 0.0)
+    assert rel[len(rel) // 2] < 1.5 * ym + 5e-3 and rel[-1] < bound, (rel[len(rel) // 2], ym, rel[-1], yx, spread)
     rel0, nrm0 = _report(frames, tag + ", torsion_loss_weight = 0")
     ym0, yx0 = _yardstick(ytag, "notorsion")
     print(f"[{tag}] yardstick, torsion_loss_weight = 0: median {ym0:.4f} max {yx0:.4f}")
+    assert _whole(frames) < 1e-2, _whole(frames)
     assert nrm0[-1] < 0.1 and rel0[len(rel0) // 2] < 1.5 * ym0 + 5e-3 and rel0[-1] < 2.0 * yx0, (rel0[len(rel0) // 2], ym0, rel0[-1], yx0, nrm0[-1])
 
 
@@ -195,7 +228,7 @@ def test_step_vs_reference_golden_config3_window():
     (train_DFOLD_dynamics.py:660-667,1182-1400; src/model/Dfold_network_dynamic.py:450-546): every output, the loss
     terms, every parameter gradient (norm + sampled entries)."""
     full, frames = _step_vs_golden("network_F32_N256.npz")
-    _check_big(full, frames, "cfg3 F32 N256", "F32_N256", full_max=False)
+    _check_big(full, frames, "cfg3 F32 N256", "F32_N256")
 
 
 def test_step_vs_reference_golden_config2_window():
@@ -211,7 +244,7 @@ def test_step_vs_reference_golden_config5_nres512():
     from dynamicpdb_amd import experiment, synthetic
     keep = {}
     full, frames = _step_vs_golden("network_F8_N512.npz", keep=keep)
-    _check_big(full, frames, "cfg5 F8 N512", "F8_N512", full_max=False)
+    _check_big(full, frames, "cfg5 F8 N512", "F8_N512")
     del keep
     torch.cuda.empty_cache()
     dev = torch.device(DEV)
