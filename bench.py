@@ -231,7 +231,10 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
     flops = 2.0 * 1280 * 640 * T(F) * T(N) * B        # algorithmic (non-padding taps), SURVEY 8(d): same for all 8 convs
     achieved = flops / avg_s / 1e12
     dev = batch["t"].device
-    dense = dense_conv_launches(dev, B, F, N)
+    # (DFOLD_BENCH_NO_DENSE=1: the rocprofv3 kernel-trace runs skip the isolated dense launches, whose kernels would be averaged into
+    #  the same rows as the step's own launches; the line then repeats the in-step forward time for them)
+    dense = dense_conv_launches(dev, B, F, N) if os.environ.get("DFOLD_BENCH_NO_DENSE") != "1" else \
+        {"forward": avg_s * 1e3, "dgrad": avg_s * 1e3, "wgrad": avg_s * 1e3}
     frac_of = lambda t_ms: round(flops / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
     traffic, traffic_source = None, None
     wt, c = None, None

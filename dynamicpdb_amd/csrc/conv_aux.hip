@@ -539,4 +539,34 @@ extern "C" int dfold_grid_load_flags(const void* src, void* grid, int32_t* ps, i
   return dfold_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// row-block flags of a dense fp32 gradient (round 6): one wave per block of rows, then the prefix sums
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_block_flags_kernel(const float* __restrict__ G, int* __restrict__ scratch, long R, int C, long ld,
+                                                              int block, int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nblocks) return;
+  const long r0 = (long)b * block;
+  const long rows = r0 + block <= R ? block : R - r0;
+  unsigned any = 0;
+  for (long i = lane; i < rows * C; i += 64) {
+    const long r = i / C, c = i - r * C;
+    any |= __float_as_uint(G[(r0 + r) * ld + c]) & 0x7fffffffu;
+  }
+  if (__ballot(any != 0) != 0 && lane == 0) scratch[b] = 1;
+}
+
+extern "C" int dfold_row_block_flags(const float* G, int32_t* ps, int32_t* scratch, int64_t R, int32_t C, int64_t ld, int32_t block,
+                                     void* stream) {
+  if (!G || !ps || !scratch || R <= 0 || C <= 0 || ld < C || block <= 0) return DFOLD_EINVAL;
+  const long nb = (R + block - 1) / block;
+  if (nb > (1L << 24)) return DFOLD_EINVAL;
+  DFOLD_LAUNCH(row_block_flags_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, (hipStream_t)stream, G, scratch, (long)R, C, (long)ld,
+               block, (int)nb);
+  if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
+  DFOLD_LAUNCH(frame_flags_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ps, scratch, 1, (int)nb);
+  return dfold_check_launch();
+}
+
 extern "C" int dfold_abi_version(void) { return DFOLD_ABI_VERSION; }

@@ -290,7 +290,9 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm256_kernel(const GemmPa
 // only the weight tile is staged per K step.  LDS-DMA pieces per wave and K step: 6 instead of 9 (their issue cost inside
 // the MFMA stream is the largest loss of the K loop: scripts/exp_conv_variants.py, NODMA +45 %).  Same K order, same
 // accumulation order: results are bit-identical to the per-tap form.
-template <int ROLE, int NJ, bool HALO = false>
+// RZ (round 6): row-block flags for A (dfold_gemm_desc.nz_ps with a plain row map): a tile whose 256 A rows are all zero by the
+// flags leaves out its K walk (zero accumulators, the usual epilogue).
+template <int ROLE, int NJ, bool HALO = false, bool RZ = false>
 __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmParams p) {
   constexpr int BNW = 64 * NJ;                 // N tile: 320 (NJ = 5) or 256 (NJ = 4)
   constexpr int BW_BYTES = BNW * BK * 2;
@@ -504,6 +506,13 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
   };
 
+  bool rz_live = true;
+  if (RZ) {
+    const int bs = p.nz_f0;
+    const int m_last = (m0 + BM3 < p.M ? m0 + BM3 : p.M) - 1;
+    rz_live = p.nz_ps[m_last / bs + 1] - p.nz_ps[m0 / bs] > 0;
+  }
+  if (!RZ || rz_live) {
   if (HALO) {
     // prologue: the whole halo tile of group 0 (33 pieces over 8 waves, surplus slots re-load piece 32), then weight tile 0
     const char* h0 = A + (p.a_seg0 + (long)df_lo * p.a_seg_s1) * 2;
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void dfold_mfma_gemm320_kernel(const GemmPa
     mma(0);
     mma(1);
   }
+  }   // rz_live
   if (ROLE == 1 && p.ws != nullptr) {
     // Deterministic split-K: gridDim.y workgroups hold partial sums of this output tile (each walked its own range of
     // channel chunks).  Every one parks its fp32 partial tile in the workspace; the last to arrive adds the partials in
@@ -691,6 +701,8 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   if ((d->flags & DFOLD_GEMM_BIAS) && !d->bias) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) && !d->R) return DFOLD_EINVAL;
   if ((d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)) && (d->flags & DFOLD_GEMM_OUT_BF16)) return DFOLD_EINVAL;
+  if ((d->flags & DFOLD_GEMM_C2RELU) && (!d->C2 || d->R2 || !(d->flags & DFOLD_GEMM_OUT_BF16))) return DFOLD_EINVAL;
+  if ((d->flags & DFOLD_GEMM_MASK2) && (!d->R2 || d->C2 || !(d->flags & DFOLD_GEMM_OUT_BF16))) return DFOLD_EINVAL;
   if (d->a_rows.mode != 0 && (d->a_rows.n <= 0 || d->a_rows.f <= 0 || d->a_rows.mode > 2 || d->a_rows.mode < 0)) return DFOLD_EINVAL;
   if (d->c_rows.mode != 0 && (d->c_rows.n <= 0 || d->c_rows.f <= 0 || d->c_rows.mode > 2 || d->c_rows.mode < 0)) return DFOLD_EINVAL;
   // mode 2 (cells of a window as one line, any N_res): conv launches of the 512 x 160 kernel only, both maps over the same grid
@@ -714,7 +726,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   p.ws = nullptr; p.cnt = nullptr; p.sk_per = 0; p.sk_tiles = 0; p.sk_fence = 1;
   p.conv_f0 = (d->conv_frames >> 16) & 0x7fff; p.conv_F = d->conv_frames & 0xffff;
   p.nz_ps = d->nz_ps; p.nz_radius = d->nz_radius; p.nz_f0 = d->nz_f0;
-  if (p.nz_ps && (d->a_rows.mode == 0 || p.nz_radius < 0 || p.nz_f0 < 0)) return DFOLD_EINVAL;
+  if (p.nz_ps && (p.nz_radius < 0 || p.nz_f0 < (d->a_rows.mode == 0 ? 1 : 0))) return DFOLD_EINVAL;
   if (lin && (d->M % (int)row_vw_host(p.am))) return DFOLD_EINVAL;
   static int prio_mode = -1;
   if (prio_mode < 0) {
@@ -820,7 +832,10 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);
     else if (role == 2)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<2, 5>), dim3((unsigned)(tiles320 * 25), 1, 1), dim3(512), lds, (hipStream_t)stream, p);
-    else
+    else if (p.nz_ps && d->a_rows.mode == 0 && d->nbatch == 1) {
+      DFOLD_MAX_LDS_ONCE((dfold_mfma_gemm320_kernel<0, 5, false, true>), 2 * STAGE3_BYTES);
+      DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<0, 5, false, true>), grid3, dim3(512), lds, (hipStream_t)stream, p);
+    } else
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<0, 5>), grid3, dim3(512), lds, (hipStream_t)stream, p);
     return dfold_check_launch();
   }

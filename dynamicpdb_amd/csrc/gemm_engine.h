@@ -52,8 +52,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   const int fl = p.flags;
   const int frow = lane & 31, fhalf = lane >> 5;
   const bool has_r = (fl & (DFOLD_GEMM_RESID | DFOLD_GEMM_RELUMASK)) != 0;
-  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
-  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
+  const bool c2_relu = p.C2 != nullptr && (fl & DFOLD_GEMM_C2RELU) != 0;
+  const bool mask2 = (fl & DFOLD_GEMM_MASK2) != 0;
+  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr && !c2_relu;
+  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr && !mask2;
   float bias_v[NJ];
   bool nok[NJ];
 #pragma unroll
@@ -74,7 +76,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int j = 0; j < NJ; ++j) {
         const bool ok = mok && nok[j];
         rv[j] = (has_r && ok) ? bf2f(p.R[ro + j * 32]) : 0.f;
-        r2v[j] = (c2_mask && ok) ? bf2f(p.R2[ro + j * 32]) : 0.f;
+        r2v[j] = ((c2_mask || mask2) && ok) ? bf2f(p.R2[ro + j * 32]) : 0.f;
         cv[j] = ((fl & DFOLD_GEMM_ACCUM) && ok) ? ((const float*)p.C)[ro + j * 32] : 0.f;
       }
 #pragma unroll
@@ -84,8 +86,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         float v = acc[i][j][e] * p.alpha + bias_v[j];
         if (fl & DFOLD_GEMM_RELU) v = fmaxf(v, 0.f);
         if (c2_pre && ok) ((bf16_t*)p.C2)[off] = f2bf(v);
+        if (mask2) v = r2v[j] > 0.f ? v : 0.f;
         if (fl & DFOLD_GEMM_RESID) v += rv[j];
         if (fl & DFOLD_GEMM_RELUMASK) v = rv[j] > 0.f ? v : 0.f;
+        if (c2_relu && ok) ((bf16_t*)p.C2)[off] = f2bf(fmaxf(bf2f(f2bf(v)), 0.f));
         if (fl & DFOLD_GEMM_OUT_BF16) {
           if (ok) ((bf16_t*)p.C)[off] = f2bf(v);
         } else if (fl & DFOLD_GEMM_ATOMIC) {
@@ -112,8 +116,10 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
   constexpr int CPR = NJ * 4;  // 16-byte chunks per row
   const int fl = p.flags;
   const int frow = lane & 31, fhalf = lane >> 5;
-  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr;
-  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr;
+  const bool c2_relu = p.C2 != nullptr && (fl & DFOLD_GEMM_C2RELU) != 0;
+  const bool mask2 = (fl & DFOLD_GEMM_MASK2) != 0;
+  const bool c2_pre = p.C2 != nullptr && p.R2 == nullptr && !c2_relu;
+  const bool c2_mask = p.C2 != nullptr && p.R2 != nullptr && !mask2;
   // (every global load of this epilogue is issued in a batch in front of its uses: written as `cond ? load : 0` / inside the
   //  store loop each one became its own branch with an s_waitcnt vmcnt(0) behind it -- 5 + 2 x 10 memory round trips per tile
   //  and wave on the launches with a residual or a ReLU mask, scripts/isa_audit.py)
@@ -159,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
 #pragma unroll
       for (int k = 0; k < CPR / 2; ++k) rr[k] = *(const gu32x4*)(p.R + (offs[k] < 0 ? 0 : offs[k]));
     }
-    if (c2_mask) {
+    if (c2_mask || mask2) {
 #pragma unroll
       for (int k = 0; k < CPR / 2; ++k) r2[k] = *(const gu32x4*)(p.R2 + (offs[k] < 0 ? 0 : offs[k]));
     }
@@ -171,6 +177,13 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
       const long off = offs[k];
       const bool live = off >= 0;
       if (c2_pre && live) *(gu32x4*)((bf16_t*)p.C2 + off) = val;
+      if (mask2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t rq = r2[k][q];
+          val[q] = (bf_lo(rq) > 0.f ? (val[q] & 0xffffu) : 0u) | (bf_hi(rq) > 0.f ? (val[q] & 0xffff0000u) : 0u);
+        }
+      }
       if (need_r) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -182,6 +195,13 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
         }
       }
       if (live) *(gu32x4*)((bf16_t*)p.C + off) = val;
+      if (c2_relu) {
+        gu32x4 rl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rl[q] = (bf_lo(val[q]) > 0.f ? (val[q] & 0xffffu) : 0u) | (bf_hi(val[q]) > 0.f ? (val[q] & 0xffff0000u) : 0u);
+        if (live) *(gu32x4*)((bf16_t*)p.C2 + off) = rl;
+      }
       if (c2_mask) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -40,6 +40,8 @@ struct TnGemmParams {
   int tiles_n, nb1, nsteps, flags;
   int M, N;
   float alpha;
+  const int* rz_ps;                   // row-block flags of A (prefix sums over blocks of rz_block reduction rows) or nullptr
+  int rz_block;
 };
 
 template <int OFF>
@@ -75,6 +77,10 @@ __device__ __forceinline__ void tg_pin() {   // (2 MFMA, 1 DMA) pairs inside a b
                : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(bfr[set][0]), "+v"(bfr[set][1]), "+v"(bfr[set][2]),   \
                  "+v"(bfr[set][3]))
 
+// RZ (round 6): row-block flags for A.  A split-K part walks only the blocks of rz_block reduction rows in which A can hold a
+// non-zero (one 64-bit mask per part, built with a ballot, walked on the scalar unit: lowest set bit = next block); a part
+// without any adds nothing and exits.  The rows left out contribute exact zeros.
+template <bool RZ>
 __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char tl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +93,16 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
   const int z = blockIdx.y, z0 = z / p.nb1, z1 = z - z0 * p.nb1;
   const long k0 = (long)blockIdx.z * p.ksplit;
   const long pitchA = p.lda * 2, pitchB = p.ldb * 2;
+  unsigned long rz_mask = 0;           // RZ: live blocks of this part still ahead of the K cursor
+  int rz_in = 0, rz_spb = 1, rz_steps = 0;
+  if (RZ) {
+    const int b0 = (int)(k0 / p.rz_block), nblk = (int)(p.ksplit / p.rz_block);     // (host: ksplit a multiple of rz_block, <= 64 blocks)
+    const bool lv = lane < nblk && p.rz_ps[b0 + lane + 1] - p.rz_ps[b0 + lane] > 0;
+    rz_mask = __ballot(lv);
+    if (rz_mask == 0) return;
+    rz_spb = p.rz_block / GBK;
+    rz_steps = __builtin_popcountl(rz_mask) * rz_spb;
+  }
   const char* pa = p.A + (z0 * p.sa0 + z1 * p.sa1 + m0) * 2 + k0 * pitchA;
   const char* pb = p.B + (z0 * p.sb0 + z1 * p.sb1 + n0) * 2 + k0 * pitchB;
 
@@ -100,7 +116,14 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
     boff0 = (unsigned)(row * pitchB + (n0 + lc * 8 < p.N ? lc : 0) * 16);
   }
   const long dA = GBK * pitchA, dB = GBK * pitchB;
-  int st_left = p.nsteps;
+  int st_left = RZ ? rz_steps : p.nsteps;
+  const char *pa0 = pa, *pb0 = pb;
+  if (RZ) {
+    const int cb = __builtin_ctzl(rz_mask);
+    rz_mask &= rz_mask - 1;
+    pa = pa0 + (long)cb * rz_spb * dA;
+    pb = pb0 + (long)cb * rz_spb * dB;
+  }
   auto stage_a = [&](int buf) {
     char* la = tl + buf * G_STAGE;
 #pragma unroll
@@ -112,10 +135,26 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       __builtin_amdgcn_global_load_lds((const void*)(pb + t * 16 * pitchB + boff0), (tg_lds_ptr_t)(lb + (t * 8 + w) * 1024), 16, 0, 0);
+    if (RZ) {
+      if (st_left > 1) {               // a tile after this one exists (else: re-read it, harmlessly)
+        --st_left;
+        if (++rz_in < rz_spb) {
+          pa += dA;
+          pb += dB;
+        } else {
+          rz_in = 0;
+          const int nb = __builtin_ctzl(rz_mask);
+          rz_mask &= rz_mask - 1;
+          pa = pa0 + (long)nb * rz_spb * dA;
+          pb = pb0 + (long)nb * rz_spb * dB;
+        }
+      }
+    } else {
     const unsigned adv = (unsigned)(1 - st_left) >> 31;        // a tile after this one exists (else: re-read it, harmlessly)
     st_left -= (int)adv;
     pa += dA & -(long)adv;
     pb += dB & -(long)adv;
+    }
   };
 
   f32x16 acc[2][GNJ];
@@ -147,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
 
   stage_a(0);
   stage_b(0);
-  const int nsteps = p.nsteps;
+  const int nsteps = RZ ? rz_steps : p.nsteps;
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
   if (w < 4) {
     for (int s = 0; s < nsteps; ++s) {
@@ -277,10 +316,10 @@ __global__ __launch_bounds__(512, 2) void dfold_tn_gemm_kernel(const TnGemmParam
   }
 }
 
-extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda,
-                                  int64_t ldb, int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1,
-                                  int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags,
-                                  float alpha, void* stream) {
+static int tn_gemm_launch(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1,
+                          int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags,
+                          float alpha, const int32_t* rz_ps, int32_t rz_block, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || splitk <= 0) return DFOLD_EINVAL;
   if ((M & 7) || (N & 7) || (K % ((long)splitk * GBK))) return DFOLD_EINVAL;
   if (lda < M || ldb < N || ldc < N || (lda & 7) || (ldb & 7) || ((sa0 | sa1 | sb0 | sb1) & 7)) return DFOLD_EINVAL;
@@ -290,6 +329,9 @@ extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t
                                         ((uintptr_t)C & 15)))
     return DFOLD_EINVAL;
   if (splitk > 1 && !(flags & DFOLD_GEMM_ATOMIC)) return DFOLD_EINVAL;
+  if (rz_ps && (rz_block <= 0 || (rz_block % GBK) || nbatch != 1 || !(flags & (DFOLD_GEMM_ATOMIC | DFOLD_GEMM_ACCUM)) ||
+                ((K / splitk) % rz_block) || (K / splitk) / rz_block > 64))
+    return DFOLD_EINVAL;
   if ((long)(GBK + 2) * lda * 2 >= (1L << 31) || (long)(GBK + 2) * ldb * 2 >= (1L << 31)) return DFOLD_EINVAL;   // 32-bit lane offsets
   TnGemmParams p;
   p.A = (const char*)A; p.B = (const char*)B; p.C = C;
@@ -298,8 +340,31 @@ extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t
   p.ksplit = K / splitk;
   p.tiles_n = (N + GBT - 1) / GBT; p.nb1 = nb1 > 0 ? nb1 : 1; p.nsteps = (int)(p.ksplit / GBK); p.flags = flags; p.alpha = alpha;
   p.M = M; p.N = N;
+  p.rz_ps = rz_ps; p.rz_block = rz_block;
   dim3 grid((unsigned)(((M + GBT - 1) / GBT) * p.tiles_n), (unsigned)nbatch, (unsigned)splitk);
-  DFOLD_MAX_LDS_ONCE(dfold_tn_gemm_kernel, 2 * G_STAGE);
-  DFOLD_LAUNCH(dfold_tn_gemm_kernel, grid, dim3(512), (size_t)(2 * G_STAGE), (hipStream_t)stream, p);
+  if (rz_ps) {
+    DFOLD_MAX_LDS_ONCE(dfold_tn_gemm_kernel<true>, 2 * G_STAGE);
+    DFOLD_LAUNCH(dfold_tn_gemm_kernel<true>, grid, dim3(512), (size_t)(2 * G_STAGE), (hipStream_t)stream, p);
+  } else {
+    DFOLD_MAX_LDS_ONCE(dfold_tn_gemm_kernel<false>, 2 * G_STAGE);
+    DFOLD_LAUNCH(dfold_tn_gemm_kernel<false>, grid, dim3(512), (size_t)(2 * G_STAGE), (hipStream_t)stream, p);
+  }
   return dfold_check_launch();
+}
+
+extern "C" int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda,
+                                  int64_t ldb, int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1,
+                                  int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags,
+                                  float alpha, void* stream) {
+  return tn_gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, nbatch, nb1, sa0, sa1, sb0, sb1, sc0, sc1, splitk, flags, alpha, nullptr, 0,
+                        stream);
+}
+
+extern "C" int dfold_gemm_tn_bf16_rowflags(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda,
+                                           int64_t ldb, int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1,
+                                           int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags,
+                                           float alpha, const int32_t* ps, int32_t block, void* stream) {
+  if (!ps) return DFOLD_EINVAL;
+  return tn_gemm_launch(A, B, C, M, N, K, lda, ldb, ldc, nbatch, nb1, sa0, sa1, sb0, sb1, sc0, sc1, splitk, flags, alpha, ps, block,
+                        stream);
 }

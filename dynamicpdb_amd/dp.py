@@ -342,16 +342,27 @@ class GradReducer:
             return                                # no collective, no host wait: the stream waits, the host runs ahead
         self._steps_since_check = 0               # (static mode: one flag collective every `static_check_every` steps catches a
                                                   #  divergence that only another rank can see)
-        flags = torch.zeros(2 * n, dtype=torch.int32)
+        # (2 n per-parameter flags + one for "a bucket of this rank was short of gradients while the static promise is armed":
+        #  on the periodic check step of the static mode every rank learns of it in the same collective and they fail TOGETHER --
+        #  between check steps the rank that sees it raises alone, see above)
+        armed = self.static_graph and self._clean_steps >= 2
+        flags = torch.zeros(2 * n + 1, dtype=torch.int32)
         for i in self._late:
             flags[i] = 1
         for i in self._stray:
             flags[n + i] = 1
+        if armed and self._missing:
+            flags[2 * n] = 1
         if self.world > 1:
             stage = self._stage_host or dev.type != "cuda"
             f = flags if stage else flags.to(dev)
             dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
             flags = f.cpu()
+        if bool(flags[2 * n]):
+            raise RuntimeError("GradReducer(static_graph=True): on some rank a bucket was short of gradients (a parameter stopped "
+                               f"receiving one; this rank: buckets {self._missing}) -- every rank raises on this check step; run "
+                               "without static_graph to have such steps repaired collectively")
+        flags = flags[:2 * n]
         if not bool(flags.any()):
             # two clean steps in the STEADY state arm the static mode: the discovery step (one blocking reduction of
             # everything) verifies nothing about the hook-driven path, and a step that needed finish() to launch a bucket

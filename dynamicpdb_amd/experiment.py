@@ -131,6 +131,8 @@ def set_t_feats(diffuser, feats, t, like):
     rs, ts = diffuser.score_scaling(t)
     feats['t'] = torch.full_like(like, float(t))
     feats['t_host'] = np.full(tuple(like.shape), float(t))      # (the forward then needs no device -> host copy of t)
+    from .model.ipa_pytorch_dynamic import stamp_t_host
+    stamp_t_host(feats)            # valid for exactly this 't' tensor: a later `feats['t'] = ...` or in-place write voids the copy
     feats['rot_score_scaling'] = torch.full_like(like, float(rs))
     feats['trans_score_scaling'] = torch.full_like(like, float(ts))
     return feats

@@ -49,7 +49,12 @@ class FullScoreNetwork(nn.Module):
         feats = input_feats if batched else {k: (v[None] if torch.is_tensor(v) and k not in ('t',) else v)
                                              for k, v in input_feats.items()}
         if not batched:
+            keep = ipa_pytorch_dynamic.t_host_valid(input_feats)      # (before 't' is replaced by its reshaped view)
             feats['t'] = input_feats['t'].reshape(1)
+            if keep:
+                ipa_pytorch_dynamic.stamp_t_host(feats)
+            else:
+                feats.pop('t_host', None)
         dev = feats['rigids_0'].device
         if dev.type != 'cuda':
             raise RuntimeError("FullScoreNetwork (dynamicpdb_amd) needs device tensors on an MI355X; no CPU fallback")

@@ -72,8 +72,9 @@ def _pad_cols8(g2d):
     return out
 
 
-def _linear_backward(x2d, weight, g2d, need_dx=True):
-    """x2d bf16 [M,K], g2d bf16 [M,N]  ->  dx bf16 [M,K] | None, dW fp32 [N,K], db fp32 [N]"""
+def _linear_backward(x2d, weight, g2d, need_dx=True, rz=None):
+    """x2d bf16 [M,K], g2d bf16 [M,N]  ->  dx bf16 [M,K] | None, dW fp32 [N,K], db fp32 [N].  rz: row-block flags of g2d
+    (ops.row_block_flags) for the weight-gradient product"""
     M, K = x2d.shape
     N = weight.shape[0]
     g8 = _pad_cols8(g2d)
@@ -85,7 +86,7 @@ def _linear_backward(x2d, weight, g2d, need_dx=True):
         gemm(g8, wt, dx, M, K, N8, a_rows=rows_plain(N8), c_rows=rows_plain(K), ldb=N8)
     if ops.gemm_tn_ok(N8, K, M, ragged=True) and K % 8 == 0 and g8.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
         # both operands have the reduction index (the rows) as their slow axis: csrc/tn_gemm.hip reads them as they lie
-        dW = ops.weight_grad_tn(g8, x2d, M, N8, K)
+        dW = ops.weight_grad_tn(g8, x2d, M, N8, K, rz=rz)
         db = torch.zeros(N8, dtype=torch.float32, device=x2d.device)
         ops.colsum_bf16(g8, db, M, N8, N8)
         return dx, dW[:N], db[:N]
@@ -197,6 +198,93 @@ class EmbedInFn(Function):
                                             c_int64(x2d.shape[0]), c_int32(k), c_int32(weight.shape[0]), stream()),
               "dfold_embed_in_bwd")
         return (dx.view(ctx.xshape) if dx is not None else None, dW, db)
+
+
+class AngleResnetFn(Function):
+    """AngleResnet up to its raw 2-vectors (openfold/model/structure_module.py:114-151: linear_in(relu s) + linear_initial(relu
+    s_initial), two residual blocks a += linear_2(relu(linear_1(relu a))), linear_out(relu a)) as ONE node (round 6; before: a chain
+    of LinearFn nodes with aten ReLUs / adds between them).  Every ReLU and residual add rides in a GEMM epilogue: the residual
+    stream leaves a launch together with its ReLU'd copy, the next layer's operand (DFOLD_GEMM_RESID + DFOLD_GEMM_C2RELU); in the
+    backward the ReLU masks are epilogue masks (DFOLD_GEMM_RELUMASK) and a branch gradient joins the residual gradient stream in
+    the launch that produces it (DFOLD_GEMM_MASK2 + DFOLD_GEMM_RESID).  The incoming gradient of a per-position head is zero on
+    every row no loss term reads (the reference's loss: all frames but the last): the node flags the 256-row blocks that hold a
+    non-zero (dfold_row_block_flags) and its seven dx launches and seven weight-gradient products skip the rest on the device --
+    loss-agnostic like the conv tower's zero-frame skipping (a loss that reads every row flags every block).
+    s, s_initial bf16 [..., C]; returns fp32 [..., no_angles * 2]."""
+
+    @staticmethod
+    def forward(ctx, s, s_initial, *params):
+        (w_in, b_in, w_init, b_init, w11, b11, w12, b12, w21, b21, w22, b22, w_out, b_out) = params
+        C = w_in.shape[1]
+        H = w_in.shape[0]
+        s2, si2 = s.reshape(-1, C).contiguous(), s_initial.reshape(-1, C).contiguous()
+        M = s2.shape[0]
+        dev = s2.device
+        new = lambda n: torch.empty((M, n), dtype=BF16, device=dev)
+        lin = lambda x, w, b, out, **kw: gemm(x, CACHE.w(w), out, M, w.shape[0], w.shape[1], a_rows=rows_plain(w.shape[1]),
+                                              c_rows=rows_plain(w.shape[0]), ldb=w.shape[1], bias=b.detach(), **kw)
+        r_s, r_i = ops.relu_mask_bf16(s2, s2, new(C)), ops.relu_mask_bf16(si2, si2, new(C))
+        a, r_a0 = new(H), new(H)
+        lin(r_s, w_in, b_in, a)
+        lin(r_i, w_init, b_init, a, R=a, C2=r_a0, flags=ops.GEMM_RESID | ops.GEMM_C2RELU)
+        h0, r_a1 = new(H), new(H)
+        lin(r_a0, w11, b11, h0, flags=ops.GEMM_RELU)
+        lin(h0, w12, b12, a, R=a, C2=r_a1, flags=ops.GEMM_RESID | ops.GEMM_C2RELU)
+        h1, r_a2 = new(H), new(H)
+        lin(r_a1, w21, b21, h1, flags=ops.GEMM_RELU)
+        lin(h1, w22, b22, a, R=a, C2=r_a2, flags=ops.GEMM_RESID | ops.GEMM_C2RELU)
+        out = torch.empty((M, w_out.shape[0]), dtype=torch.float32, device=dev)
+        lin(r_a2, w_out, b_out, out)
+        ctx.save_for_backward(r_s, r_i, r_a0, h0, r_a1, h1, r_a2, *params)
+        ctx.sshape = s.shape
+        return out.view(*s.shape[:-1], w_out.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        r_s, r_i, r_a0, h0, r_a1, h1, r_a2, *params = ctx.saved_tensors
+        (w_in, b_in, w_init, b_init, w11, b11, w12, b12, w21, b21, w22, b22, w_out, b_out) = params
+        M, H = r_a2.shape
+        C = r_s.shape[1]
+        dev = r_s.device
+        g = gy.reshape(M, -1)
+        g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
+        block = 256
+        rz = (ops.row_block_flags(g, block), block) if (_ANGLE_RZ and M % block == 0) else None
+        nz = None if rz is None else (rz[0], 0, block)
+        g8 = _pad_cols8(ops.cast_bf16(g))
+        new = lambda n: torch.empty((M, n), dtype=BF16, device=dev)
+
+        def dx(gr, w, out, **kw):        # out = epi(gr @ W): gr bf16 [M, N8], W [N, K] -> [M, K]
+            wt = CACHE.wt(w)             # [K][N8]
+            return gemm(gr, wt, out, M, w.shape[1], wt.shape[1], a_rows=rows_plain(gr.shape[1]), c_rows=rows_plain(w.shape[1]),
+                        ldb=wt.shape[1], nz=nz, **kw)
+
+        def dwb(x, w, gr, with_bias=True):
+            _, dW, db = _linear_backward(x, w, gr, need_dx=False, rz=rz)
+            return dW, (db if with_bias else None)
+
+        da = dx(g8, w_out, new(H), R=r_a2, flags=ops.GEMM_RELUMASK)
+        dW_out, db_out = dwb(r_a2, w_out, g8)
+        grads = {}
+        for (wa, wb_, h, r_prev, tag) in ((w21, w22, h1, r_a1, 2), (w11, w12, h0, r_a0, 1)):
+            dW2, db2 = dwb(h, wb_, da)
+            dh = dx(da, wb_, new(H), R=h, flags=ops.GEMM_RELUMASK)
+            dW1, db1 = dwb(r_prev, wa, dh)
+            da_new = new(H)
+            dx(dh, wa, da_new, R=da, R2=r_prev, flags=ops.GEMM_RESID | ops.GEMM_MASK2)
+            da = da_new
+            grads[tag] = (dW1, db1, dW2, db2)
+        dW_in, db_in = dwb(r_s, w_in, da)
+        dW_init, _ = dwb(r_i, w_init, da, with_bias=False)
+        need = ctx.needs_input_grad
+        ds = dx(da, w_in, new(C), R=r_s, flags=ops.GEMM_RELUMASK).view(ctx.sshape) if need[0] else None
+        dsi = dx(da, w_init, new(C), R=r_i, flags=ops.GEMM_RELUMASK).view(ctx.sshape) if need[1] else None
+        return (ds, dsi, dW_in, db_in, dW_init, db_in.clone(), grads[1][0], grads[1][1], grads[1][2], grads[1][3],
+                grads[2][0], grads[2][1], grads[2][2], grads[2][3], dW_out, db_out)
+
+
+# DFOLD_ANGLE_RZ=0: the angle head's backward launches walk every row (A/B runs of the row-block skipping)
+_ANGLE_RZ = os.environ.get("DFOLD_ANGLE_RZ", "1") != "0"
 
 
 def ctypes_float(v):

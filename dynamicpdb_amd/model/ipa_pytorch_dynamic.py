@@ -21,6 +21,21 @@ from . import functional as F_
 from . import geometry as G
 
 
+def stamp_t_host(feats):
+    """record which tensor (identity by weak reference, and version counter) feats['t_host'] is the host copy of"""
+    import weakref
+    t = feats['t']
+    feats['t_host_stamp'] = (weakref.ref(t), t._version)
+    return feats
+
+
+def t_host_valid(feats):
+    """feats['t_host'] may stand in for feats['t'] only if 't' is still the very tensor, unwritten, it was copied from"""
+    st = feats.get('t_host_stamp')
+    t = feats.get('t')
+    return feats.get('t_host') is not None and st is not None and torch.is_tensor(t) and st[0]() is t and st[1] == t._version
+
+
 def _require_cuda(t):
     if not t.is_cuda:
         raise RuntimeError("dynamicpdb_amd operators run on an MI355X device tensor (no CPU fallback); "
@@ -163,16 +178,28 @@ class AngleResnet(nn.Module):
     def forward(self, s, s_initial):
         _require_cuda(s)
         s, s_initial = s.to(BF16), s_initial.to(BF16)
-        a = F_.linear(_relu(s), self.linear_in.weight, self.linear_in.bias) + \
-            F_.linear(_relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
-        for l in self.layers:
-            h = F_.linear(_relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
-            a = a + F_.linear(h, l.linear_2.weight, l.linear_2.bias)
-        out = F_.linear(_relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
+        l0, l1 = self.layers[0], self.layers[1]
+        if (self.no_blocks == 2 and self.c_in % 8 == 0 and self.c_hidden % 8 == 0 and _ANGLE_FUSED):
+            # one autograd node: ReLUs, residual adds and the ReLU backward ride in the GEMM epilogues (functional.AngleResnetFn)
+            out = F_.AngleResnetFn.apply(s, s_initial, self.linear_in.weight, self.linear_in.bias, self.linear_initial.weight,
+                                         self.linear_initial.bias, l0.linear_1.weight, l0.linear_1.bias, l0.linear_2.weight,
+                                         l0.linear_2.bias, l1.linear_1.weight, l1.linear_1.bias, l1.linear_2.weight, l1.linear_2.bias,
+                                         self.linear_out.weight, self.linear_out.bias)
+        else:
+            a = F_.linear(_relu(s), self.linear_in.weight, self.linear_in.bias) + \
+                F_.linear(_relu(s_initial), self.linear_initial.weight, self.linear_initial.bias)
+            for l in self.layers:
+                h = F_.linear(_relu(a), l.linear_1.weight, l.linear_1.bias, relu=True)
+                a = a + F_.linear(h, l.linear_2.weight, l.linear_2.bias)
+            out = F_.linear(_relu(a), self.linear_out.weight, self.linear_out.bias, out_fp32=True)
         out = out.view(out.shape[:-1] + (-1, 2))
         unnorm = out
         denom = torch.sqrt(torch.clamp(torch.sum(out ** 2, dim=-1, keepdim=True), min=self.eps))
         return unnorm, out / denom
+
+
+# DFOLD_ANGLE_FUSED=0: AngleResnet as the chain of single-layer nodes with aten ReLUs / adds of rounds 1-5
+_ANGLE_FUSED = os.environ.get("DFOLD_ANGLE_FUSED", "1") != "0"
 
 
 class InvariantPointAttention(nn.Module):
@@ -346,8 +373,13 @@ class DFOLDIpaScore(nn.Module):
         else:
             unorm_angles, angles = self.angle_resnet(node_feat, init_node_feat)
         t = input_feats['t'].reshape(B)
+        # 't_host' is a second copy of the diffusion times; it is trusted only while it can still be the copy of THIS 't': it
+        # must have one entry per window and have been set together with the tensor (experiment.set_t_feats / synthetic.device_batch
+        # record the tensor's identity and version) -- a batch whose 't' was reassigned or written afterwards falls back to the
+        # device -> host copy instead of a stale sigma
+        t_host = input_feats.get('t_host') if t_host_valid(input_feats) and np.size(input_feats['t_host']) == B else None
         rot_score = self.diffuser.calc_rot_score_t7(rigids_t[..., :4], curr_rigids[..., :4], t,
-                                                    t_host=input_feats.get('t_host')) * node_mask[..., None]
+                                                    t_host=t_host) * node_mask[..., None]
         curr_rigids = self.unscale_rigids(curr_rigids)
         trans_score = self.diffuser.calc_trans_score(rigids_t[..., 4:], curr_rigids[..., 4:], t[:, None, None, None],
                                                      use_torch=True) * node_mask[..., None]

@@ -16,20 +16,29 @@ def series_envelope(sigma, L=1000):
     return (2 * ls + 1)[None, :] * np.exp(-ls[None, :] * (ls[None, :] + 1) * sigma[:, None] ** 2 / 2)
 
 
-_ENV_CACHE = {}
+_ENV_ROWS = {}        # (sigma, L, device) -> float64 [L] device row; at most one per discretised sigma (1000) and device
 
 
 def _envelope_on_device(sigma, L, device):
-    """the series envelope of a tuple of sigmas as a device tensor, cached: the sampler visits num_t diffusion times and a
-    training run a discretised schedule of 1000 sigmas, so the host series + its upload (a synchronous copy in every forward,
-    which also keeps the forward out of HIP graphs) happens once per distinct value"""
-    key = (tuple(np.atleast_1d(np.asarray(sigma, dtype=np.float64)).tolist()), L, str(device))
-    env = _ENV_CACHE.get(key)
-    if env is None:
-        if len(_ENV_CACHE) > 4096:
-            _ENV_CACHE.clear()
-        env = _ENV_CACHE[key] = torch.tensor(series_envelope(sigma, L), dtype=torch.float64, device=device)
-    return env
+    """the series envelope of the windows' sigmas as a float64 [W, L] device tensor.  Rows are cached PER SIGMA (the schedule has
+    1000 discrete values, so3_diffuser.py:188-190: the cache is bounded at 8 MB per device however the windows of a batch
+    combine them; a cache keyed by the whole tuple of a batch almost never hit under per-window random t and kept up to 4096
+    [W, L] tensors -- ADVICE r5): the host series + upload happens once per distinct value, a batch stacks its rows on the device."""
+    sig = np.atleast_1d(np.asarray(sigma, dtype=np.float64))
+    rows = []
+    for v in sig.tolist():
+        key = (v, L, str(device))
+        r = _ENV_ROWS.get(key)
+        if r is None:
+            if len(_ENV_ROWS) > 8192:
+                _ENV_ROWS.clear()
+            r = _ENV_ROWS[key] = torch.tensor(series_envelope(v, L)[0], dtype=torch.float64, device=device)
+        rows.append(r)
+    if len(rows) == 1:
+        return rows[0][None]
+    if all(r is rows[0] for r in rows):
+        return rows[0][None].expand(len(rows), L).contiguous()
+    return torch.stack(rows)
 
 
 def igso3_score(vec, sigma, eps=1e-6, L=1000):

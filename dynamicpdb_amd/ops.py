@@ -10,6 +10,8 @@ from . import _lib
 from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU, GEMM_RELUMASK, GEMM_RESID, GemmDesc,
                    RowMap, check, stream)
 
+GEMM_C2RELU, GEMM_MASK2 = 128, 256          # include/dfold_hip.h
+
 BF16 = torch.bfloat16
 _zero_pages = {}
 _seg_tables = {}
@@ -137,16 +139,42 @@ def gemm_tn_ok(M, N, K, ragged=False):
     return M % 256 == 0 and N % 256 == 0
 
 
-def weight_grad_tn(g2d, x2d, M, N, K, out=None):
+def weight_grad_tn(g2d, x2d, M, N, K, out=None, rz=None):
     """dW fp32 [N, K] (+)= g2d^T x2d for g2d bf16 [M, N], x2d bf16 [M, K]: the long row axis M is cut into split-K parts so
-    that the few 256 x 256 output tiles still fill the chip."""
+    that the few 256 x 256 output tiles still fill the chip.  rz = (ps, block): row-block flags of g2d (row_block_flags): parts
+    whose rows are all zero exit at once -- the split is then as fine as the flags (parts of `block` rows, at most 256 of them)."""
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     S = max(1, min(64, 512 // tiles))
     while S > 1 and (M % (S * 64)):
         S -= 1
+    if rz is not None and (rz[1] % 64 or (M // S) % rz[1] or (M // S) // rz[1] > 64):
+        rz = None                        # (a part must be whole flag blocks, at most 64 of them: else every row is walked)
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=g2d.device)
-    return gemm_tn(g2d, x2d, out, N, K, M, N, K, K, splitk=S, flags=GEMM_ATOMIC)
+    if rz is None:
+        return gemm_tn(g2d, x2d, out, N, K, M, N, K, K, splitk=S, flags=GEMM_ATOMIC)
+    check(_lib.lib().dfold_gemm_tn_bf16_rowflags(_p(g2d), _p(x2d), _p(out), c_int32(N), c_int32(K), c_int64(M), c_int64(N), c_int64(K),
+                                                 c_int64(K), c_int32(1), c_int32(1), c_int64(0), c_int64(0), c_int64(0), c_int64(0),
+                                                 c_int64(0), c_int64(0), c_int32(S), c_int32(GEMM_ATOMIC), ctypes.c_float(1.0),
+                                                 _p(rz[0]), c_int32(rz[1]), stream()), "dfold_gemm_tn_bf16_rowflags")
+    return out
+
+
+def row_block_flags(g2d, block=256):
+    """prefix sums of the non-zero flags of blocks of `block` rows of the fp32 matrix g2d [R, C] (dfold_row_block_flags)"""
+    R, C = g2d.shape
+    nb = (R + block - 1) // block
+    ps = torch.empty(nb + 1, dtype=torch.int32, device=g2d.device)
+    key = (g2d.device, nb)
+    scratch = _rz_scratch.get(key)
+    if scratch is None:
+        scratch = _rz_scratch[key] = torch.zeros(nb, dtype=torch.int32, device=g2d.device)
+    check(_lib.lib().dfold_row_block_flags(_p(g2d), _p(ps), _p(scratch), c_int64(R), c_int32(C), c_int64(g2d.stride(0)), c_int32(block),
+                                           stream()), "dfold_row_block_flags")
+    return ps
+
+
+_rz_scratch = {}
 
 
 def cast_bf16(x):
@@ -345,6 +373,20 @@ def conv_lin_wins(Wn, nf, N, CO, n_cu, nz=False):
     t_old = -(-(Wn * nf * N) // 256) * (CO // 320)
     t_new = -(-(Wn * (-(-(nf * (N + 4)) // 256))) // 2) * (CO // 160)
     return t_old >= n_cu // 2 and -(-t_new // n_cu) <= -(-t_old // n_cu)
+
+
+_TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
+
+
+def conv_tail_frames(nf, tiles_per_frame, n_cu):
+    """Frames to cut off the end of a thin conv launch of nf frames (512 x 160 tiles, tiles_per_frame of them per frame) so that
+    what stays is whole rounds of n_cu tiles: the remainder must be whole frames and at most a quarter of a round (a larger
+    remainder fills the chip well enough on its own).  0: leave the launch alone."""
+    tiles = nf * tiles_per_frame
+    rem = tiles % n_cu if n_cu > 0 else 0
+    if tiles_per_frame <= 0 or tiles <= n_cu or rem == 0 or rem % tiles_per_frame or 4 * rem > n_cu:
+        return 0
+    return rem // tiles_per_frame
 
 
 # DFOLD_CONV_SKIP_PAD=1: let the edge tiles of a conv launch skip their all-padding frame taps (dfold_gemm_desc.conv_frames).

@@ -197,6 +197,8 @@ def device_batch(rng, diffuser, B, F, N, t=0.5):
         torsion_angles_mask=torch.ones(B, F, N, 7, device=dev), sc_ca_t=torch.zeros(B, F, N, 3, device=dev),
         t=torch.full((B,), float(t), dtype=f32, device=dev))
     w["t_host"] = np.full((B,), float(t))          # the diffusion times as host numbers (no device -> host copy in the forward)
+    from .model.ipa_pytorch_dynamic import stamp_t_host
+    stamp_t_host(w)
     fm = diffuser.forward_marginal_t7(rigids_0, torch.full((B,), float(t), dtype=torch.float64), rng=rng)
     w["rigids_t"] = fm["rigids_t"].to(f32)
     w["rot_score"], w["trans_score"] = fm["rot_score"], fm["trans_score"]

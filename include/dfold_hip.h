@@ -67,6 +67,10 @@ typedef struct {
 #define DFOLD_GEMM_OUT_BF16 16 /* C is bf16 (else fp32) */
 #define DFOLD_GEMM_ACCUM 32    /* fp32 C += v */
 #define DFOLD_GEMM_ATOMIC 64   /* fp32 atomicAdd(C, v): split-K slices (batches that share C) */
+#define DFOLD_GEMM_C2RELU 128  /* bf16 C with a second output C2 (R2 == NULL): C2 = max(value written to C, 0) -- the next layer's
+                                  ReLU'd operand leaves with the residual stream (AngleResnet, structure_module.py:64-71) */
+#define DFOLD_GEMM_MASK2 256   /* v = R2[off] > 0 ? v : 0 BEFORE the residual add (R2 bf16; no C2): the ReLU backward of a
+                                  branch that joins a residual gradient stream in the same launch */
 
 typedef struct {
   const void* A;        /* bf16 */
@@ -116,7 +120,11 @@ typedef struct {
      An output tile all of whose input frame rows are zero by that statement does not walk K: its accumulators are zero and
      the epilogue runs as usual (results identical to the full walk: the skipped products are exact zeros).  Decided on the
      device per tile; no host synchronisation.  nz_f0 = padded frame row of the first tap row of logical frame 0 of a_rows.
-     Launches that do not take the 512 x 160 kernel, and stream-K launches, ignore the fields (same results). */
+     Launches that do not take the 512 x 160 kernel, and stream-K launches, ignore the fields (same results).
+     Plain row maps (a_rows.mode == 0, round 6): nz_ps = the prefix sums of dfold_row_block_flags over blocks of nz_f0 rows of A
+     (nz_radius unused): a 256-row output tile whose A rows are all zero by them skips its K walk (accumulators zero, epilogue
+     as usual) -- the dx products of a dense layer whose incoming gradient lives on a few frames.  Honoured by the 256 x 320
+     kernel's dense form, ignored elsewhere. */
   const int32_t* nz_ps;
   int32_t nz_radius, nz_f0;
 } dfold_gemm_desc;
@@ -152,6 +160,19 @@ int dfold_grid_transpose_shift(const void* X, void* T, int32_t W, int32_t Fp, in
 int dfold_gemm_tn_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
                        int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                        int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags, float alpha, void* stream);
+/* dfold_gemm_tn_bf16 with row-block flags for A (the incoming gradient of a dense layer's weight-gradient product): ps = the
+   prefix sums of dfold_row_block_flags over blocks of `block` reduction rows; a split-K part whose rows are all zero by them
+   adds nothing and exits (needs DFOLD_GEMM_ATOMIC or DFOLD_GEMM_ACCUM: C already holds what the part would have left) */
+int dfold_gemm_tn_bf16_rowflags(const void* A, const void* B, void* C, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
+                                int64_t ldc, int32_t nbatch, int32_t nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
+                                int64_t sc0, int64_t sc1, int32_t splitk, int32_t flags, float alpha, const int32_t* ps,
+                                int32_t block, void* stream);
+/* Which blocks of `block` consecutive rows of G (fp32 [R][C], rows of ld elements) hold a non-zero: ps int32 [nblocks + 1],
+   ps[i] = number of non-zero blocks j < i (nblocks = ceil(R / block)); scratch: nblocks int32, zero before the call and left
+   zero.  The gradient that reaches a per-position head from a loss that reads some frames only (train_DFOLD_dynamics.py:
+   1219-1340: the last one) is zero on all other rows; the dense backward launches skip them on the device. */
+int dfold_row_block_flags(const float* G, int32_t* ps, int32_t* scratch, int64_t R, int32_t C, int64_t ld, int32_t block,
+                          void* stream);
 /* 5x5 conv weight gradient straight from the zero-padded channels-last grids (the autograd of nn.Conv2d,
    src/model/ipa_pytorch_dynamic.py:669-690), no operand copies (csrc/conv_wgrad_tn.hip, ds_read_b64_tr_b16 fragments):
      dWg[a][tap][b] (+)= sum_{w < W, f0 <= f < f0+nf, n < N}  A[w][2+f][2+n][a] * B[w][f+z0][n+z1][b],   z0, z1 = 0..4,

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- \
+DFOLD_BENCH_NO_DENSE=1 DFOLD_BENCH_PMC=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- \
     python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-last-frame-mode --no-all-positions-mode --no-triangle --no-other-configs --no-eval-config --no-neighbours ${BENCH_EXTRA:-} > /tmp/b.log 2>&1 < /dev/null
 echo "rocprofv3 rc=$?"
 tail -n 2 /tmp/b.log | cut -c1-400

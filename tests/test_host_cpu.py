@@ -36,10 +36,27 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert L.dfold_gemm_bf16(None, c_void_p(0)) == -1
     from ctypes import c_float, c_int32, c_int64
     one = c_void_p(16)           # a non-null, 16-byte aligned token: validation must fail before anything dereferences it
-    # direct conv weight gradient: channel counts off its tiles (256 / 64), ragged N_res, frame range outside the grid
-    for (ca, cb, n, f0, nf) in ((100, 64, 64, 0, 2), (256, 40, 64, 0, 2), (256, 64, 60, 0, 2), (256, 64, 64, 3, 2)):
-        assert L.dfold_conv_wgrad_tn(one, one, one, c_int32(ca), c_int32(cb), c_int32(1), c_int32(8), c_int32(68), c_int32(n),
-                                     c_int32(f0), c_int32(nf), c_int32(0), c_int32(0), c_void_p(0)) == -1
+    # direct conv weight gradient: channel counts off its tiles (256 / 64), frame range outside the grid, N_res wider than the
+    # grid; with frame flags: a ragged N_res (the linear K walk has no frames), more than 64 frames, more than 8 windows
+    for (ca, cb, n, f0, nf, w, fp, nz) in ((100, 64, 64, 0, 2, 1, 8, None), (256, 40, 64, 0, 2, 1, 8, None), (256, 64, 64, 3, 2, 1, 8, None),
+                                           (256, 64, 66, 0, 2, 1, 8, None), (256, 64, 60, 0, 2, 1, 8, one), (256, 64, 64, 0, 65, 1, 72, one),
+                                           (256, 64, 64, 0, 2, 9, 8, one)):
+        assert L.dfold_conv_wgrad_tn(one, one, one, c_int32(ca), c_int32(cb), c_int32(w), c_int32(fp), c_int32(68), c_int32(n),
+                                     c_int32(f0), c_int32(nf), c_int32(0), c_int32(0), nz, c_int32(0), c_void_p(0)) == -1
+    # frame flags: a frame range outside the grid, N_res * C not a multiple of 8
+    assert L.dfold_grid_load_flags(one, one, one, one, c_int32(1), c_int32(4), c_int32(16), c_int32(8), c_int32(3), c_int32(2), c_void_p(0)) == -1
+    assert L.dfold_grid_load_flags(one, one, one, one, c_int32(1), c_int32(4), c_int32(3), c_int32(12), c_int32(0), c_int32(2), c_void_p(0)) == -1
+    # conv launches through the mode-2 row map: the two maps over different grids, M not whole windows of 256-row runs
+    d2 = _lib.GemmDesc()
+    for name in ("A", "B", "C", "zeros"):
+        setattr(d2, name, 16)
+    d2.M, d2.N, d2.nseg, d2.seglen, d2.nbatch, d2.nb1, d2.flags, d2.ldb, d2.seg_div, d2.seg_div_mid = 512, 160, 25, 64, 1, 1, 16, 1600, 5, 5
+    d2.a_rows = _lib.RowMap(0, 64, 2, 96, 4, 8, 100)
+    d2.c_rows = _lib.RowMap(0, 160, 2, 96, 4, 8, 104)
+    assert L.dfold_gemm_bf16(byref(d2), c_void_p(0)) == -1
+    d2.c_rows = _lib.RowMap(0, 160, 2, 96, 4, 8, 100)
+    d2.M = 300
+    assert L.dfold_gemm_bf16(byref(d2), c_void_p(0)) == -1
     # fused IPA backward: N_res not a multiple of 8 / above 512, key pitch not a multiple of 64
     for (n, npad) in ((20, 64), (520, 576), (64, 72)):
         assert L.dfold_ipa_fused_bwd(one, one, one, one, one, one, None, one, one, one, one, one, one, one, one, c_int32(1), c_int32(1),

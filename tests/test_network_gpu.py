@@ -196,7 +196,11 @@ def test_trunk_dead_code_elimination_equals_all_positions(monkeypatch):
     their other output frames have no consumer (reference ipa_pytorch_dynamic.py:858-873).  Against the all-positions
     evaluation, under a loss that reads EVERY frame of EVERY output key (so nothing is dead for the loss's sake): same
     outputs on all frames, same loss, same gradient for every parameter.  Without the split-K of the thin launches the conv
-    results are bit-identical; with it (default) the cone launches associate their sums differently (bf16-rounding level)."""
+    results are bit-identical; with it (default) the cone launches associate their sums differently (bf16-rounding level).
+    (Round 6: at an N_res that is not a multiple of 256 -- 16 here -- the zero-frame-flagged backward launches of an all-frames
+    application run on the 512 x 160 kernel through the mode-2 row map while the cone launches stay on the per-tap kernel, another
+    fp32 summation order: the bit-identical pass pins both to the per-tap kernel, DFOLD_CONV_LIN=0; at the benchmarked N_res 256
+    every launch is on the one kernel either way.)"""
     from dynamicpdb_amd import ops, synthetic
     dev = torch.device("cuda:0")
     F, N, B = 24, 16, 2
@@ -226,6 +230,7 @@ def test_trunk_dead_code_elimination_equals_all_positions(monkeypatch):
     try:
         for split, tol_out, tol_grad in ((False, 1e-5, 2e-3), (True, 2e-2, 0.3)):
             monkeypatch.setattr(ops, "conv_splitk", real_splitk if split else (lambda *a, **k: 1))
+            monkeypatch.setattr(ops, "_CONV_LIN", 1 if split else 0)
             full = run(False)
             dce = run(True)
             assert float(full[2]["score_model.trunk.conv_0.conv1.0.weight"].abs().max()) > 0

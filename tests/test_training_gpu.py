@@ -341,6 +341,58 @@ def test_checkpoint_resume_continues_the_run_on_device(tmp_path):
     opt.load_state_dict(checkpoint.read_checkpoint(path)["optimizer"])      # interchangeable state layout
 
 
+def test_angle_resnet_fused_node_row_block_skipping_and_unfused_chain(monkeypatch):
+    """Round 6: the angle head as one node (functional.AngleResnetFn: ReLUs, residual adds and ReLU backward in GEMM epilogues) with
+    the row-block skipping of its backward: (a) a gradient that lives on a few 256-row blocks only (what the reference's
+    last-frame loss sends) -- with the flags (default) against DFOLD_ANGLE_RZ=0: identical input gradients (skipped tiles are
+    zeros either way), weight gradients equal up to the order of the fp32 atomics; (b) a dense gradient: nothing skipped, same
+    statement; (c) against the chain of single-layer nodes of rounds 1-5 (DFOLD_ANGLE_FUSED=0): the same function up to bf16
+    rounding of the residual stream (one rounding fewer per residual add here)."""
+    from dynamicpdb_amd.model import functional as F_
+    from dynamicpdb_amd.model import ipa_pytorch_dynamic as ipa_mod
+    dev = torch.device(DEV)
+    torch.manual_seed(5)
+    m = ipa_mod.AngleResnet(1280, 1280, 2, 7, 1e-12).to(dev)
+    with torch.no_grad():
+        for l in m.layers:
+            l.linear_2.weight.normal_(0, 0.02)            # (`final` initialisation: zeros)
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    B, F, N = 2, 4, 256
+    s = torch.randn(B, F, N, 1280, device=dev).to(torch.bfloat16)
+    s0 = torch.randn(B, F, N, 1280, device=dev).to(torch.bfloat16)
+
+    def run(gu, fused=True, rz=True):
+        monkeypatch.setattr(ipa_mod, "_ANGLE_FUSED", fused)
+        monkeypatch.setattr(F_, "_ANGLE_RZ", rz)
+        m.zero_grad(set_to_none=True)
+        a, b = s.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        u, ang = m(a, b)
+        (u * gu).sum().backward()
+        return u.detach(), a.grad, b.grad, {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    sparse = torch.zeros(B, F, N, 7, 2, device=dev)
+    sparse[:, -1] = torch.randn(B, N, 7, 2, device=dev)            # the last frame of each window: 2 of 8 row blocks
+    sparse[0, 1, 17, 3, 0] = 0.3                                    # + a single element somewhere else
+    dense = torch.randn(B, F, N, 7, 2, device=dev)
+    for gu in (sparse, dense):
+        on, off = run(gu, rz=True), run(gu, rz=False)
+        assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1]) and torch.equal(on[2], off[2])
+        assert float(on[1].float().abs().max()) > 0
+        for k in on[3]:
+            assert rel_l2(on[3][k], off[3][k]) < 1e-5, k
+    # rows of untouched blocks get exactly zero input gradient
+    assert float(on[1].float().abs().max()) > 0
+    sp = run(sparse)
+    assert float(sp[1][:, 2].float().abs().max()) == 0 and float(sp[1][0, 1].float().abs().max()) > 0
+    chain = run(sparse, fused=False)
+    assert rel_l2(sp[0], chain[0]) < 1e-2
+    assert rel_l2(sp[1], chain[1]) < 3e-2 and rel_l2(sp[2], chain[2]) < 3e-2
+    for k in sp[3]:
+        assert rel_l2(sp[3][k], chain[3][k]) < 3e-2, (k, rel_l2(sp[3][k], chain[3][k]))
+
+
 def test_angle_resnet_module_vs_oracle_fwd_bwd():
     """AngleResnet (openfold/model/structure_module.py:75-158) on its own: the drop-in module on the device
     against the oracle restatement -- unnormalised and normalised angles against the plain fp32 oracle; input and

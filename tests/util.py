@@ -101,8 +101,19 @@ def record_relu_masks():
             log.append((y > 0).float().cpu())
         return y
 
+    # the fused angle head (functional.AngleResnetFn, round 6): its seven ReLU'd tensors are what it saves for its backward, in the
+    # order of the reference's ReLU calls (s, s_initial, a, h, a, h, a) -- read from the node's save list as the forward returns
+    angle_fwd = F_.AngleResnetFn.forward
+
+    def angle_forward(ctx, *a):
+        out = angle_fwd(ctx, *a)
+        log.extend((t > 0).float().cpu() for t in ctx.to_save[:7])
+        return out
+
     ops.ConvTower.forward, ipa_mod._relu, F_.linear = tower_forward, relu_logged, linear_logged
+    F_.AngleResnetFn.forward = staticmethod(angle_forward)
     try:
         yield log
     finally:
         ops.ConvTower.forward, ipa_mod._relu, F_.linear = tower_fwd, relu, linear
+        F_.AngleResnetFn.forward = staticmethod(angle_fwd)
