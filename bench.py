@@ -215,9 +215,23 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
         return rc
 
     L.dfold_conv_wgrad_tn = timed_wgrad
+    legacy = None
     try:
         trainer.update_fn(batch, step_optimizer=False)
         torch.cuda.synchronize()
+        if ops.CONV_NZ:
+            # the same step once more with the zero-frame skipping off: what rounds 1-5 quoted for the backward launches (every
+            # tile walked; the data-gradient launches then multiply the structural zeros of the gradient grids)
+            keep_ev, keep_wg = list(events), list(wg_events)
+            del events[:], wg_events[:]
+            ops.CONV_NZ = False
+            try:
+                trainer.update_fn(batch, step_optimizer=False)
+                torch.cuda.synchronize()
+            finally:
+                ops.CONV_NZ = True
+            legacy = (list(events), list(wg_events))
+            events[:], wg_events[:] = keep_ev, keep_wg
     finally:
         ops.gemm = orig
         del L.dfold_conv_wgrad_tn        # the exported function is visible again
@@ -236,6 +250,19 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
     dense = dense_conv_launches(dev, B, F, N) if os.environ.get("DFOLD_BENCH_NO_DENSE") != "1" else \
         {"forward": avg_s * 1e3, "dgrad": avg_s * 1e3, "wgrad": avg_s * 1e3}
     frac_of = lambda t_ms: round(flops / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
+    no_skip = None
+    if legacy is not None:
+        lm = max(m for _, _, m, _ in legacy[0])
+        lf = [e0.elapsed_time(e1) for e0, e1, m, fwd in legacy[0] if m == lm and fwd]
+        lb = [e0.elapsed_time(e1) for e0, e1, m, fwd in legacy[0] if m == lm and not fwd]
+        lw = [e0.elapsed_time(e1) for e0, e1, n in legacy[1] if n == nf_full]
+        avg = lambda v: sum(v) / max(1, len(v))
+        no_skip = {"what": "the same instrumented step with DFOLD_CONV_NZ=0 (every tile / reduction row walked, as rounds 1-5): full-size "
+                           "launches in the step, on the step's own operands (ReLU-sparse activations, gradients that are structurally "
+                           "zero on most frames: the power-limited kernels clock higher on them than on dense data)",
+                   "forward_ms": round(avg(lf), 4), "forward_frac": frac_of(avg(lf)), "dgrad_ms": round(avg(lb), 4),
+                   "dgrad_frac": frac_of(avg(lb)), "wgrad_ms": round(avg(lw), 4), "wgrad_frac": frac_of(avg(lw)),
+                   "launches": [len(lf), len(lb), len(lw)]}
     traffic, traffic_source = None, None
     wt, c = None, None
     if (B, F, N) == (8, 32, 256):
@@ -272,6 +299,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
                                "forward_ms": round(dense["forward"], 4), "forward_frac": frac_of(dense["forward"]),
                                "dgrad_ms": round(dense["dgrad"], 4), "dgrad_frac": frac_of(dense["dgrad"]),
                                "wgrad_ms": round(dense["wgrad"], 4), "wgrad_frac": frac_of(dense["wgrad"])},
+            "in_step_without_skipping": no_skip,
             "backward_launches": {"what": "full-size data-gradient launches of the step (same kernel, NZ instantiation): tiles whose "
                                           "input frames are zero by the frame flags skip their K walk, so a launch costs what its "
                                           "live tiles cost (DFOLD_CONV_NZ=0: every tile)",
