@@ -974,7 +974,11 @@ def main():
                 torch.cuda.empty_cache()
         if not args.no_other_configs and args.mode == "all_frames" and (B, F, N) == (8, 32, 256):
             extra("config2", lambda: other_config("BASELINE config 2", 4, 32, 128, dev, max(4, args.steps // 2), tlog))
-            extra("config5_one_gpu", lambda: other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog))
+            extra("config5_one_gpu", lambda: dict(other_config("BASELINE config 5 (per-GPU shard)", 2, 64, 512, dev, max(4, args.steps // 4), tlog),
+                                                  parity_note="the reference cannot hold a 64-frame x N_res 512 window (SURVEY 8d): parity at this "
+                                                              "shape is the reference's own run at 8 frames x N_res 512 (golden) plus SELF-consistency "
+                                                              "at 64 frames (the two step modes agree, cosine > 0.9999: tests/test_parity_baseline_gpu.py"
+                                                              "::test_step_vs_reference_golden_config5_nres512)"))
         if not args.no_triangle:
             extra("triangle", lambda: triangle_roofline(dev))
         if not args.no_eval_config:

@@ -11,10 +11,13 @@
  * Conventions
  *   - plain pointers + sizes only; every pointer is a DEVICE pointer owned by the caller (incl. all
  *     workspace); nothing is allocated, freed or synchronised inside the library -- with one exception:
- *     dfold_gemm_bf16 with splitk != 1 on a 5x5 conv launch keeps ONE fine-grained (L2-uncached,
- *     hipDeviceMallocFinegrained) buffer per device for the partial tiles that travel between XCDs,
- *     allocated on first use and grown (with a device synchronise) when a launch needs more, never
- *     above 336 MB; if that allocation fails the caller's splitk_ws is used with device-wide fences.
+ *     dfold_gemm_bf16 with splitk != 1 on a 5x5 conv launch keeps a fine-grained (L2-uncached,
+ *     hipDeviceMallocFinegrained) buffer per (device, stream) for the partial tiles that travel between XCDs
+ *     (launches in flight on two streams never share slots; the table is guarded by a mutex), allocated on
+ *     first use and grown -- with a synchronise of THAT stream -- when a launch needs more; never inside a
+ *     graph capture.  If that is not possible (capture, allocation failure, more than 64 streams) the caller's
+ *     splitk_ws is used with device-wide fences.  The hand-over through that buffer relies on gfx950 not
+ *     caching fine-grained memory in the L2s / vector L1 (each slot is read once per launch); no other target.
  *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous and stream-ordered.
  *   - return 0 on success, DFOLD_EINVAL (-1) for a rejected argument, DFOLD_ELAUNCH (-2) if the
  *     launch failed.  The Python layer maps non-zero to ValueError / RuntimeError.
