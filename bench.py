@@ -219,7 +219,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
     try:
         trainer.update_fn(batch, step_optimizer=False)
         torch.cuda.synchronize()
-        if ops.CONV_NZ:
+        if ops.CONV_NZ and os.environ.get("DFOLD_BENCH_NO_DENSE") != "1":      # (not under the kernel-trace profiler: see below)
             # the same step once more with the zero-frame skipping off: what rounds 1-5 quoted for the backward launches (every
             # tile walked; the data-gradient launches then multiply the structural zeros of the gradient grids)
             keep_ev, keep_wg = list(events), list(wg_events)

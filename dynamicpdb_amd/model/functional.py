@@ -405,6 +405,7 @@ def _zT(z2d):
 _IPA_FUSED = os.environ.get("DFOLD_IPA_FUSED", "1") != "0"     # A/B switch: "0" = the unfused round-2 chain
 _IPA_BWD_FUSED = os.environ.get("DFOLD_IPA_BWD_FUSED", "1") != "0"   # "0": the product / VALU row pass chain instead of csrc/ipa_fused_bwd.hip
 _PAIR_PROJ_FUSED = os.environ.get("DFOLD_PAIR_PROJ_FUSED", "1") != "0"   # "0": linear_b / down_z as three GEMM launches (A/B runs)
+_IPA_PAIR_STREAM = os.environ.get("DFOLD_IPA_PAIR_STREAM", "1") != "0"   # "0": the pair-value products as batched GEMMs (rounds 1-5)
 _IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
 _IPA_WS = {}
 
@@ -526,7 +527,17 @@ class IpaCoreFn(Function):
             check(L.dfold_ipa_opt_fwd(_p(P), _p(v_pts), _p(o_pt), c_int32(B), c_int32(F), c_int32(N), c_int32(H), stream()),
                   "dfold_ipa_opt_fwd")
         # o_pair[b,f,i,h,:] = sum_j P[b,f,h,i,j] pz[b,i,j,:] + b_dz   (:498-502): per (b,i) a [F*H, N] x [N, PZ] product
-        if direct:
+        stream_pair = _IPA_PAIR_STREAM and PZ == 32 and N % 16 == 0
+        if stream_pair:
+            # streaming kernel (csrc/ipa_pair.hip, round 6): one workgroup per (b, i), fragments straight from global memory
+            if direct:
+                o_pair, dst, ldo, co = feats[..., HC + 384:HC + 384 + H * PZ], feats, feat_ld, HC + 384
+            else:
+                o_pair = torch.empty((B, F, N, H * PZ), dtype=BF16, device=dev)
+                dst, ldo, co = o_pair, H * PZ, 0
+            check(L.dfold_ipa_pair_value_fwd(_p(Pb), _p(pzT), _p(b_dz.detach().float().contiguous()), _p(dst), c_int32(B), c_int32(F),
+                                             c_int32(N), c_int32(H), c_int64(ldo), c_int64(co), stream()), "dfold_ipa_pair_value_fwd")
+        elif direct:
             # the same product written into columns [HC + 384, HC + 384 + H PZ) of the feature matrix: row (f, h) of batch
             # (b, i) lands at ((b F + f) N + i) feat_ld + h PZ -- the grid row map with a "padded width" of N feat_ld / PZ cells
             o_pair = feats[..., HC + 384:HC + 384 + H * PZ]
@@ -630,8 +641,12 @@ class IpaCoreFn(Function):
         NPv = (N + 63) // 64 * 64
         ctr = ctx.ctr if ctx.ctr is not None else _ipa_centre(k_pts)
         dPp = torch.empty((B, F, H, N, N), dtype=BF16, device=dev)
-        gemm(do_pair, pz, dPp, F * H, N, PZ, a_rows=rows_grid(PZ, H, F, F, N * H), c_rows=rows_plain(NN), ldb=PZ,
-             nbatch=B * N, nb1=N, sa=(F * N * H * PZ, H * PZ), sb=(NN * PZ, N * PZ), sc=(F * H * NN, N))
+        if _IPA_PAIR_STREAM and PZ == 32 and N % 4 == 0:
+            check(L.dfold_ipa_pair_value_bwd(_p(do_pair), _p(pz), _p(dPp), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                             c_int64(H * PZ), stream()), "dfold_ipa_pair_value_bwd")
+        else:
+            gemm(do_pair, pz, dPp, F * H, N, PZ, a_rows=rows_grid(PZ, H, F, F, N * H), c_rows=rows_plain(NN), ldb=PZ,
+                 nbatch=B * N, nb1=N, sa=(F * N * H * PZ, H * PZ), sb=(NN * PZ, N * PZ), sc=(F * H * NN, N))
         DOP = ws.get("DOP/%d" % N, (B * F, H, N, 224))
         VP = ws.get("VP/%d" % N, (B * F, H, N, 224))
         KT = ws.get("KT/%d" % N, (B * F, H, 352, NPv))       # zero-filled once: pad rows / columns are never written

@@ -227,6 +227,15 @@ int dfold_ipa_points_bwd(const float* raw_q, const float* raw_kv, const float* t
  * w_b bf16 [8][128], w_dz bf16 [32][128] -> bias_t fp32 [B][8][N][N], pz bf16 [B][N][N][32], pzT bf16 [B][N][32][N].  N % 8 == 0. */
 int dfold_ipa_pair_proj(const void* z_bf16, const void* w_b_bf16, const void* w_dz_bf16, float* bias_t, void* pz_bf16, void* pzT_bf16,
                         int32_t B, int32_t N, void* stream);
+/* Pair-value side of the IPA attention as streaming kernels (round 6; ipa_pytorch_dynamic.py:498-502 and its autograd), one
+ * workgroup per (window, query residue), every MFMA fragment a 16-byte global load, no transposed copies:
+ *   fwd: out[((b F + f) N + i) ld + c_off + h 32 + c] = sum_j P[b][f][h][i][j] pzT[b][i][c][j] + b_dz[c]   (bf16; N % 16 == 0)
+ *   bwd: dP[b][f][h][i][j] = sum_c do_pair[((b F + f) N + i) ld_dop + h 32 + c] pz[b][i][j][c]              (bf16; N % 4 == 0)
+ * P, dP bf16 [B][F][H][N][N]; pz bf16 [B][N][N][32], pzT bf16 [B][N][32][N] (dfold_ipa_pair_proj); b_dz fp32 [32]. */
+int dfold_ipa_pair_value_fwd(const void* P_bf16, const void* pzT_bf16, const float* b_dz, void* out_bf16, int32_t B, int32_t F,
+                             int32_t N, int32_t H, int64_t ld, int64_t c_off, void* stream);
+int dfold_ipa_pair_value_bwd(const void* do_pair_bf16, const void* pz_bf16, void* dP_bf16, int32_t B, int32_t F, int32_t N, int32_t H,
+                             int64_t ld_dop, void* stream);
 /* o_pt [P][8][12][3] global frame -> geo_l / geo_g bf16 [P][384] = [x|y|z|norm] of R^T(o_pt - t) and of o_pt (:470-488,504);
  * ld: row stride of geo_l / geo_g in elements (384, or the row of the concatenated feature matrix they are columns of) */
 int dfold_ipa_outfeat_fwd(const float* o_pt, const float* t7, void* geo_l, void* geo_g, int64_t ld, int64_t P, float eps,

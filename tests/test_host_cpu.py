@@ -354,7 +354,8 @@ def test_data_parallel_gradient_average_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    from util import free_port
+    port = free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -439,3 +439,37 @@ def test_ipa_fused_backward_protein_scale_coordinates(B, F, N, monkeypatch):
     for n in names:
         assert errs[n] < tol[n], (n, errs[n])
         assert torch.isfinite(grads[True][names.index(n)]).all(), n
+
+
+@pytest.mark.parametrize("B,F,N,H", [(2, 32, 256, 8), (1, 3, 48, 8), (2, 5, 96, 8), (1, 40, 64, 8), (1, 2, 40, 8)])
+def test_pair_value_streaming_kernels_vs_fp64(B, F, N, H):
+    """Round 6, csrc/ipa_pair.hip: o_pair = P pz + b_dz (ipa_pytorch_dynamic.py:498-502) and the pair-value term of dL/dP as
+    streaming kernels (one workgroup per (window, query residue), MFMA fragments straight from global memory) against fp64 sums
+    on the same bf16 operands -- F H below / above / not a multiple of the 256-row workgroup, N_res 40 (backward only: the forward
+    needs N_res % 16 == 0 and falls back to the batched GEMM), output written into a wider feature matrix at a column offset."""
+    from ctypes import c_int32, c_int64
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd.ops import _p
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(N + F)
+    bf = torch.bfloat16
+    P = torch.softmax(torch.randn(B, F, H, N, N, generator=gen) * 2, -1).to(bf).to(dev)
+    pz = torch.randn(B, N, N, 32, generator=gen).to(bf).to(dev)
+    pzT = pz.transpose(2, 3).contiguous()
+    b_dz = torch.randn(32, generator=gen).to(dev)
+    L = _lib.lib()
+    if N % 16 == 0:
+        ld, co = H * 32 + 64, 24
+        out = torch.full((B, F, N, ld), 7.0, dtype=bf, device=dev)
+        _lib.check(L.dfold_ipa_pair_value_fwd(_p(P), _p(pzT), _p(b_dz), _p(out), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
+                                              c_int64(ld), c_int64(co), _lib.stream()), "fwd")
+        want = torch.einsum("bfhij,bijc->bfihc", P.double(), pz.double()) + b_dz.double()
+        got = out[..., co:co + H * 32].reshape(B, F, N, H, 32)
+        assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
+        assert float((out[..., :co].float() - 7).abs().max()) == 0 and float((out[..., co + H * 32:].float() - 7).abs().max()) == 0
+    dop = torch.randn(B, F, N, H * 32, generator=gen).to(bf).to(dev)
+    dP = torch.full((B, F, H, N, N), 3.0, dtype=bf, device=dev)
+    _lib.check(L.dfold_ipa_pair_value_bwd(_p(dop), _p(pz), _p(dP), c_int32(B), c_int32(F), c_int32(N), c_int32(H), c_int64(H * 32),
+                                          _lib.stream()), "bwd")
+    want = torch.einsum("bfihc,bijc->bfhij", dop.view(B, F, N, H, 32).double(), pz.double())
+    assert rel_l2(dP, want) < 3e-3, rel_l2(dP, want)

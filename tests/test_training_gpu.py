@@ -609,7 +609,8 @@ def test_data_parallel_real_model_two_ranks_on_one_gpu():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 2000
+    from util import free_port
+    port = free_port()
     procs = [ctx.Process(target=_dp_real_model_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -117,3 +117,12 @@ def record_relu_masks():
     finally:
         ops.ConvTower.forward, ipa_mod._relu, F_.linear = tower_fwd, relu, linear
         F_.AngleResnetFn.forward = staticmethod(angle_fwd)
+
+
+def free_port():
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests: a pid-derived port can collide with a socket
+    an earlier test of the same session left in TIME_WAIT / a store that is still being torn down)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
