@@ -406,6 +406,7 @@ _IPA_FUSED = os.environ.get("DFOLD_IPA_FUSED", "1") != "0"     # A/B switch: "0"
 _IPA_BWD_FUSED = os.environ.get("DFOLD_IPA_BWD_FUSED", "1") != "0"   # "0": the product / VALU row pass chain instead of csrc/ipa_fused_bwd.hip
 _PAIR_PROJ_FUSED = os.environ.get("DFOLD_PAIR_PROJ_FUSED", "1") != "0"   # "0": linear_b / down_z as three GEMM launches (A/B runs)
 _IPA_PAIR_STREAM = os.environ.get("DFOLD_IPA_PAIR_STREAM", "1") != "0"   # "0": the pair-value products as batched GEMMs (rounds 1-5)
+_IPA_PAIR_TN = os.environ.get("DFOLD_IPA_PAIR_TN", "1") != "0"       # "0": dz's pair product through two transposed copies (rounds 1-5)
 _IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
 _IPA_WS = {}
 
@@ -677,17 +678,24 @@ class IpaCoreFn(Function):
         B, F, N, H, C, CZ, PZ = ctx.dims
         NN, dev = N * N, q.device
         FH = F * H
-        PbT2 = ops.transpose_bf16(Pb, FH, N, ld_src=NN, nbatch=B * N, nb1=N, bs_src=(FH * NN, N))       # [B,N(i),N(j),FH]
         dop = do_pair.view(B, F, N, H, PZ).permute(0, 2, 1, 3, 4).contiguous()                          # [B,N,F,H,PZ]
-        dopT = ops.transpose_bf16(dop, FH, PZ, nbatch=B * N, nb1=1, bs_src=(FH * PZ, 0))                 # [B,N,PZ,FH]
         # dz = dpz W_dz + dbias W_b as ONE product: dpz (PZ columns) and the bias gradient (8 columns) are written side by
         # side into the [B*N*N, PZ + 8] operand and meet the concatenated transposed weights -- one bf16 pass over dz instead
         # of an fp32 product, an accumulating K = 8 product (268 MB read + written for 0.1 GFLOP) and a cast
         KZ = PZ + 8
         dpzb = torch.empty((B * NN, KZ), dtype=BF16, device=dev)
-        gemm(PbT2, dopT, dpzb, N, PZ, FH, a_rows=rows_plain(FH), c_rows=rows_plain(KZ), ldb=FH, nbatch=B * N, nb1=1,
-             sa=(N * FH, 0), sb=(PZ * FH, 0), sc=(N * KZ, 0))
-        del PbT2, dopT
+        if _IPA_PAIR_TN and FH % 64 == 0 and N % 8 == 0 and ops.gemm_tn_ok(N, PZ, FH, ragged=True):
+            # dpz[b,i,j,c] = sum_(f,h) P[b,f,h,i,j] do_pair[b,f,i,h,c]: the reduction index (f, h) is the slow axis of BOTH operands as
+            # they lie (rows of P are N^2 apart, rows of the regrouped do_pair 32 apart): the reduction-major product reads them in
+            # place (round 6; before: a 134 MB transposed copy of the probabilities + one of do_pair per block)
+            ops.gemm_tn(Pb, dop, dpzb, N, PZ, FH, NN, PZ, KZ, nbatch=B * N, nb1=N, sa=(FH * NN, N), sb=(N * FH * PZ, FH * PZ),
+                        sc=(N * N * KZ, N * KZ))
+        else:
+            PbT2 = ops.transpose_bf16(Pb, FH, N, ld_src=NN, nbatch=B * N, nb1=N, bs_src=(FH * NN, N))       # [B,N(i),N(j),FH]
+            dopT = ops.transpose_bf16(dop, FH, PZ, nbatch=B * N, nb1=1, bs_src=(FH * PZ, 0))                 # [B,N,PZ,FH]
+            gemm(PbT2, dopT, dpzb, N, PZ, FH, a_rows=rows_plain(FH), c_rows=rows_plain(KZ), ldb=FH, nbatch=B * N, nb1=1,
+                 sa=(N * FH, 0), sb=(PZ * FH, 0), sc=(N * KZ, 0))
+            del PbT2, dopT
         db_hn = torch.empty((B, H, NN), dtype=BF16, device=dev)
         check(L.dfold_ipa_bias_grad(_p(dS), _p(db_hn), _p(dpzb, PZ), c_int64(KZ), c_int32(B), c_int32(F), c_int32(N), c_int32(H),
                                     ctypes_float(math.sqrt(1.0 / 3)), stream()), "dfold_ipa_bias_grad")
