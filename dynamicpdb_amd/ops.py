@@ -51,6 +51,13 @@ def grid_slack(Wp, C):
     return (4 * Wp + 288) * C
 
 
+def has_grid_slack(g, t):
+    """does the padded grid tensor t own grid_slack() elements of storage behind its last window?"""
+    C = t.shape[-1]
+    behind = t.untyped_storage().nbytes() // t.element_size() - (t.storage_offset() + g.Wn * g.Fp * g.Wp * C)
+    return behind >= grid_slack(g.Wp, C)
+
+
 def seg_table(values, device):
     key = (tuple(values), device)
     t = _seg_tables.get(key)
@@ -165,16 +172,11 @@ def row_block_flags(g2d, block=256):
     R, C = g2d.shape
     nb = (R + block - 1) // block
     ps = torch.empty(nb + 1, dtype=torch.int32, device=g2d.device)
-    key = (g2d.device, nb)
-    scratch = _rz_scratch.get(key)
-    if scratch is None:
-        scratch = _rz_scratch[key] = torch.zeros(nb, dtype=torch.int32, device=g2d.device)
+    scratch = torch.zeros(nb, dtype=torch.int32, device=g2d.device)      # (per call: callers on different streams share nothing)
     check(_lib.lib().dfold_row_block_flags(_p(g2d), _p(ps), _p(scratch), c_int64(R), c_int32(C), c_int64(g2d.stride(0)), c_int32(block),
                                            stream()), "dfold_row_block_flags")
     return ps
 
-
-_rz_scratch = {}
 
 
 def cast_bf16(x):
@@ -420,6 +422,10 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
     # mode 2) so that the 512 x 160 one-wave-per-SIMD kernel takes the launch -- 256-row runs of consecutive cells, pad columns
     # computed and not stored ((N + 4) / N of the FLOPs).  DFOLD_CONV_LIN=0: the per-tap 256 x 320 kernel of rounds 2-5.
     lin = _CONV_LIN and g.N % 256 != 0 and CO % 160 == 0 and ck == 64 and out.dtype == BF16 and x.dtype == BF16
+    if lin:
+        # the launch reads up to grid_slack() elements behind the last window (rows that are never stored): only tensors that
+        # own that much storage behind them take this path (Grid.alloc / Workspace.get provide it; a bare torch tensor does not)
+        lin = has_grid_slack(g, x)
     if lin and _CONV_LIN == 1:
         lin = conv_lin_wins(g.Wn, nf, g.N, CO, cu_count(x.device), nz is not None)
     if lin:
@@ -536,7 +542,7 @@ def conv5x5_wgrad(g, x, gy, dwg, ws, accumulate=True, bias_grad=None, f_lo=0, nf
     bias_grad (fp32 [CO], accumulated): the conv bias gradient, summed while gy is transposed (no extra pass).
     f_lo / nf: gy is zero outside frames [f_lo, f_lo + nf): only those cells enter the reduction."""
     CI, CO = x.shape[-1], gy.shape[-1]
-    if (_WGRAD_TN if tn is None else tn) and wgrad_tn_ok(g, CI, CO):
+    if (_WGRAD_TN if tn is None else tn) and wgrad_tn_ok(g, CI, CO) and (g.N % 64 == 0 or (has_grid_slack(g, x) and has_grid_slack(g, gy))):
         return conv5x5_wgrad_tn(g, x, gy, dwg, accumulate, bias_grad, f_lo, nf, nz)
     plane, N = g.plane, g.NP        # N: K-run length of one frame row in the transposed copies
     tag = "" if g.N == g.NP else "_n%d" % g.N   # ragged N: own scratch (its pad columns must never have been written)

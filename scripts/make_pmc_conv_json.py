@@ -20,13 +20,20 @@ def entry(key, name):
 
 
 try:
-    out = entry("dfold_conv_w4_kernel", "dfold_conv_w4_kernel (one wave per SIMD, 512 x 160 tile)")
+    try:        # round 6: the plain instantiation = the forward launches (the NZ instantiation skips tiles)
+        out = entry("dfold_conv_w4_kernel<false, false>", "dfold_conv_w4_kernel<false, false> (one wave per SIMD, 512 x 160 tile; forward launches)")
+        out["nz_instantiation"] = entry("dfold_conv_w4_kernel<false, true>", "dfold_conv_w4_kernel<false, true> (data-gradient launches with zero-frame flags)")
+    except StopIteration:
+        out = entry("dfold_conv_w4_kernel", "dfold_conv_w4_kernel (one wave per SIMD, 512 x 160 tile)")
 except StopIteration:      # passes taken with DFOLD_CONV_W4=0 / before round 5
     out = entry("dfold_mfma_gemm320_kernel<1, 5, true>", "dfold_mfma_gemm320_kernel<1, 5, true> (halo form)")
 out["note"] = ("rocprofv3 --pmc, two passes (FETCH_SIZE TCC_HIT_sum | WRITE_SIZE TCC_MISS_sum TCC_REQ_sum; scripts/gpu_pmc.sh -> "
                f"profiles/{tag}_pmc_fetch_hit.txt, {tag}_pmc_write_miss_req.txt), averages per launch over the conv forward+dgrad launches of "
                "the all-frames update_fn steps of the pass at BASELINE config 3; FETCH_SIZE is doubled when converted to bytes (gfx950 "
                "wide-coalesced-read correction, MI355X_MICROARCH.md section HBM); WRITE_SIZE is uncalibrated")
-out["wgrad_tn"] = entry("conv_wgrad_tn_kernel", "conv_wgrad_tn_kernel")
+try:
+    out["wgrad_tn"] = entry("conv_wgrad_tn_kernel<false>", "conv_wgrad_tn_kernel<false>")
+except StopIteration:
+    out["wgrad_tn"] = entry("conv_wgrad_tn_kernel", "conv_wgrad_tn_kernel")
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_conv.json"), "w"), indent=1)
 print(json.dumps(out)[:600])
