@@ -188,10 +188,11 @@ def _use_fused():
 
 
 def _use_row_kernel():
-    """triangle attention with q|k|v|g kept on chip: "1" (default) the whole-row kernel at N_res <= 256
-    (csrc/triatt_fused.hip) and the query-block kernel above (csrc/triatt_rows.hip, any N_res), "2" the query-block kernel
-    at every N_res, "0" the two-kernel form of csrc/pair_fused.hip (q|k|v|g through HBM)"""
-    return os.environ.get("DFOLD_TRIATT_ROW", "1")
+    """triangle attention with q|k|v|g kept on chip: "3" (default since round 6) the register-resident kernel
+    (csrc/triatt_reg.hip) at N_res <= 512 and the query-block kernel (csrc/triatt_rows.hip, any N_res) above, "1" the whole-row
+    kernel at N_res <= 256 (csrc/triatt_fused.hip) and the query-block kernel above, "2" the query-block kernel at every N_res,
+    "0" the two-kernel form of csrc/pair_fused.hip (q|k|v|g through HBM)"""
+    return os.environ.get("DFOLD_TRIATT_ROW", "3")
 
 
 _TRIATT_DBG = None      # tests: fp32 [4][N][32] device tensor receiving q|k|v|gate of head 0, row 0, item 0
@@ -684,8 +685,9 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
         xc = xc.float()
     maskf = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.contiguous().float()
     mode = _use_row_kernel()
-    row_kernel = N <= 256 and mode == "1"
-    rows_kernel = mode == "2" or (mode == "1" and N > 256)
+    reg_kernel = mode == "3" and N <= 512
+    row_kernel = (N <= 256 and mode == "1") or reg_kernel
+    rows_kernel = mode == "2" or (mode in ("1", "3") and N > 256 and not reg_kernel)
     ending = 0 if starting else 1
     st = stream()
     out = torch.empty((B, N, N, 128), dtype=xc.dtype, device=dev)
@@ -711,10 +713,12 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
         check(L.dfold_triatt_bias_blocked(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(w_tri), _p(tri),
                                           c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), st),
               "dfold_triatt_bias_blocked")
-        check(L.dfold_triatt_fused_fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat),
-                                       _p(bcat), _p(tri), _p(wo), _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0),
-                                       _p(_TRIATT_DBG), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf),
-                                       ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), st), "dfold_triatt_fused_fwd")
+        fwd = L.dfold_triatt_reg_fwd if reg_kernel else L.dfold_triatt_fused_fwd
+        check(fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat),
+                  _p(bcat), _p(tri), _p(wo), _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0),
+                  _p(_TRIATT_DBG), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf),
+                  ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), st),
+              "dfold_triatt_reg_fwd" if reg_kernel else "dfold_triatt_fused_fwd")
         return out, xc, maskf
     q = _ws_get(ws, "q", (B, N, N, 128), BF16, dev)
     k = _ws_get(ws, "k", (B, N, N, 128), BF16, dev)

@@ -150,6 +150,25 @@ def _stages_att(m, x, mask, reps):
                  bytes=cells * (2 * 128 * es + 4) + B * N * 4 * NP * NP * 4,        # x, out, mask + the bias re-read per row (L2)
                  flop=2.0 * cells * 128 * 512 + 4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
         ]
+    if N <= 512:        # the register-resident form (csrc/triatt_reg.hip, round 6): the same bias pass + one workgroup per (item, row)
+        tribr = torch.empty((B, 4, NP, NP), dtype=torch.float32, device=dev)
+
+        def g0():
+            check(L.dfold_triatt_bias_blocked(_p(x), c_int32(xb), _p(g), _p(b), _p(wt), _p(tribr), c_int32(B), c_int32(N), c_int32(NP),
+                                              c_int32(ending), ctypes_float(1e-5), stream()), "bias")
+
+        def g1():
+            check(L.dfold_triatt_reg_fwd(_p(x), c_int32(xb), _p(mask), _p(g), _p(b), _p(wcat), _p(bcat), _p(tribr), _p(wo), _p(bo),
+                                         _p(out), c_int32(xb), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending),
+                                         ctypes_float(1e9), ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), stream()), "reg")
+        g0()
+        rows += [
+            dict(stage="register form: triangle-bias pass (LN + 4-wide projection)", s=_time(g0, reps), bytes=cells * (128 * es + 16),
+                 flop=2.0 * cells * 128 * 4),
+            dict(stage="register form: LN+q|k|v|g+attention+gate+linear_o per row", s=_time(g1, reps),
+                 bytes=cells * (2 * 128 * es + 4) + B * N * 4 * NP * NP * 4,        # x, out, mask + the bias re-read per row (L2)
+                 flop=2.0 * cells * 128 * 512 + 4.0 * B * N * N * N * 128 + 2.0 * cells * 128 * 128),
+        ]
     # the query-block form (csrc/triatt_rows.hip, any N_res): LN + bias pass that also writes xn, then one workgroup per
     # (item, row, 256 queries)
     xn = torch.empty((B, N, N, 128), dtype=BF16, device=dev)

@@ -445,6 +445,58 @@ def test_triatt_row_kernel_stages_and_output(N, ending, monkeypatch):
     assert rel_l2(y, ref) < 1.5e-2 and rel_l2(yb.float(), ref) < 2.5e-2, (rel_l2(y, ref), rel_l2(yb.float(), ref))
 
 
+@pytest.mark.parametrize("N,ending", [(256, 0), (256, 1), (200, 1), (27, 0), (128, 1), (100, 0), (384, 0), (300, 1), (512, 0), (512, 1),
+                                      (450, 0)])
+def test_triatt_register_kernel_stages_and_output(N, ending, monkeypatch):
+    """csrc/triatt_reg.hip (round 6: LayerNorm output and every projection of a wave's 64 cells in registers, K / V^T
+    double-buffered in LDS, online softmax over 128-key chunks; N_res <= 512, workgroups of 2 / 4 / 6 / 8 waves): (a) the
+    q | k | v | sigmoid(g) tiles of head 0 of row 0 against fp32 torch math on the same LayerNorm output (debug tap), (b) the
+    whole operator against the two-kernel form and against the CPU oracle (one item above N_res 256 to bound the oracle's
+    time), per cell as well; ragged last wave / tile / chunk, masked keys, both nodes, fp32 and bf16 I/O; a batch equals its
+    items one by one bit for bit."""
+    from dynamicpdb_amd.model import triangle as T
+    dev = torch.device(DEV)
+    B = 2
+    ctor = T.TriangleAttentionEndingNode if ending else T.TriangleAttentionStartingNode
+    m = _rand_module(ctor(128, 32, 4), 95).to(dev)
+    x, mask = _inputs(B, N, 96 + N, holes=0.08)
+    x, mask = x.to(dev), mask.to(dev)
+    dbg = torch.zeros(4, N, 32, device=dev)
+    monkeypatch.setattr(T, "_TRIATT_DBG", dbg)
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "3")
+    with torch.no_grad():
+        y = m(x, mask=mask)
+        yb = m(x.to(BF16), mask=mask)
+    monkeypatch.setattr(T, "_TRIATT_DBG", None)
+    with torch.no_grad():
+        y1 = m(x[1], mask=mask[1])
+    monkeypatch.setenv("DFOLD_TRIATT_ROW", "0")
+    with torch.no_grad():
+        y2 = m(x, mask=mask)
+    assert torch.isfinite(y).all() and torch.equal(y[1], y1)
+    xr = x[0, :, 0] if ending else x[0, 0]                    # row 0 of item 0 in the operator's coordinates, [N, 128]
+    xn = _ln(xr, m.layer_norm.weight, m.layer_norm.bias).to(BF16).float()
+    mh = m.mha
+    for pj, (lin, act) in enumerate(((mh.linear_q, None), (mh.linear_k, None), (mh.linear_v, None), (mh.linear_g, torch.sigmoid))):
+        ref = xn @ lin.weight[:32].to(BF16).float().t()
+        if lin.bias is not None:
+            ref = ref + lin.bias[:32]
+        if act is not None:
+            ref = act(ref)
+        assert rel_l2(dbg[pj], ref) < 5e-3, (pj, rel_l2(dbg[pj], ref))
+    e2 = rel_l2(y, y2)
+    assert e2 < 6e-3, e2              # both round the same intermediates to bf16, in other places
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    nref = B if N <= 256 else 1
+    ref = torch.stack([_oracle("tri_att_end" if ending else "tri_att_start", P, x[b].cpu(), mask[b].cpu()) for b in range(nref)])
+    e32, e16 = rel_l2(y[:nref], ref), rel_l2(yb[:nref].float(), ref)
+    print(f"[register kernel N={N} ending={ending}] rel-L2 vs two-kernel form {e2:.2e}, vs oracle: fp32 I/O {e32:.2e}, "
+          f"bf16 I/O {e16:.2e}")
+    assert e32 < 1.5e-2 and e16 < 2.5e-2, (e32, e16)
+    d = (y[:nref].cpu() - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-3)
+    assert float(d.max()) < 0.15, float(d.max())
+
+
 @pytest.mark.parametrize("N,ending", [(512, 0), (512, 1), (256, 1), (200, 0), (27, 1), (520, 0), (264, 1)])
 def test_triatt_query_block_kernel_stages_and_output(N, ending, monkeypatch):
     """csrc/triatt_rows.hip (projections kept on chip, ANY N_res: one workgroup per (item, row, 256 queries), online softmax
