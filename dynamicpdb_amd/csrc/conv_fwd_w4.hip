@@ -86,38 +86,75 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
   bool first_piece = true;
   for (;;) {
   const int tile = SK ? u / ngroups : lid;
-  const int g_begin = SK ? u - tile * ngroups : 0;
-  const int g_end = SK ? (g_begin + (u_end - u) < ngroups ? g_begin + (u_end - u) : ngroups) : ngroups;
+  int g_begin = SK ? u - tile * ngroups : 0;
+  int g_end = SK ? (g_begin + (u_end - u) < ngroups ? g_begin + (u_end - u) : ngroups) : ngroups;
   const int m0 = (tile / tiles_n) * W4_BM, n0 = (tile % tiles_n) * W4_BN;
   bool live = true;
+  int S_eff = (int)gridDim.y;       // parts per tile of a split-K launch
   if (NZ) {
-    live = false;
     const int fp1 = p.am.fp + 1;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int m = m0 + 256 * r;
-      if (m < M) {
-        unsigned ww, ff, fl;          // window, first and last logical frame of the run's output cells
-        if (p.am.mode == 2) {
-          const unsigned vw = row_vw(p.am), v = (unsigned)m - ((unsigned)m / vw) * vw;
-          ww = (unsigned)m / vw;
-          ff = v / (unsigned)p.am.wp;
-          fl = (v + 255u) / (unsigned)p.am.wp;
-          if (ff >= (unsigned)p.am.f) continue;             // a run behind the last frame: nothing of it is stored
-          fl = fl < (unsigned)p.am.f ? fl : (unsigned)p.am.f - 1u;
-        } else {
-          const unsigned wf = (unsigned)m / (unsigned)p.am.n;
-          ww = wf / (unsigned)p.am.f;
-          ff = fl = wf - ww * (unsigned)p.am.f;
-        }
-        int a = p.nz_f0 + (int)ff - p.nz_radius, b = p.nz_f0 + (int)fl + 4 + p.nz_radius;
-        a = a < 0 ? 0 : a;
-        b = b > p.am.fp - 1 ? p.am.fp - 1 : b;
-        const int* row = p.nz_ps + (long)ww * fp1;
-        live = live || row[b + 1] - row[a] > 0;
+    // can the 256-row run that starts at GEMM row m read a non-zero?  (two loads of the window's frame prefix sums)
+    auto run_live = [&](int m) -> bool {
+      if (m >= M) return false;
+      unsigned ww, ff, fl;          // window, first and last logical frame of the run's output cells
+      if (p.am.mode == 2) {
+        const unsigned vw = row_vw(p.am), v = (unsigned)m - ((unsigned)m / vw) * vw;
+        ww = (unsigned)m / vw;
+        ff = v / (unsigned)p.am.wp;
+        fl = (v + 255u) / (unsigned)p.am.wp;
+        if (ff >= (unsigned)p.am.f) return false;          // a run behind the last frame: nothing of it is stored
+        fl = fl < (unsigned)p.am.f ? fl : (unsigned)p.am.f - 1u;
+      } else {
+        const unsigned wf = (unsigned)m / (unsigned)p.am.n;
+        ww = wf / (unsigned)p.am.f;
+        ff = fl = wf - ww * (unsigned)p.am.f;
       }
-    }
+      int a = p.nz_f0 + (int)ff - p.nz_radius, b = p.nz_f0 + (int)fl + 4 + p.nz_radius;
+      a = a < 0 ? 0 : a;
+      b = b > p.am.fp - 1 ? p.am.fp - 1 : b;
+      const int* row = p.nz_ps + (long)ww * fp1;
+      return row[b + 1] - row[a] > 0;
+    };
+    live = run_live(m0) || run_live(m0 + 256);
     if (!live && blockIdx.y != 0) return;     // (split-K: part 0 alone writes the zero tile)
+    if (!SK && p.sk_per == -1) {
+      // ---- split factor chosen on the DEVICE from the flags (round 6): the launch carries S_max parts per tile; how many of
+      // them walk K is decided here, the same way by every workgroup of a window.  The live tiles of a skipped launch run as
+      // whole rounds on the CUs (64 .. 576 live tiles of 512 / 1024: 1 .. 3 rounds for 0.25 .. 2.25 rounds of work); L live
+      // tiles x S parts spread evenly.  L is estimated from the tile rows of this workgroup's own window (all windows alike:
+      // the loss reads the same frames of each) -- a function of the data alone, so the fp32 association, too, is the same
+      // in every step that meets the same gradient pattern.  Cost model = ops.conv_splitk's.
+      const unsigned rows_w = p.am.mode == 2 ? row_vw(p.am) : (unsigned)p.am.n * (unsigned)p.am.f;
+      S_eff = 1;
+      if (rows_w % W4_BM == 0) {
+        const unsigned tpw = rows_w / W4_BM, w_first = ((unsigned)m0 / rows_w) * rows_w;
+        int cnt = 0;
+        for (unsigned j0 = 0; j0 < tpw; j0 += 64) {
+          const unsigned j = j0 + (unsigned)lane;
+          const bool lv = j < tpw && (run_live((int)(w_first + j * W4_BM)) || run_live((int)(w_first + j * W4_BM + 256)));
+          cnt += __builtin_popcountll(__ballot(lv));
+        }
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        const int L = cnt * (int)((unsigned)M / rows_w) * tiles_n, n_cu = p.sk_tiles, chunks = p.nseg / 25, steps = 25 * chunks;
+        int best_cost = ((L + n_cu - 1) / n_cu) * (steps + 16);
+        for (int S = 2; S <= (int)gridDim.y; ++S) {
+          // (measured, same-box A/B of the step: splitting pays where all parts of all live tiles run at once -- 64 live tiles
+          //  0.79 -> 0.50 ms, 128: 0.80 -> 0.64 -- and loses a few per cent beyond one round, where the parts of a tile sit at
+          //  different K positions next to each other and the weight slabs of 4 - 5 K ranges share the L2: 320 live tiles
+          //  1.00 -> 1.08 ms, 192 of the wider launch 0.83 -> 0.97)
+          if (S == 3 || chunks % S || L * S > n_cu) continue;
+          const int cost = ((L * S + n_cu - 1) / n_cu) * (steps / S + 16 + 2 * S);
+          if (10 * cost < 9 * best_cost) {
+            best_cost = cost;
+            S_eff = S;
+          }
+        }
+      }
+      if ((int)blockIdx.y >= S_eff) return;
+      const int gpp = ngroups / S_eff;
+      g_begin = (int)blockIdx.y * gpp;
+      g_end = g_begin + gpp;
+    }
   }
   // (split-K launches: part blockIdx.y walks its own range of channel chunks -- p.nseg, p.sa0, p.sb0 are per part)
   const char* A = (const char*)p.A + (long)blockIdx.y * p.sa0 * 2;
@@ -396,11 +433,11 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
         if (tid == 0) p.cnt[tile] = 0;   // counters are left clean for the next launch
       }
     }
-  } else if (p.ws != nullptr && live) {
+  } else if (p.ws != nullptr && live && S_eff > 1) {
     // Deterministic split-K, as in the 256 x 320 kernel: every part parks its fp32 partial tile in the workspace, the last part
     // to arrive adds them in the fixed order z = 0 .. S-1 and runs the epilogue.  The 512 x 160 tile has as many elements as a
     // 256 x 320 one.
-    const int S = gridDim.y;
+    const int S = S_eff;
     park(p.ws + ((long)blockIdx.y * nwg + lid) * tile_elems + lane_off);
     if (p.sk_fence) __threadfence();
     __syncthreads();
@@ -477,11 +514,26 @@ static float* w4_partials(size_t bytes, hipStream_t stream) {
   return en->ptr;
 }
 
+// splitk <= -2 (zero-frame-flagged launches only): up to -splitk parts per tile, how many of them walk K is decided on the
+// device (see the kernel); p.sk_tiles = compute units.  The partial tiles of such a launch need -splitk x tiles slots, which
+// only the library's own fine-grained buffer provides: without it the launch runs unsplit.
 int dfold_conv_w4_launch(const GemmParams& p0, int splitk, hipStream_t stream) {
   GemmParams p = p0;
   const unsigned tiles = (unsigned)(((p.M + W4_BM - 1) / W4_BM) * (p.N / W4_BN));
   p.sk_fence = 1;
-  if (splitk > 1) {
+  if (splitk <= -2) {
+    float* fine = p.nz_ps ? w4_partials((size_t)(-splitk) * tiles * W4_BM * W4_BN * sizeof(float), stream) : nullptr;
+    if (fine) {
+      p.ws = fine;
+      p.sk_fence = 0;
+      p.sk_per = -1;
+      splitk = -splitk;
+    } else {
+      p.ws = nullptr;
+      p.sk_per = 0;
+      splitk = 1;
+    }
+  } else if (splitk > 1) {
     float* fine = w4_partials((size_t)splitk * tiles * W4_BM * W4_BN * sizeof(float), stream);
     if (fine) {
       p.ws = fine;

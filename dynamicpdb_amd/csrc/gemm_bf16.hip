@@ -769,6 +769,20 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
       return dfold_conv_w4_launch_streamk(p, n_cu, (hipStream_t)stream);
     }
   }
+  // splitk <= -2: zero-frame-flagged 5x5 conv launch with a split factor chosen on the device, at most -splitk parts per tile
+  // (conv_fwd_w4.hip; round 6).  Only the one-wave-per-SIMD kernel has it: anything else is an argument error.
+  int nz_adapt = 0;
+  if (d->splitk <= -2) {
+    if (!d->nz_ps || -d->splitk > 8 || role != 1 || d->nbatch != 1 || !d->splitk_cnt || (d->nseg % 25) ||
+        (d->flags & (DFOLD_GEMM_ACCUM | DFOLD_GEMM_ATOMIC)))
+      return DFOLD_EINVAL;
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      return DFOLD_ELAUNCH;
+    nz_adapt = -d->splitk;
+    p.cnt = d->splitk_cnt;
+    p.sk_tiles = n_cu;
+  }
   if (d->splitk > 1) {
     const int chunks = d->nseg / 25;
     if (role != 1 || d->nbatch != 1 || !d->splitk_ws || !d->splitk_cnt || (d->nseg % 25) || (chunks % d->splitk) ||
@@ -789,7 +803,7 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
         (d->nseg % (25 * S)) || p.conv_F != 0 || d->a_seg_s0 != BK || d->b_seg_s0 != BK || !(d->flags & DFOLD_GEMM_OUT_BF16) ||
         ((p.cm.ld | p.cm.base) & 7) || !(a_extent < (1L << 31)) || !((long)d->N * d->ldb < (1L << 31)))
       return DFOLD_EINVAL;
-    return dfold_conv_w4_launch(p, S, (hipStream_t)stream);
+    return dfold_conv_w4_launch(p, nz_adapt ? -nz_adapt : S, (hipStream_t)stream);
   }
   if (S > 1 || (variant >= 256 && variant != 2560 && (d->N % BN3) == 0 && (d->seglen % BK) == 0 && (d->M >= 2048 || role == 2) && steps >= 4 &&
       tiles320 * d->nbatch >= 128 && a_extent < (1L << 31) && (long)d->N * d->ldb < (1L << 31))) {
@@ -824,7 +838,8 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     const long tiles_w4 = (long)((d->M + 511) / 512) * (d->N / 160);
     if (halo && w4_mode && d->nbatch == 1 && (d->N % 160) == 0 && d->a_seg_s0 == BK && d->b_seg_s0 == BK &&
         (d->flags & DFOLD_GEMM_OUT_BF16) && ((p.cm.ld | p.cm.base) & 7) == 0 && (S == 1 || tiles_w4 <= tiles320 || w4_mode == 2 || lin))
-      return dfold_conv_w4_launch(p, S, (hipStream_t)stream);
+      return dfold_conv_w4_launch(p, nz_adapt ? -nz_adapt : S, (hipStream_t)stream);
+    // (a flagged launch that does not qualify for the kernel that can choose its split runs unsplit below: performance only)
 
     if (halo)
       DFOLD_LAUNCH((dfold_mfma_gemm320_kernel<1, 5, true>), grid3, dim3(512), (size_t)HALO_LDS, (hipStream_t)stream, p);

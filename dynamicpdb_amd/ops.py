@@ -97,7 +97,7 @@ def gemm(A, B, C, M, N, seglen, *, a_rows, c_rows, ldb, nseg=1, bias=None, R=Non
     d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
     d.M, d.N, d.nseg, d.seglen, d.nbatch, d.nb1, d.flags, d.alpha = M, N, nseg, seglen, nbatch, nb1, flags, alpha
     d.splitk, d.conv_frames = splitk, conv_frames
-    split = splitk > 1 or splitk == -1
+    split = splitk > 1 or splitk <= -1
     d.splitk_ws, d.splitk_cnt = _p(splitk_ws if split else None), _p(splitk_cnt if split else None)
     if nz is not None:           # (frame-flag prefix sums, radius, padded frame row of logical frame 0): dfold_gemm_desc.nz_ps
         d.nz_ps, d.nz_radius, d.nz_f0 = _p(nz[0]), nz[1], nz[2]
@@ -378,6 +378,20 @@ def conv_lin_wins(Wn, nf, N, CO, n_cu, nz=False):
 
 
 _TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_fwd: whole rounds unsplit + the remainder's frames split
+# zero-frame-flagged launches: up to this many split-K parts per tile, the number that walks K is chosen on the device from the
+# flags (conv_fwd_w4.hip; 0 / DFOLD_CONV_SPLITK=0: never split, bit-identical with the unflagged launch)
+_NZ_SPLIT = int(os.environ.get("DFOLD_CONV_NZ_SPLIT", "5"))
+
+
+def nz_split_parts(CI):
+    """parts per tile a zero-frame-flagged conv launch carries (0: none): the largest of 5, 4, 2 that divides the 64-channel
+    chunks and is allowed by DFOLD_CONV_NZ_SPLIT"""
+    if _NZ_SPLIT < 2 or CI % 64 or os.environ.get("DFOLD_CONV_SPLITK", "1") == "0":
+        return 0
+    for S in (5, 4, 2):
+        if S <= _NZ_SPLIT and (CI // 64) % S == 0:
+            return S
+    return 0
 
 
 def conv_tail_frames(nf, tiles_per_frame, n_cu):
@@ -437,6 +451,9 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
             if S != 1:
                 sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
                           splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
+            elif nz is not None and nz_split_parts(CI) and tiles <= _SPLITK_CAP * cu_count(x.device):
+                sk = dict(splitk=-nz_split_parts(CI), splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
+                          splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
         return gemm(x, wf, out, Ml, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in_lin(CI, f_lo, nf),
                     c_rows=g.rows_center_lin(CO, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2,
                     a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI), seg_div=5, seg_div_mid=5, flags=flags,
@@ -461,6 +478,11 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
             S = 1                     # (the launch would not take the kernel that has the stream-K form)
         if S > 1 or S == -1:
             sk = dict(splitk=S, splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
+                      splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
+        elif (nz is not None and nz_split_parts(CI) and g.N % 256 == 0 and M % 512 == 0 and CO % 160 == 0 and ck == 64 and out.dtype == BF16
+              and (M // 512) * (CO // 160) <= _SPLITK_CAP * cu_count(x.device) and not _SKIP_PAD_TAPS):
+            # a flagged launch on the 512 x 160 kernel: the device decides how many parts per live tile walk K (nz_split_parts)
+            sk = dict(splitk=-nz_split_parts(CI), splitk_ws=ws.get("splitk_ws", (_SPLITK_CAP * cu_count(x.device) * 256 * 320,), torch.float32),
                       splitk_cnt=ws.get("splitk_cnt", (_SPLITK_CAP * cu_count(x.device),), torch.int32))
     return gemm(x, wf, out, M, CO, ck, nseg=25 * (CI // ck), a_rows=g.rows_in(CI, f_lo, nf),
                 c_rows=g.rows_center(CO, 0, f_lo, nf), ldb=25 * CI, **sk, bias=bias, R=R, C2=C2, R2=R2, a_seg=g.tap_offsets(CI, ck), b_seg=(0, ck, 5 * CI, CI),

@@ -343,7 +343,7 @@ def test_conv_splitk_matches_unsplit(dev):
 
 
 @pytest.mark.parametrize("Wn,dense", [(8, False), (9, False), (8, True)])
-def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense):
+def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense, monkeypatch):
     """Round 6: the tower's backward with the frame flags of the incoming gradient (dfold_grid_load_flags -> nz_ps / radius on
     every data- and weight-gradient launch) against the same backward without them: bit-identical data gradient, weight and
     bias gradients -- the tiles / reduction rows left out are exact zeros.  Sparse case: a gradient that lives on a few frames
@@ -351,6 +351,7 @@ def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense):
     nothing changes.  9 windows: the weight-gradient kernel takes 8 windows per call.  Also: the flags are what the gradient
     says, and a launch handed all-zero flags computes nothing (the kernels do honour them)."""
     from dynamicpdb_amd import ops
+    monkeypatch.setattr(ops, "_NZ_SPLIT", 0)      # (the device-chosen split of the flagged launches has its own test below)
     F, N, C = 8, 256, 1280
     gen = torch.Generator(device="cpu").manual_seed(11)
     ws = [(torch.randn(co, ci, 5, 5, generator=gen) * (2.0 / (25 * ci)) ** 0.5).to(dev)
@@ -416,6 +417,50 @@ def test_conv_zero_frame_skipping_bit_identical(dev, Wn, dense):
     assert float(dw.abs().max()) == 0
     ops.conv5x5_wgrad_tn(g, saved[10], gt, dw, accumulate=False)
     assert float(dw.abs().max()) > 0
+
+
+@pytest.mark.parametrize("live", [(31,), (28, 29, 30, 31), tuple(range(12, 32)), tuple(range(32))])
+def test_conv_flagged_launch_with_device_chosen_split(dev, live, monkeypatch):
+    """Round 6: a zero-frame-flagged data-gradient launch on the 512 x 160 kernel carries up to five split-K parts per tile and
+    decides ON THE DEVICE, from the flags, how many of them walk K (conv_fwd_w4.hip: the live tiles of a skipped launch otherwise
+    run as whole rounds on 256 CUs).  At the benchmarked grid (8 x 32 x 256, both channel directions) with 1 / 4 / 20 / 32 live
+    frames per window: the result equals the unsplit launch up to the fp32 association of the K parts (bf16 outputs: a few
+    last-bit flips), is bit-identical from run to run, leaves the arrival counters clean, and with every frame live (dense
+    gradient) no part is split off -- bit-identical with the unflagged launch."""
+    from dynamicpdb_amd import ops
+    Wn, F, N = 8, 32, 256
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    g = ops.Grid(Wn, F, N, dev)
+    wsp = ops.Workspace(dev) if hasattr(ops, "Workspace") else None
+    for CI, CO in ((1280, 640), (640, 1280)):
+        wd = (torch.randn(CO, 25, CI, generator=gen) * (2.0 / (25 * CI)) ** 0.5).to(torch.bfloat16).to(dev)
+        x = g.alloc(CI)
+        xi = g.interior(x)
+        for f in live:
+            xi[:, f] = torch.randn(Wn, N, CI, generator=gen).to(torch.bfloat16).to(dev)
+        ps = torch.full((Wn, g.Fp + 1), -1, dtype=torch.int32, device=dev)
+        scratch = torch.zeros(Wn * g.Fp + 1, dtype=torch.int32, device=dev)
+        gt = g.alloc(CI)
+        ops.grid_load_flags(g, xi.contiguous(), gt, ps, scratch)
+        outs = []
+        for parts in (0, 5, 5):
+            monkeypatch.setattr(ops, "_NZ_SPLIT", parts)
+            out = g.alloc(CO)
+            ops.conv5x5_fwd(g, gt, wd, None, out, relu=False, ws=wsp, nz=(ps, 0))
+            outs.append(g.interior(out).clone())
+        monkeypatch.setattr(ops, "_NZ_SPLIT", 0)
+        ref = g.alloc(CO)
+        ops.conv5x5_fwd(g, gt, wd, None, ref, relu=False, ws=wsp)
+        assert torch.equal(outs[0], g.interior(ref))              # flags without split: the same bits as no flags
+        assert torch.equal(outs[1], outs[2])                      # deterministic
+        e = rel_l2(outs[1].float(), outs[0].float())
+        assert e < 2e-3, e                                        # bf16 last-bit flips of re-associated fp32 sums
+        if len(live) == F:
+            assert torch.equal(outs[1], outs[0])                  # nothing to gain: nothing split
+        assert float(outs[0].float().abs().max()) > 0
+        cnt = wsp.get("splitk_cnt", (ops._SPLITK_CAP * ops.cu_count(torch.device(dev)),), torch.int32) if wsp is not None else None
+        if cnt is not None:
+            assert int(cnt.abs().max()) == 0
 
 
 def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
