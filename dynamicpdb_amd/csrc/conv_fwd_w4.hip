@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void dfold_conv_w4_kernel(const GemmParams 
       return row[b + 1] - row[a] > 0;
     };
     live = run_live(m0) || run_live(m0 + 256);
-    if (!live && blockIdx.y != 0) return;     // (split-K: part 0 alone writes the zero tile)
+    if (!live && (blockIdx.y != 0 || (p.flags & DFOLD_GEMM_NZ_KEEP))) return;     // (split-K: part 0 alone writes the zero tile -- unless
+                                                                                   //  the caller says it is there already)
     if (!SK && p.sk_per == -1) {
       // ---- split factor chosen on the DEVICE from the flags (round 6): the launch carries S_max parts per tile; how many of
       // them walk K is decided here, the same way by every workgroup of a window.  The live tiles of a skipped launch run as

@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import (GEMM_ACCUM, GEMM_ATOMIC, GEMM_BIAS, GEMM_OUT_BF16, GEMM_RELU, GEMM_RELUMASK, GEMM_RESID, GemmDesc,
                    RowMap, check, stream)
 
-GEMM_C2RELU, GEMM_MASK2 = 128, 256          # include/dfold_hip.h
+GEMM_C2RELU, GEMM_MASK2, GEMM_NZ_KEEP = 128, 256, 512          # include/dfold_hip.h
 
 BF16 = torch.bfloat16
 _zero_pages = {}
@@ -381,6 +381,8 @@ _TAIL_SPLIT = os.environ.get("DFOLD_CONV_TAIL_SPLIT", "1") != "0"     # conv5x5_
 # zero-frame-flagged launches: up to this many split-K parts per tile, the number that walks K is chosen on the device from the
 # flags (conv_fwd_w4.hip; 0 / DFOLD_CONV_SPLITK=0: never split, bit-identical with the unflagged launch)
 _NZ_SPLIT = int(os.environ.get("DFOLD_CONV_NZ_SPLIT", "5"))
+# flagged tower backward: dead tiles are left alone instead of being written with the zeros they hold already (ConvTower.backward)
+_NZ_KEEP = os.environ.get("DFOLD_CONV_NZ_KEEP", "1") != "0"
 
 
 def nz_split_parts(CI):
@@ -413,13 +415,15 @@ _SKIP_PAD_TAPS = os.environ.get("DFOLD_CONV_SKIP_PAD", "0") == "1"
 
 
 def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=None, relu_mask=None, C2=None, R2=None,
-                f_lo=0, nf=None, ws=None, nz=None):
+                f_lo=0, nf=None, ws=None, nz=None, nz_keep=False):
     """out[cell] = epi(sum_taps x[cell+tap] @ wf[:, tap, :]^T).  x [Wn,Fp,Wp,CI], wf [CO,25,CI], out [Wn,Fp,Wp,CO].
     f_lo / nf: only the output cells of frames [f_lo, f_lo + nf) are computed (they read x frames f_lo-2 .. f_lo+nf+1).
     nz = (ps, radius): frame flags of grid_load_flags and the distance within which x can be non-zero around the flagged
     frames; output tiles whose input frames are all zero by that statement skip their K walk on the device."""
     CO, _, CI = wf.shape
     flags = GEMM_RELU if relu else 0
+    if nz is not None and nz_keep:
+        flags |= GEMM_NZ_KEEP     # out / C2 already hold the epilogue of a zero product on the tiles the flags call dead
     R = None
     if resid is not None:
         flags |= GEMM_RESID
@@ -466,7 +470,8 @@ def conv5x5_fwd(g, x, wf, bias, out, *, relu=True, resid=None, pre_resid_out=Non
         nf_b = conv_tail_frames(nf, (g.Wn * g.N // 512) * (CO // 160), cu_count(x.device))
         if nf_b:
             kw = dict(relu=relu, resid=resid, pre_resid_out=pre_resid_out, relu_mask=relu_mask,
-                      C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws, nz=nz)
+                      C2=None if pre_resid_out is not None else C2, R2=None if pre_resid_out is not None else R2, ws=ws, nz=nz,
+                      nz_keep=nz_keep)
             conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo, nf=nf - nf_b, **kw)
             return conv5x5_fwd(g, x, wf, bias, out, f_lo=f_lo + nf - nf_b, nf=nf_b, **kw)
     S, sk = 1, {}
@@ -834,7 +839,14 @@ class ConvTower:
         gi = gtop
         ws = self.ws
         full = ((0, g.F), (0, g.F))
-        if last_frame_only:
+        # flagged backward: dead tiles are not written at all (DFOLD_GEMM_NZ_KEEP).  What a dead tile's epilogue would store is a
+        # zero -- du = mask . 0; gn = gi + 0 and dv' = mask . gn where gi, the previous stage's result, is itself zero that far from
+        # a flagged frame -- and the scratch grids hold zeros there already: zeroed below, and a tile that is dead at one stage
+        # was dead at every earlier one (the radius only grows), i.e. never written since.  dv starts as mask . gtop: zero wherever
+        # gtop is.  (A dead tile's epilogue read and wrote 0.3 - 0.65 MB at a fraction of the HBM rate: 0.25 ms of a 0.65 - 1.4 ms
+        # launch.)
+        keep = _NZ_KEEP and nz_ps is not None and not last_frame_only
+        if last_frame_only or keep:
             for name, ch in (("du", C // 2), ("g0", C), ("g1", C)):
                 ws.get(name, (g.Wn, g.Fp, g.Wp, ch), zero=True)
         dv = relu_mask_bf16(gi, saved[3 * 3 + 2], ws.get("dv", tuple(gtop.shape)))
@@ -851,14 +863,14 @@ class ConvTower:
             self._wgrad(g, 2 * i + 1, u, dv, l2, n2, finalize, nz0)
             du = ws.get("du", tuple(u.shape))
             sws = ws
-            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws, nz=nz0)
+            conv5x5_fwd(g, dv, self.wd[2 * i + 1], None, du, relu=False, relu_mask=u, f_lo=l1, nf=n1, ws=sws, nz=nz0, nz_keep=keep)
             self._wgrad(g, 2 * i, hprev, du, l1, n1, finalize, nz2)
             gn = ws.get("g%d" % (i & 1), tuple(gtop.shape))
             if i > 0:
                 conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, C2=dv, R2=saved[3 * (i - 1) + 2],
-                            f_lo=l0, nf=n0, ws=sws, nz=nz2)
+                            f_lo=l0, nf=n0, ws=sws, nz=nz2, nz_keep=keep)
             else:
-                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0, ws=sws, nz=nz2)
+                conv5x5_fwd(g, du, self.wd[2 * i], None, gn, relu=False, resid=gi, f_lo=l0, nf=n0, ws=sws, nz=nz2, nz_keep=keep)
             gi = gn
         return gi
 

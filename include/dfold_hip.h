@@ -74,6 +74,11 @@ typedef struct {
                                   ReLU'd operand leaves with the residual stream (AngleResnet, structure_module.py:64-71) */
 #define DFOLD_GEMM_MASK2 256   /* v = R2[off] > 0 ? v : 0 BEFORE the residual add (R2 bf16; no C2): the ReLU backward of a
                                   branch that joins a residual gradient stream in the same launch */
+#define DFOLD_GEMM_NZ_KEEP 512 /* zero-frame-flagged 5x5 conv launch (nz_ps): the caller guarantees that C (and C2) already hold, on
+                                * every tile the flags call dead, what the epilogue of a zero product would write there -- those
+                                * tiles are left alone (round 6: the tower's backward, whose scratch grids are zeroed per call and
+                                * whose dead region only shrinks from stage to stage; a dead tile's epilogue is a pure copy of zeros
+                                * at a quarter of the HBM rate) */
 
 typedef struct {
   const void* A;        /* bf16 */
