@@ -23,7 +23,6 @@
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
 #include <math.h>
-#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) unsigned tgu32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned tgu32x2;
@@ -530,15 +529,16 @@ static int tg_launch(const TriAttRegParams& p, hipStream_t stream) {
 
 extern "C" int dfold_triatt_reg_fwd(const void* x, int32_t x_is_bf16, const float* mask, const float* ln_gamma,
                                     const float* ln_beta, const void* w_cat_bf16, const float* bias_cat, const float* tri,
-                                    const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, float* dbg, int32_t B,
-                                    int32_t N, int32_t NP, int32_t ending, float inf, float scale, float eps, void* stream) {
+                                    const void* w_o_bf16, const float* b_o, void* out, int32_t out_is_bf16, float* dbg,
+                                    int32_t dbg_phase_clock, int32_t B, int32_t N, int32_t NP, int32_t ending, float inf, float scale,
+                                    float eps, void* stream) {
   if (!x || !mask || !ln_gamma || !ln_beta || !w_cat_bf16 || !bias_cat || !tri || !w_o_bf16 || !b_o || !out) return DFOLD_EINVAL;
   if (B <= 0 || N <= 0 || N > 512 || NP < N || (NP & 63) || (long)B * N > 0x7fffffffL) return DFOLD_EINVAL;
   TriAttRegParams p;
   p.x = x; p.mask = mask; p.gamma = ln_gamma; p.beta = ln_beta; p.W = (const bf16_t*)w_cat_bf16; p.bcat = bias_cat; p.tri = tri;
   p.Wo = (const bf16_t*)w_o_bf16; p.bo = b_o; p.out = out; p.dbg = dbg; p.B = B; p.N = N; p.NP = NP; p.ending = ending ? 1 : 0;
   p.x_bf16 = x_is_bf16 ? 1 : 0; p.out_bf16 = out_is_bf16 ? 1 : 0; p.inf = inf; p.scale = scale; p.eps = eps;
-  { const char* e = getenv("DFOLD_TG_X"); p.xflags = e ? atoi(e) : 0; }
+  p.xflags = (dbg != nullptr && dbg_phase_clock) ? 64 : 0;
   if (N <= 128) return tg_launch<2>(p, (hipStream_t)stream);
   if (N <= 256) return tg_launch<4>(p, (hipStream_t)stream);
   if (N <= 384) return tg_launch<6>(p, (hipStream_t)stream);

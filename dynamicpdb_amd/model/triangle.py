@@ -196,6 +196,7 @@ def _use_row_kernel():
 
 
 _TRIATT_DBG = None      # tests: fp32 [4][N][32] device tensor receiving q|k|v|gate of head 0, row 0, item 0
+_TRIATT_PHASE_CLOCK = False     # scripts/triatt_phase_times.py: the register-resident kernel stamps its phases behind _TRIATT_DBG
 
 
 def _np64(N):
@@ -713,12 +714,14 @@ def _triatt_fused(x, mask, starting, inf, pack, ws=None):
         check(L.dfold_triatt_bias_blocked(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(g_ln), _p(b_ln), _p(w_tri), _p(tri),
                                           c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(1e-5), st),
               "dfold_triatt_bias_blocked")
-        fwd = L.dfold_triatt_reg_fwd if reg_kernel else L.dfold_triatt_fused_fwd
-        check(fwd(_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat),
-                  _p(bcat), _p(tri), _p(wo), _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0),
-                  _p(_TRIATT_DBG), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf),
-                  ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), st),
-              "dfold_triatt_reg_fwd" if reg_kernel else "dfold_triatt_fused_fwd")
+        head = (_p(xc), c_int32(1 if xc.dtype == BF16 else 0), _p(maskf), _p(g_ln), _p(b_ln), _p(wcat), _p(bcat), _p(tri), _p(wo),
+                _p(b_o), _p(out), c_int32(1 if out.dtype == BF16 else 0), _p(_TRIATT_DBG))
+        tail = (c_int32(B), c_int32(N), c_int32(NP), c_int32(ending), ctypes_float(inf), ctypes_float(1.0 / math.sqrt(32.0)),
+                ctypes_float(1e-5), st)
+        if reg_kernel:
+            check(L.dfold_triatt_reg_fwd(*head, c_int32(1 if _TRIATT_PHASE_CLOCK else 0), *tail), "dfold_triatt_reg_fwd")
+        else:
+            check(L.dfold_triatt_fused_fwd(*head, *tail), "dfold_triatt_fused_fwd")
         return out, xc, maskf
     q = _ws_get(ws, "q", (B, N, N, 128), BF16, dev)
     k = _ws_get(ws, "k", (B, N, N, 128), BF16, dev)

@@ -432,12 +432,15 @@ int dfold_triatt_fused_fwd(const void* x, int32_t x_is_bf16, const float* mask, 
 /* The same operator for N <= 512 with every projection kept in REGISTERS (round 6, csrc/triatt_reg.hip;
  * triangular_attention.py:78-139, primitives.py:219-243,377-448): one wave owns 64 cells of the row -- their LayerNorm output
  * stays in the MFMA operand layout in its registers, Q^T / sigmoid(G^T) / gated O leave the matrix pipe in the operand layout
- * of the next product, only K and V^T of a head go through LDS (double-buffered: one barrier per head; 66 KB at N <= 256 =
- * two rows per CU).  Same arguments and pass 0 (dfold_triatt_bias_blocked) as dfold_triatt_fused_fwd. */
+ * of the next product, only K and V^T of a head go through LDS; the head's weights (and W_o) wait there as ready-made operand
+ * fragments, requested by LDS-DMA a whole attention phase ahead (66 KB at N <= 256 =
+ * two rows per CU).  Same arguments and pass 0 (dfold_triatt_bias_blocked) as dfold_triatt_fused_fwd, plus dbg_phase_clock
+ * (measurement, scripts/triatt_phase_times.py; needs dbg with room for 4 N 32 + 512 floats): the waves of one workgroup in mid
+ * grid write s_memtime at every phase boundary to dbg[4 N 32 + 64 wave + k]. */
 int dfold_triatt_reg_fwd(const void* x, int32_t x_is_bf16, const float* mask, const float* ln_gamma, const float* ln_beta,
                          const void* w_cat_bf16, const float* bias_cat, const float* tri, const void* w_o_bf16, const float* b_o,
-                         void* out, int32_t out_is_bf16, float* dbg, int32_t B, int32_t N, int32_t NP, int32_t ending,
-                         float inf, float scale, float eps, void* stream);
+                         void* out, int32_t out_is_bf16, float* dbg, int32_t dbg_phase_clock, int32_t B, int32_t N, int32_t NP,
+                         int32_t ending, float inf, float scale, float eps, void* stream);
 /* The same operator for ANY N (round 4, csrc/triatt_rows.hip; triangular_attention.py:78-139, primitives.py:219-243,377-448):
  * the query-block form of the row kernel.  Pass 0, dfold_triatt_ln_bias: one streaming pass over x that writes
  *   xn bf16 [B][N][N][128] = LayerNorm(x') in the operator's coordinates (x' = x, or x^T for ending != 0) and

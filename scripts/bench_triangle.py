@@ -159,7 +159,7 @@ def _stages_att(m, x, mask, reps):
 
         def g1():
             check(L.dfold_triatt_reg_fwd(_p(x), c_int32(xb), _p(mask), _p(g), _p(b), _p(wcat), _p(bcat), _p(tribr), _p(wo), _p(bo),
-                                         _p(out), c_int32(xb), c_void_p(0), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending),
+                                         _p(out), c_int32(xb), c_void_p(0), c_int32(0), c_int32(B), c_int32(N), c_int32(NP), c_int32(ending),
                                          ctypes_float(1e9), ctypes_float(1.0 / math.sqrt(32.0)), ctypes_float(1e-5), stream()), "reg")
         g0()
         rows += [

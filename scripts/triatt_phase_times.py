@@ -1,7 +1,6 @@
-"""Phase timestamps (s_memtime) of one workgroup of the register-resident triangle attention (csrc/triatt_reg.hip, debug build
-switch DFOLD_TG_X=64): cycles since the wave's start at every phase boundary, per wave."""
+"""Phase timestamps (s_memtime) of one workgroup of the register-resident triangle attention (csrc/triatt_reg.hip, argument
+dbg_phase_clock of dfold_triatt_reg_fwd): cycles since the wave's start at every phase boundary, per wave."""
 import os, sys
-os.environ["DFOLD_TG_X"] = str(64 | int(os.environ.get("DFOLD_TG_X", "0")))
 os.environ["DFOLD_TRIATT_ROW"] = "3"
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -15,6 +14,7 @@ x = torch.randn(8, N, N, 128, device=dev) * 1.5
 mask = torch.ones(8, N, N, device=dev)
 dbg = torch.zeros(4 * N * 32 + 8 * 64, device=dev)
 T._TRIATT_DBG = dbg
+T._TRIATT_PHASE_CLOCK = True
 with torch.no_grad():
     for _ in range(3):
         m(x, mask=mask)

@@ -76,6 +76,11 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
                                       c_int32(0), c_float(1e-5), c_void_p(0)) == -1
     assert L.dfold_triatt_ln_bias(one, c_int32(0), one, one, one, one, None, c_int32(1), c_int32(64), c_int32(64),
                                   c_int32(0), c_float(1e-5), c_void_p(0)) == -1
+    # register-resident triangle attention (round 6): N_res above 512, key pitch below N_res / not a multiple of 64, missing bias
+    for (n, npad, tri) in ((520, 576, one), (300, 256, one), (300, 328, one), (256, 256, None)):
+        assert L.dfold_triatt_reg_fwd(one, c_int32(0), one, one, one, one, one, tri, one, one, one, c_int32(0), None, c_int32(0),
+                                      c_int32(1), c_int32(n), c_int32(npad), c_int32(0), c_float(1e9), c_float(0.17), c_float(1e-5),
+                                      c_void_p(0)) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):
