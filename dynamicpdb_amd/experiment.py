@@ -16,10 +16,75 @@ def torsion_angle_loss(a, a_gt, a_alt_gt, mask):
     return (m * mask).sum(dim=(-1, -2)) / (mask.sum(dim=(-1, -2)) + 1e-2)
 
 
+class LossLastFrameFn(torch.autograd.Function):
+    """loss_fn on the device as ONE HIP launch (csrc/loss.hip, dfold_loss_last_frame): the live terms read the last frame of a
+    window only (train_DFOLD_dynamics.py:1219-1340), so the node takes the last-frame slices, gets the per-window terms and the
+    gradients w.r.t. (angles, x0 translations, rotation scores) back from the kernel and scatters the gradients into zero
+    tensors in its backward.  The aten graph it replaces: ~55 launches forward, ~80 backward."""
+
+    @staticmethod
+    def forward(ctx, angles, rigids, rot_score, batch, trans_w, rot_w, torsion_w, rot_t_threshold):
+        from . import _lib
+        from ctypes import c_float, c_int32, c_void_p
+        L = _lib.lib()
+        B, Fr, N = angles.shape[0], angles.shape[1], angles.shape[2]
+        p = lambda x: c_void_p(x.data_ptr())
+        f32 = lambda x: x.detach().to(torch.float32).contiguous()
+        f64 = lambda x: x.detach().to(torch.float64).contiguous()
+        bb = batch['res_mask'].to(torch.float32)
+        dm = 1 - batch['fixed_mask'].to(torch.float32)
+        ang = f32(angles[:, -1])
+        tr = f32(rigids[:, -1, :, 4:])
+        rot = f64(rot_score[:, -1])
+        a_gt, a_alt = f32(batch['torsion_angles_sin_cos'][:, -1]), f32(batch['alt_torsion_angles_sin_cos'][:, -1])
+        a_m = f32(batch['torsion_angles_mask'][:, -1])
+        tr_gt, rot_gt = f32(batch['rigids_0'][:, -1, :, 4:]), f64(batch['rot_score'][:, -1])
+        dml, lml = dm[:, -1].contiguous(), (bb[:, -1] * dm[:, -1]).contiguous()
+        rss, tt = f64(batch['rot_score_scaling'].reshape(B)), f32(batch['t'].reshape(B))
+        live = torch.any(bb > 0, dim=-1).sum(-1).to(torch.float32).contiguous()
+        dev = angles.device
+        terms = torch.empty((B, 4), dtype=torch.float64, device=dev)
+        d_ang, d_tr, d_rot = torch.empty_like(ang), torch.empty_like(tr), torch.empty_like(rot)
+        _lib.check(L.dfold_loss_last_frame(p(ang), p(a_gt), p(a_alt), p(a_m), p(tr), p(tr_gt), p(rot), p(rot_gt), p(dml), p(lml), p(rss),
+                                           p(tt), p(live), p(terms), p(d_ang), p(d_tr), p(d_rot), c_int32(B), c_int32(N), c_int32(Fr),
+                                           c_float(trans_w), c_float(rot_w), c_float(torsion_w), c_float(rot_t_threshold),
+                                           _lib.stream()), "dfold_loss_last_frame")
+        ctx.save_for_backward(d_ang, d_tr, d_rot)
+        ctx.shapes = (angles.shape, angles.dtype, rigids.shape, rigids.dtype, rot_score.shape, rot_score.dtype)
+        m = terms.mean(0)
+        ctx.mark_non_differentiable(m)
+        return m[0].clone(), m
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        d_ang, d_tr, d_rot = ctx.saved_tensors
+        sa, ta, sr, tr_, so, to = ctx.shapes
+        g_a = g_r = g_o = None
+        if ctx.needs_input_grad[0]:
+            g_a = torch.zeros(sa, dtype=ta, device=d_ang.device)
+            g_a[:, -1] = (d_ang * g_loss).to(ta)
+        if ctx.needs_input_grad[1]:
+            g_r = torch.zeros(sr, dtype=tr_, device=d_tr.device)
+            g_r[:, -1, :, 4:] = (d_tr * g_loss).to(tr_)
+        if ctx.needs_input_grad[2]:
+            g_o = torch.zeros(so, dtype=to, device=d_rot.device)
+            g_o[:, -1] = (d_rot * g_loss).to(to)
+        return g_a, g_r, g_o, None, None, None, None, None
+
+
+_LOSS_FUSED = __import__("os").environ.get("DFOLD_LOSS_FUSED", "1") != "0"
+
+
 def loss_fn(out, batch, trans_w=100.0, rot_w=7.0, torsion_w=1.0, rot_t_threshold=0.0):
     """Live loss terms for a [B,F,N,..] batch: last-frame torsion / translation-x0 / rotation-score losses, each
     repeated over the F frames of its window, gated by trans_loss < 100 (train_DFOLD_dynamics.py:1210-1400).
-    Returns (mean over windows of the reference's per-window loss, aux dict)."""
+    Returns (mean over windows of the reference's per-window loss, aux dict).  Device tensors: one HIP launch
+    (LossLastFrameFn; DFOLD_LOSS_FUSED=0 keeps the aten graph below, which is also what host tensors -- the gloo tests, the
+    oracle comparisons -- run)."""
+    if _LOSS_FUSED and out['angles'].is_cuda:
+        loss, m = LossLastFrameFn.apply(out['angles'], out['rigids'], out['rot_score'], batch, float(trans_w), float(rot_w),
+                                        float(torsion_w), float(rot_t_threshold))
+        return loss, dict(rot_loss=m[1], trans_loss=m[2], torsion_loss=m[3])
     dt = out['rigids'].dtype
     bb_mask = batch['res_mask'].to(dt)                       # [B,F,N]
     diffuse_mask = 1 - batch['fixed_mask'].to(dt)

@@ -458,6 +458,23 @@ int dfold_triatt_rows_fwd(const void* xn_bf16, const float* mask, const void* w_
                           int32_t B, int32_t N, int32_t NP, int32_t ending, float inf, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training loss (Experiment.loss_fn, train_DFOLD_dynamics.py:1182-1400, live terms; torsion term openfold/utils/loss.py:52-76
+ * as called at :1219-1224) on the LAST frame of every window, values and gradients in one launch (round 6, csrc/loss.hip).
+ * All inputs are the last-frame slices, contiguous: ang / ang_gt / ang_alt fp32 [B][N][7][2], ang_mask fp32 [B][N][7],
+ * trans_pred / trans_gt fp32 [B][N][3], rot_pred / rot_gt float64 [B][N][3] (the IGSO(3) score head works in float64),
+ * diffuse_mask = 1 - fixed_mask and loss_mask = res_mask * diffuse_mask fp32 [B][N], rot_score_scaling float64 [B], t fp32 [B],
+ * live_frames fp32 [B] = frames of the window with any residue (the normalisation of :1388-1396; F = frames of a window).
+ * terms float64 [B][4] = per-window (final, rot, gated trans, torsion), already repeated over the F frames and divided by
+ * live_frames as the reference does; loss = mean over windows of terms[:,0].  d_ang / d_trans (fp32) / d_rot (float64):
+ * d loss / d (ang, trans_pred, rot_pred).  Gate trans < 100 and t > rot_t_threshold as :1338-1340, :1304. */
+int dfold_loss_last_frame(const float* ang, const float* ang_gt, const float* ang_alt, const float* ang_mask,
+                          const float* trans_pred, const float* trans_gt, const double* rot_pred, const double* rot_gt,
+                          const float* diffuse_mask, const float* loss_mask, const double* rot_score_scaling, const float* t,
+                          const float* live_frames, double* terms, float* d_ang, float* d_trans, double* d_rot, int32_t B,
+                          int32_t N, int32_t F, float trans_weight, float rot_weight, float torsion_weight,
+                          float rot_t_threshold, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * First layer of the feature embedders (force/vel/index/rigid/angle_embeder[0:2], src/model/ipa_pytorch_dynamic.py:
  * 757-796): h = SiLU(x W^T + b), x fp32 [P,k] (k <= 16), W fp32 [256,k], h bf16 [P,256].  Backward accumulates
  * dW / db with fp32 atomics (caller zeroes them); dx (fp32 [P,k]) may be NULL.

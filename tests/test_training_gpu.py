@@ -477,6 +477,63 @@ def test_loss_fn_on_device_vs_oracle_values_and_gradients():
     assert set(aux) >= {"rot_loss", "trans_loss", "torsion_loss"}
 
 
+@pytest.mark.parametrize("case", ["plain", "gate_closed", "t_below_threshold", "holes_and_dead_frames", "equal_alt"])
+def test_loss_one_launch_equals_the_aten_graph(case, monkeypatch):
+    """Round 6: loss_fn on device tensors is one HIP launch (csrc/loss.hip through experiment.LossLastFrameFn: values and the
+    gradients w.r.t. angles / x0 translations / rotation scores of the last frame).  Against the aten graph of the same
+    formulas (DFOLD_LOSS_FUSED=0, the path host tensors take) on the device: loss, the three aux terms and the three gradients
+    -- with the trans < 100 gate open and closed, t below the rotation threshold, masked residues / frames without any residue
+    (the F / live-frames normalisation), float64 rotation scores as the score head produces them, and alt torsions equal to
+    the true ones (the tie of torch.minimum)."""
+    from dynamicpdb_amd import experiment, synthetic
+    from dynamicpdb_amd.data.se3_diffuser import SE3Diffuser
+    dev = torch.device(DEV)
+    F, N, B = 6, 37, 4
+    conf = synthetic.default_conf(F, cache_dir="/tmp/dfold_igso3_cache/")
+    diffuser = SE3Diffuser(conf.diffuser)
+    ws = [synthetic.synthetic_window(400 + i, F, N, t=0.15 + 0.2 * i, diffuser=diffuser) for i in range(B)]
+    batch = {k: torch.stack([w[k] for w in ws]).to(dev) for k in ws[0] if k != "t"}
+    batch["t"] = torch.cat([w["t"] for w in ws]).to(dev)
+    rng = np.random.default_rng(9)
+    kw = {}
+    rig = rng.standard_normal((B, F, N, 7), dtype=np.float32)
+    if case == "gate_closed":
+        rig[1, :, :, 4:] += 40.0            # window 1: translation loss far above 100 -> its rot / trans terms are gated off
+    if case == "t_below_threshold":
+        kw["rot_t_threshold"] = 0.4         # windows 0 and 1 lose their rotation term
+    if case == "holes_and_dead_frames":
+        rm = batch["res_mask"].clone()
+        rm[:, :, ::5] = 0
+        rm[2, 1] = 0                        # a frame without any residue: F / (live frames) != 1
+        rm[2, 3] = 0
+        batch["res_mask"] = rm
+        fm = batch["fixed_mask"].clone().float()
+        fm[:, :, 1::7] = 1
+        batch["fixed_mask"] = fm
+    if case == "equal_alt":
+        batch["alt_torsion_angles_sin_cos"] = batch["torsion_angles_sin_cos"].clone()
+    base = {"angles": torch.tensor(rng.standard_normal((B, F, N, 7, 2), dtype=np.float32)), "rigids": torch.tensor(rig),
+            "rot_score": torch.tensor(rng.standard_normal((B, F, N, 3)))}          # float64, as igso3_score returns it
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(experiment, "_LOSS_FUSED", fused)
+        ob = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        loss, aux = experiment.loss_fn(ob, batch, **kw)
+        loss.backward()
+        res.append((float(loss), {k: float(v) for k, v in aux.items()}, {k: ob[k].grad.clone() for k in ob}))
+    (l1, a1, g1), (l0, a0, g0) = res
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    for k in a0:
+        assert abs(a1[k] - a0[k]) <= 2e-6 * max(abs(a0[k]), 1e-3), (k, a1[k], a0[k])
+    for k in g0:
+        assert g1[k].dtype == g0[k].dtype and g1[k].shape == g0[k].shape
+        assert float(g1[k][:, :-1].abs().max()) == 0            # only the last frame is read
+        assert rel_l2(g1[k].double(), g0[k].double()) < 5e-6, (k, rel_l2(g1[k].double(), g0[k].double()))
+    if case == "gate_closed":
+        assert float(g1["rigids"][1].abs().max()) == 0 and float(g1["rot_score"][1].abs().max()) == 0
+        assert float(g1["angles"][1].abs().max()) > 0
+
+
 def test_conv_gradients_flow_through_autograd_and_ddp_wrapper():
     """Without a dp.GradReducer the shared conv tower's weight gradients leave ConvTowerFn.backward as ordinary autograd
     outputs: torch.autograd.grad() returns them, post-accumulate hooks fire, and the reference's own wrapper
