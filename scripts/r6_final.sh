@@ -4,6 +4,7 @@
 #   gpurun --timeout 1800 -- 'bash scripts/r6_final.sh bench'     default bench line + kernel stats  -> ${TAG:-r6}_bench_default.json, r6_kernel_stats*.csv
 #   gpurun --timeout 1200 -- 'bash scripts/r6_final.sh pmc'       counter passes of the conv kernels -> r6_pmc_*.txt/json, r6_pmc_conv_sq_*.txt
 #   gpurun --timeout 1200 -- 'bash scripts/r6_final.sh traces'    per-shape contraction / helper / aten traces of one step, triangle operators
+#   gpurun --timeout  900 -- 'bash scripts/r6_final.sh triatt'    triangle attention: stages, phase clock, counters -> ${TAG}_triatt_*
 #   gpurun --timeout  900 -- 'bash scripts/r6_final.sh dp2'       bench.py --gpus 2 dry run, two ranks on ONE GPU over gloo
 set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
@@ -27,6 +28,13 @@ case "${1:-tests}" in
     timeout 300 python scripts/gemm_trace.py > gpurun_out/${TAG:-r6}_gemm_trace.txt 2>&1; head -n 4 gpurun_out/${TAG:-r6}_gemm_trace.txt | cut -c1-200
     timeout 300 python scripts/glue_trace.py > gpurun_out/${TAG:-r6}_glue_trace.txt 2>&1; grep "aten device time" gpurun_out/${TAG:-r6}_glue_trace.txt
     timeout 300 python scripts/bench_triangle.py --n 256 512 --batch 8 --backward --no-stages --reps 6 > gpurun_out/${TAG:-r6}_triangle_fwd_bwd.txt 2>&1; tail -n 10 gpurun_out/${TAG:-r6}_triangle_fwd_bwd.txt | cut -c1-220 ;;
+  triatt)
+    # register-resident triangle attention: stage times, phase clock of one workgroup, SQ / HBM-side counters (batch 8)
+    timeout 600 python scripts/bench_triangle.py --n 256 512 --batch 8 --reps 20 --ops tri_att_start tri_att_end > gpurun_out/${TAG:-r6}_triatt_stages_b8.jsonl 2> gpurun_out/${TAG:-r6}_triatt_stages.err < /dev/null
+    tail -n 4 gpurun_out/${TAG:-r6}_triatt_stages_b8.jsonl | cut -c1-200
+    timeout 300 python scripts/triatt_phase_times.py 256 > gpurun_out/${TAG:-r6}_triatt_phases.txt 2>&1; head -n 3 gpurun_out/${TAG:-r6}_triatt_phases.txt | cut -c1-400
+    FULL=1 bash scripts/r6_triatt_pmc.sh 256 ${TAG:-r6}_triatt_n256
+    bash scripts/r6_triatt_pmc.sh 512 ${TAG:-r6}_triatt_n512 ;;
   dp2)
     DFOLD_BENCH_BACKEND=gloo DFOLD_BENCH_ONE_GPU=1 timeout 800 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
         bench.py --gpus 2 --steps 3 --warmup 1 --no-last-frame-mode --no-all-positions-mode > gpurun_out/${TAG:-r6}_bench_2rank_one_gpu.json 2> gpurun_out/${TAG:-r6}_bench_2rank_one_gpu.err < /dev/null
