@@ -267,7 +267,7 @@ def conv_kernel_roofline(model, trainer, batch, B, F, N, tlog=None, pmc=False):
     wt, c = None, None
     if (B, F, N) == (8, 32, 256):
         traffic, traffic_source = collect_conv_traffic(tlog or (lambda m: None)) if pmc else (None, "multi-rank run")
-        for tag in ("r6", "r5", "r4", "r3"):         # the newest committed PMC pass: the fallback, and the weight gradient's bytes
+        for tag in ("r6b", "r6", "r5", "r4", "r3"):         # the newest committed PMC pass: the fallback, and the weight gradient's bytes
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_conv.json")
             if os.path.exists(pmc):
                 with open(pmc) as fh:
