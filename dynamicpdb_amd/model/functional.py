@@ -846,6 +846,40 @@ class Igso3SeriesFn(Function):
         return (g * dsc).float(), None
 
 
+class RotScoreHeadFn(Function):
+    """The whole rotation-score head on the device in four launches (csrc/score.hip: dfold_rot_head_pre -> dfold_igso3_series ->
+    dfold_rot_head_post; backward dfold_rot_head_bwd): score = igso3_score(quat_to_rotvec(q_0^-1 q_t)) as float64 [..., 3] and its
+    gradient w.r.t. the predicted quaternion q_0 (q_t comes from the batch).  quats fp32 [W, ..., 4], env fp64 [W, L]."""
+
+    @staticmethod
+    def forward(ctx, quats_t, quats_0, env):
+        L_ = _lib.lib()
+        qt, q0 = quats_t.detach().float().contiguous(), quats_0.detach().float().contiguous()
+        W, L = env.shape
+        P = q0.numel() // 4
+        dev = q0.device
+        vec = torch.empty(q0.shape[:-1] + (3,), dtype=torch.float32, device=dev)
+        om = torch.empty(q0.shape[:-1], dtype=torch.float32, device=dev)
+        sc, dsc = torch.empty(om.shape, dtype=torch.float64, device=dev), torch.empty(om.shape, dtype=torch.float64, device=dev)
+        score = torch.empty(vec.shape, dtype=torch.float64, device=dev)
+        check(L_.dfold_rot_head_pre(_p(qt), _p(q0), _p(vec), _p(om), c_int64(P), stream()), "dfold_rot_head_pre")
+        check(L_.dfold_igso3_series(_p(om), _p(env), _p(sc), _p(dsc), c_int64(P), c_int64(P // W), c_int32(L), stream()),
+              "dfold_igso3_series")
+        check(L_.dfold_rot_head_post(_p(vec), _p(om), _p(sc), _p(score), c_int64(P), stream()), "dfold_rot_head_post")
+        ctx.save_for_backward(qt, q0, vec, om, sc, dsc)
+        ctx.q0_dtype = quats_0.dtype
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        qt, q0, vec, om, sc, dsc = ctx.saved_tensors
+        gd = g.to(torch.float64).contiguous()
+        d_q0 = torch.empty_like(q0)
+        check(_lib.lib().dfold_rot_head_bwd(_p(gd), _p(qt), _p(q0), _p(vec), _p(om), _p(sc), _p(dsc), _p(d_q0), c_int64(q0.numel() // 4),
+                                            stream()), "dfold_rot_head_bwd")
+        return None, d_q0.to(ctx.q0_dtype), None
+
+
 # ------------------------------------------------------------------------------------------------
 # backbone frame update
 # ------------------------------------------------------------------------------------------------

@@ -52,7 +52,19 @@ def igso3_score(vec, sigma, eps=1e-6, L=1000):
     return sc[..., None] * vec / (omega[..., None] + eps)
 
 
-def rot_score(quats_t, quats_0, sigma):
+_HEAD_FUSED = __import__("os").environ.get("DFOLD_SCORE_FUSED", "1") != "0"
+
+
+def rot_score(quats_t, quats_0, sigma, L=1000):
+    """quats [W, ..., 4] (window axis first), sigma [W] float64 (host) -> float64 score vectors [W, ..., 3].  Device tensors whose
+    q_t needs no gradient: four HIP launches (functional.RotScoreHeadFn); otherwise (DFOLD_SCORE_FUSED=0, a differentiable q_t) the
+    aten chain of the same formulas."""
+    if _HEAD_FUSED and quats_0.is_cuda and not quats_t.requires_grad:
+        from .functional import RotScoreHeadFn
+        env = _envelope_on_device(sigma, L, quats_0.device)
+        if (quats_0.numel() // 4) % env.shape[0]:
+            raise ValueError("rot_score: leading axis must enumerate the windows of `sigma`")
+        return RotScoreHeadFn.apply(quats_t, quats_0, env)
     q0t = G.quat_mul(G.quat_invert(quats_0), quats_t)
     return igso3_score(G.quat_to_rotvec(q0t), sigma)
 

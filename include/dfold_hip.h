@@ -511,6 +511,18 @@ int dfold_frames_to_atoms_bwd(const float* t7, const float* angles, const int64_
 int dfold_igso3_series(const float* omega, const double* env, double* sc, double* dsc, int64_t P, int64_t per_window,
                        int32_t L, void* stream);
 
+/* The rest of the rotation-score head around the series (round 6; SE3Diffuser.calc_rot_score src/data/se3_diffuser.py:119-125 =
+ * SO3Diffuser.torch_score so3_diffuser.py:274-305 of quat_to_rotvec(q_0^-1 q_t), src/data/utils.py:589-606, quaternion inverse /
+ * product openfold/utils/rigid_utils.py:230-286).  quats fp32 [P][4] (w, x, y, z).
+ *   pre:  vec fp32 [P][3] = rotvec(q_0^-1 q_t) in the reference's fp32 arithmetic, omega fp32 [P] = |vec| + 1e-6
+ *   (dfold_igso3_series: omega -> sc, dsc)
+ *   post: score float64 [P][3] = sc vec / (omega + 1e-6)
+ *   bwd:  g_score float64 [P][3] -> d_quats_0 fp32 [P][4] (the chain rule through all of it, float64 inside). */
+int dfold_rot_head_pre(const float* quats_t, const float* quats_0, float* vec, float* omega, int64_t P, void* stream);
+int dfold_rot_head_post(const float* vec, const float* omega, const double* sc, double* score, int64_t P, void* stream);
+int dfold_rot_head_bwd(const double* g_score, const float* quats_t, const float* quats_0, const float* vec, const float* omega,
+                       const double* sc, const double* dsc, float* d_quats_0, int64_t P, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * One reverse-SDE (denoise) step on tensor_7 frames (SE3Diffuser.reverse src/data/se3_diffuser.py:160-215,
  * SO3Diffuser.reverse so3_diffuser.py:329-365, R3Diffuser.reverse r3_diffuser.py:106-157).  t7/out fp32 [rows][N][7]

@@ -534,6 +534,84 @@ def test_loss_one_launch_equals_the_aten_graph(case, monkeypatch):
         assert float(g1["angles"][1].abs().max()) > 0
 
 
+def test_rot_score_head_four_launches_equals_the_aten_chain(monkeypatch):
+    """Round 6: the rotation-score head (SE3Diffuser.calc_rot_score, se3_diffuser.py:119-125: quaternion inverse / product,
+    quat_to_rotvec, the IGSO(3) series, sc v / (omega + eps)) on the device is four HIP launches (functional.RotScoreHeadFn, csrc/
+    score.hip) instead of ~60 + ~120 aten launches.  Against the aten chain of the same formulas (DFOLD_SCORE_FUSED=0): the float64
+    score and its gradient w.r.t. the predicted quaternion -- random relative rotations, un-normalised q_0 (the network's
+    quaternions before normalisation), relative rotations with w < 0 (the sign flip), nearly identical frames (the small-angle
+    branch of quat_to_rotvec, angle <= 1e-3) and exactly identical ones (norm subgradients)."""
+    from dynamicpdb_amd.model import score_heads
+    dev = torch.device(DEV)
+    W, F, N = 3, 4, 50
+    rng = np.random.default_rng(21)
+    sigma = np.array([0.4, 1.1, 0.15])
+    qt = rng.standard_normal((W, F, N, 4)).astype(np.float32)
+    qt /= np.linalg.norm(qt, axis=-1, keepdims=True)
+    # q_0 = q_t (x) r^-1 with a relative rotation r of 0.3 ... 2.5 sigma about a random axis: the regime the head works in (far
+    # out in the tail, f(omega) ~ exp(-omega^2 / 2 sigma^2) is below the fp32 rounding noise of the series' terms and the
+    # reference's score is noise / 1e-4 -- in every implementation)
+    ax = rng.standard_normal((W, F, N, 3))
+    ax /= np.linalg.norm(ax, axis=-1, keepdims=True)
+    th = sigma[:, None, None] * rng.uniform(0.3, 2.5, size=(W, F, N))
+    rinv = np.concatenate([np.cos(th / 2)[..., None], -np.sin(th / 2)[..., None] * ax], -1)
+    a1, b1, c1, d1 = np.moveaxis(qt.astype(np.float64), -1, 0)
+    a2, b2, c2, d2 = np.moveaxis(rinv, -1, 0)
+    q0 = np.stack([a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2, a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2,
+                   a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2, a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2], -1)
+    q0 = (q0 * rng.uniform(0.5, 1.5, size=(W, F, N, 1))).astype(np.float32)       # un-normalised, as the network's quaternions
+    q0[0, 0] = qt[0, 0] * 1.3                                               # identical rotations (zero rotation vector)
+    q0[0, 1] = qt[0, 1] + 1e-4 * rng.standard_normal((N, 4)).astype(np.float32)   # small-angle branch
+    q0[1, 0] = -q0[1, 0]                                                    # w of q_0^-1 q_t below zero: the sign flip
+    gy = torch.tensor(rng.standard_normal((W, F, N, 3))).to(dev)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(score_heads, "_HEAD_FUSED", fused)
+        a = torch.tensor(q0).to(dev).requires_grad_(True)
+        sc = score_heads.rot_score(torch.tensor(qt).to(dev), a, sigma)
+        assert sc.dtype == torch.float64 and sc.shape == (W, F, N, 3)
+        (sc * gy).sum().backward()
+        res.append((sc.detach().clone(), a.grad.clone()))
+    (s1, g1), (s0, g0) = res
+    assert torch.isfinite(s1).all() and torch.isfinite(g1).all()
+    # Where the relative rotation is tiny (angle <= 1e-3) the reference's fp32 series is rounding noise (lo dhi - hi dlo cancels
+    # to O(omega^3) in fp32: so3_diffuser.py:95-105), in the aten chain as in the kernels -- last-bit differences of omega give
+    # different noise.  Values and gradients are compared where the series is conditioned; the small-angle branch of the
+    # rotation-vector map and its backward are checked on their own below.
+    for name, sl in (("random", (slice(2, 3),)), ("flipped", (1, 0)), ("rest of windows 0 / 1", (slice(0, 2), slice(2, None)))):
+        ev, eg = rel_l2(s1[sl], s0[sl]), rel_l2(g1[sl].double(), g0[sl].double())
+        print(f"[rot score head] {name}: score rel-L2 vs the aten chain {ev:.2e}, gradient {eg:.2e}")
+        assert ev < 1e-6 and eg < 2e-5, (name, ev, eg)
+    assert float(s1[0, 0].abs().max()) == 0 and float(s0[0, 0].abs().max()) == 0          # identical frames: zero score
+    # the rotation-vector map alone (no series): dfold_rot_head_pre against geometry.quat_to_rotvec, and dfold_rot_head_bwd with
+    # sc = 1, dsc = 0 -- i.e. the gradient of v / (|v| + 2e-6) -- against float64 autograd of the same formulas, every region
+    from ctypes import c_int64, c_void_p
+    from dynamicpdb_amd import _lib
+    from dynamicpdb_amd.model import geometry as G
+    L = _lib.lib()
+    P = W * F * N
+    p = lambda t: c_void_p(t.data_ptr())
+    tq, t0 = torch.tensor(qt).to(dev).contiguous(), torch.tensor(q0).to(dev).contiguous()
+    vec = torch.empty(W, F, N, 3, device=dev)
+    om = torch.empty(W, F, N, device=dev)
+    _lib.check(L.dfold_rot_head_pre(p(tq), p(t0), p(vec), p(om), c_int64(P), _lib.stream()), "pre")
+    vref = G.quat_to_rotvec(G.quat_mul(G.quat_invert(t0), tq))
+    assert rel_l2(vec, vref) < 1e-6 and rel_l2(om, torch.linalg.norm(vref, dim=-1) + 1e-6) < 1e-6
+    assert float((2 * torch.atan2(torch.linalg.norm(vref[0, 1], dim=-1), vref.new_ones(()))).max()) < 2e-3     # (the small-angle rows are small)
+    a64 = t0.double().requires_grad_(True)
+    v64 = G.quat_to_rotvec(G.quat_mul(G.quat_invert(a64), tq.double()))
+    n64 = torch.linalg.norm(v64, dim=-1, keepdim=True)
+    (v64 / (n64 + 2e-6) * gy).sum().backward()
+    one, zero = torch.ones(W, F, N, dtype=torch.float64, device=dev), torch.zeros(W, F, N, dtype=torch.float64, device=dev)
+    dq = torch.empty(W, F, N, 4, device=dev)
+    _lib.check(L.dfold_rot_head_bwd(p(gy.contiguous()), p(tq), p(t0), p(vec), p(om), p(one), p(zero), p(dq), c_int64(P), _lib.stream()), "bwd")
+    for name, sl in (("random", (slice(2, 3),)), ("flipped", (1, 0)), ("small angle", (0, 1))):
+        e = rel_l2(dq[sl].double(), a64.grad[sl])
+        print(f"[rot score head] rotation-vector map, {name}: gradient rel-L2 vs float64 autograd {e:.2e}")
+        assert e < (2e-3 if name == "small angle" else 1e-4), (name, e)        # (small angles: v / |v| of fp32 differences of 1e-4)
+    assert torch.isfinite(dq).all()
+
+
 def test_conv_gradients_flow_through_autograd_and_ddp_wrapper():
     """Without a dp.GradReducer the shared conv tower's weight gradients leave ConvTowerFn.backward as ordinary autograd
     outputs: torch.autograd.grad() returns them, post-accumulate hooks fire, and the reference's own wrapper
