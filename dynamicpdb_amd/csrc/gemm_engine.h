@@ -218,3 +218,5 @@ __device__ __forceinline__ void gemm_epilogue_lds_bf16(const GemmParams& p, f32x
 // conv_fwd_w4.hip: the one-wave-per-SIMD 512 x 160 form of the 5x5 conv launch (dispatched from dfold_gemm_bf16)
 int dfold_conv_w4_launch(const GemmParams& p, int splitk, hipStream_t stream);
 int dfold_conv_w4_launch_streamk(const GemmParams& p, int n_wg, hipStream_t stream);
+// gemm_k256.hip: dense K = 256 products with a wide bf16 output (A panel in registers, weights streamed through LDS)
+int dfold_gemm_k256_launch(const GemmParams& p, hipStream_t stream);

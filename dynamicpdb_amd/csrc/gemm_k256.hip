@@ -1,0 +1,141 @@
+// C[M][N] = A[M][256] B[N][256]^T (+ bias), bf16 in / bf16 out: the K = 256 projections of the trunk (linear_q / linear_kv /
+// linear_q_points / linear_kv_points of InvariantPointAttention, src/model/ipa_pytorch_dynamic.py:350-396, from the 256-wide node
+// features: N = 4096 / 3072 / 2048 at M = windows x frames x residues = 65536) -- round 6.
+//
+// On the tile engine (gemm_bf16.hip, 256 x 256 tiles) these launches ran at 0.38 - 0.41 PFLOP/s: four K steps per tile, so a
+// workgroup is all prologue and epilogue, one workgroup per CU, and the output (537 MB at N = 4096) leaves at 1.6 TB/s.  Here the
+// A PANEL of a wave is loaded once and stays in REGISTERS as MFMA operand fragments for the whole row of the output (32 rows x
+// 256 = 64 registers: the register-resident scheme of triatt_reg.hip), the weights stream through LDS in chunks of 64 output
+// channels as ready-made fragments (requested two chunks ahead into registers, written to the other buffer a chunk ahead),
+// and every chunk's 32 x 64 result of a wave leaves through a wave-private LDS tile as whole 128-byte row segments.
+//   workgroup = 8 waves x 32 rows; per chunk and wave 64 MFMAs (16x16x32) against 32 fragment reads: matrix pipe and LDS are
+//   both at their rate, the launch is bound by the output stream.
+#include "gemm_engine.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned k2u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned k2u32x2;
+#define K2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define K2_WBUF 32768                      // 32 fragments of 1 KB: (channel tile ct, k step ks) -> fragment ct * 8 + ks
+#define K2_SPITCH 144                      // staged row: 64 bf16 + 16 bytes
+#define K2_STAGE (32 * K2_SPITCH)
+#define K2_LDS (2 * K2_WBUF + 8 * K2_STAGE)
+
+// RAGGED: the (single) row block that straddles M, launched on its own -- predicated stores hide their number from the compiler's
+// wait-count pass, which then waits for them wherever it waits for a weight fragment request
+template <bool BIAS, bool RAGGED>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k256_kernel(const GemmParams p, const int block0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int M = p.M, NC = p.N >> 6;
+  const long m0 = (long)(block0 + (int)blockIdx.x) * 256 + w * 32;
+  const bf16_t* const A = p.A + p.am.base;
+  bf16_t* const C = (bf16_t*)p.C + p.cm.base;
+  // ---- the wave's A panel: xa[t][ks], lane (l15, l4) = row m0 + 16 t + l15, k = 32 ks + 8 l4 .. + 8 (rows past M: the last row,
+  //      computed and never stored) ----
+  bf16x8 xa[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long m = m0 + t * 16 + l15;
+    if (RAGGED) m = m < M ? m : M - 1;
+    const bf16_t* src = A + m * p.am.ld + l4 * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xa[t][ks] = *(const bf16x8*)(src + ks * 32);
+  }
+  // ---- weights: fragment f = ct * 8 + ks of a chunk holds, in lane (l15, l4), B[n0 + 16 ct + l15][32 ks + 8 l4 .. + 8]; wave w
+  //      moves fragments 4 w .. 4 w + 3 (ct = w >> 1, ks = 4 (w & 1) + j) ----
+  const bf16_t* const wsrc = p.B + (long)((w >> 1) * 16 + l15) * p.ldb + (w & 1) * 128 + l4 * 8;
+  const long chunk_stride = 64 * p.ldb;
+  bf16x8 wst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + j * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *(bf16x8*)(smem + (w * 4 + j) * 1024 + lane * 16) = wst[j];
+  if (NC > 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + chunk_stride + j * 32);
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the A panel is in (said here, the loop below would otherwise wait for it mid-chunk)
+  char* const st = smem + 2 * K2_WBUF + w * K2_STAGE;
+
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const char* const wb = smem + (c & 1) * K2_WBUF;
+    // the fragments of chunk c + 1 (requested a whole chunk ago) go into the other buffer -- every wave left it before the
+    // barrier that ended chunk c - 1 --, those of chunk c + 2 are requested: in vmcnt order they are OLDER than this chunk's
+    // stores, so waiting for them next time round does not wait for stores
+    if (c + 1 < NC) {
+      char* const wn = smem + ((c + 1) & 1) * K2_WBUF;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(bf16x8*)(wn + (w * 4 + j) * 1024 + lane * 16) = wst[j];
+      if (c + 2 < NC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + (long)(c + 2) * chunk_stride + j * 32);
+      }
+    }
+    f32x4 bv[4];            // (a compile-time switch: as a run-time one every channel tile of the epilogue got its own branch, load and
+                            //  s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous chunk's stores)
+    if (BIAS) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const f32x4*)(p.bias + c * 64 + ct * 16 + l4 * 4);
+    }
+    // acc[t][ct]: lane (l15, l4) = row 16 t + l15, output channels 64 c + 16 ct + 4 l4 .. + 4   (A operand = weight fragment)
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 bf[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bf[ct] = *(const bf16x8*)(wb + (ct * 8 + ks) * 1024 + lane * 16);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][ct] = K2_MFMA(bf[ct], xa[t][ks], acc[t][ct]);
+    }
+    // ---- epilogue of the chunk: (+ bias) -> bf16 -> the wave's LDS tile [32 rows][64 channels] -> whole 128-byte row segments ----
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 v = acc[t][ct];
+        if (BIAS) v += bv[ct];
+        *(k2u32x2*)(st + (t * 16 + l15) * K2_SPITCH + ct * 32 + l4 * 8) = (k2u32x2){pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3])};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = lane + 64 * j, row = id >> 3, pc = id & 7;
+      const k2u32x4 v = *(const k2u32x4*)(st + row * K2_SPITCH + pc * 16);
+      const long m = m0 + row;
+      if (!RAGGED || m < M) *(k2u32x4*)(C + m * p.cm.ld + c * 64 + pc * 8) = v;
+    }
+    __syncthreads();        // the next chunk's fragments are complete; every wave has left this chunk's buffer and its own tile
+  }
+}
+
+// the launch qualifies (checked by the caller, dfold_gemm_bf16): plain row maps, one K segment of 256, N % 64 == 0, bf16 out,
+// flags within {OUT_BF16, BIAS}, alpha == 1
+template <bool BIAS, bool RAGGED>
+static void k256_launch(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
+  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<BIAS, RAGGED>), K2_LDS);
+  DFOLD_LAUNCH((gemm_k256_kernel<BIAS, RAGGED>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS, stream, p, block0);
+}
+int dfold_gemm_k256_launch(const GemmParams& p, hipStream_t stream) {
+  const int full = p.M / 256, bias = (p.flags & DFOLD_GEMM_BIAS) != 0;
+  if (full > 0) {
+    if (bias) k256_launch<true, false>(p, 0, full, stream);
+    else k256_launch<false, false>(p, 0, full, stream);
+    if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
+  }
+  if (p.M % 256) {
+    if (bias) k256_launch<true, true>(p, full, 1, stream);
+    else k256_launch<false, true>(p, full, 1, stream);
+  }
+  return dfold_check_launch();
+}

@@ -463,6 +463,29 @@ def test_conv_flagged_launch_with_device_chosen_split(dev, live, monkeypatch):
             assert int(cnt.abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,N,bias", [(8192, 2048, False), (4096 + 37, 1024, True), (65536, 4096, False)])
+def test_k256_projection_kernel_vs_fp64(dev, M, N, bias, monkeypatch):
+    """Round 6: dense products with K = 256 and a wide bf16 output (the q / kv / point projections of IPA) run on
+    csrc/gemm_k256.hip -- the wave's A panel stays in registers as operand fragments, the weights stream through LDS in chunks of
+    64 output channels.  Against float64 on the same bf16 operands (rounded to bf16), with a ragged last row block and a bias,
+    and against the tile kernels (DFOLD_GEMM_K256=0 is read once per process: the comparison is with the math, not a re-dispatch)."""
+    from dynamicpdb_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    A = torch.randn(M, 256, generator=gen).to(torch.bfloat16).to(dev)
+    B = (torch.randn(N, 256, generator=gen) / 16).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=gen).to(dev) if bias else None
+    C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, B, C, M, N, 256, a_rows=ops.rows_plain(256), c_rows=ops.rows_plain(N), ldb=256, bias=b)
+    rows = torch.cat([torch.arange(0, min(M, 600)), torch.arange(M - 300, M)]).to(dev)       # (fp64 reference on a row sample)
+    ref = A[rows].double() @ B.double().t()
+    if bias:
+        ref = ref + b.double()
+    assert torch.isfinite(C.float()).all()
+    e = rel_l2(C[rows].double(), ref)
+    assert e < 4e-3, e
+    assert float((C[rows].double() - ref.to(torch.bfloat16).double()).abs().max()) <= 2 * float(ref.abs().max()) * 2 ** -8
+
+
 def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
     """csrc/conv_fwd_w4.hip (512 x 160 tile, one wave per SIMD, 32-channel halo groups): unsplit conv launches whose tiles are
     runs of 256 consecutive residues.  Whole outputs against fp64 conv2d on the same bf16 operands for every epilogue of the
