@@ -81,6 +81,14 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
         assert L.dfold_triatt_reg_fwd(one, c_int32(0), one, one, one, one, one, tri, one, one, one, c_int32(0), None, c_int32(0),
                                       c_int32(1), c_int32(n), c_int32(npad), c_int32(0), c_float(1e9), c_float(0.17), c_float(1e-5),
                                       c_void_p(0)) == -1
+    # round 6: loss launch / rotation-score head: empty problems, missing buffers
+    assert L.dfold_loss_last_frame(one, one, one, one, one, one, one, one, one, one, one, one, one, one, one, one, one, c_int32(0), c_int32(4),
+                                   c_int32(2), c_float(100.0), c_float(7.0), c_float(1.0), c_float(0.0), c_void_p(0)) == -1
+    assert L.dfold_loss_last_frame(one, one, one, one, one, one, one, one, one, one, one, one, None, one, one, one, one, c_int32(1), c_int32(4),
+                                   c_int32(2), c_float(100.0), c_float(7.0), c_float(1.0), c_float(0.0), c_void_p(0)) == -1
+    assert L.dfold_rot_head_pre(one, one, one, one, c_int64(0), c_void_p(0)) == -1
+    assert L.dfold_rot_head_post(one, one, None, one, c_int64(8), c_void_p(0)) == -1
+    assert L.dfold_rot_head_bwd(one, one, one, one, one, one, one, None, c_int64(8), c_void_p(0)) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):
@@ -666,6 +674,23 @@ def test_conv_tail_split_policy():
         for tpf in (4, 8, 16, 32, 64):
             k = ops.conv_tail_frames(nf, tpf, 256)
             assert 0 <= k < nf and ((nf - k) * tpf) % 256 == 0 or k == 0
+
+
+def test_flagged_launch_split_policy(monkeypatch):
+    """ops.nz_split_parts: the parts per tile a zero-frame-flagged conv launch carries (the device decides how many of them walk K):
+    the largest of 5 / 4 / 2 that divides the 64-channel chunks, capped by DFOLD_CONV_NZ_SPLIT, none when splitting is off."""
+    from dynamicpdb_amd import ops
+    monkeypatch.delenv("DFOLD_CONV_SPLITK", raising=False)
+    monkeypatch.setattr(ops, "_NZ_SPLIT", 5)
+    assert ops.nz_split_parts(1280) == 5 and ops.nz_split_parts(640) == 5 and ops.nz_split_parts(256) == 4 and ops.nz_split_parts(128) == 2
+    assert ops.nz_split_parts(192) == 0 and ops.nz_split_parts(100) == 0          # 3 chunks: no admissible factor; not whole chunks
+    monkeypatch.setattr(ops, "_NZ_SPLIT", 4)
+    assert ops.nz_split_parts(1280) == 4 and ops.nz_split_parts(640) == 2
+    monkeypatch.setattr(ops, "_NZ_SPLIT", 0)
+    assert ops.nz_split_parts(1280) == 0
+    monkeypatch.setattr(ops, "_NZ_SPLIT", 5)
+    monkeypatch.setenv("DFOLD_CONV_SPLITK", "0")
+    assert ops.nz_split_parts(1280) == 0
 
 
 def test_isa_audit_keeps_the_serialised_load_fixes_fixed():
