@@ -1,4 +1,4 @@
-// C[M][N] = A[M][256] B[N][256]^T (+ bias), bf16 in / bf16 out: the K = 256 projections of the trunk (linear_q / linear_kv /
+// C[M][N] = A[M][256] B[N][256]^T (+ bias), bf16 in / bf16 or fp32 out: the K = 256 projections of the trunk (linear_q / linear_kv /
 // linear_q_points / linear_kv_points of InvariantPointAttention, src/model/ipa_pytorch_dynamic.py:350-396, from the 256-wide node
 // features: N = 4096 / 3072 / 2048 at M = windows x frames x residues = 65536) -- round 6.
 //
@@ -16,13 +16,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned k2u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned k2u32x2;
 #define K2_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define K2_WBUF 32768                      // 32 fragments of 1 KB: (channel tile ct, k step ks) -> fragment ct * 8 + ks
-#define K2_SPITCH 144                      // staged row: 64 bf16 + 16 bytes
-#define K2_STAGE (32 * K2_SPITCH)
-#define K2_LDS (2 * K2_WBUF + 8 * K2_STAGE)
+#define K2_SPITCH(F32) ((F32) ? 272 : 144)    // staged row: 64 bf16 | fp32 + 16 bytes
+#define K2_STAGE(F32) (32 * K2_SPITCH(F32))
+#define K2_LDS(F32) (2 * K2_WBUF + 8 * K2_STAGE(F32))
 
 // RAGGED: the (single) row block that straddles M, launched on its own -- predicated stores hide their number from the compiler's
 // wait-count pass, which then waits for them wherever it waits for a weight fragment request
-template <bool BIAS, bool RAGGED>
+template <bool BIAS, bool RAGGED, bool F32>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k256_kernel(const GemmParams p, const int block0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int M = p.M, NC = p.N >> 6;
   const long m0 = (long)(block0 + (int)blockIdx.x) * 256 + w * 32;
   const bf16_t* const A = p.A + p.am.base;
-  bf16_t* const C = (bf16_t*)p.C + p.cm.base;
+  char* const C = (char*)p.C + p.cm.base * (F32 ? 4 : 2);
   // ---- the wave's A panel: xa[t][ks], lane (l15, l4) = row m0 + 16 t + l15, k = 32 ks + 8 l4 .. + 8 (rows past M: the last row,
   //      computed and never stored) ----
   bf16x8 xa[2][8];
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the A panel is in (said here, the loop below would otherwise wait for it mid-chunk)
-  char* const st = smem + 2 * K2_WBUF + w * K2_STAGE;
+  constexpr int SP = K2_SPITCH(F32);
+  char* const st = smem + 2 * K2_WBUF + w * K2_STAGE(F32);
 
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
@@ -103,39 +104,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 2; ++t) {
         f32x4 v = acc[t][ct];
         if (BIAS) v += bv[ct];
-        *(k2u32x2*)(st + (t * 16 + l15) * K2_SPITCH + ct * 32 + l4 * 8) = (k2u32x2){pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3])};
+        if (F32)
+          *(f32x4*)(st + (t * 16 + l15) * SP + ct * 64 + l4 * 16) = v;
+        else
+          *(k2u32x2*)(st + (t * 16 + l15) * SP + ct * 32 + l4 * 8) = (k2u32x2){pack2bf_hw(v[0], v[1]), pack2bf_hw(v[2], v[3])};
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    // 32 rows x 128 (bf16) | 256 (fp32) bytes: lane -> (row, 16-byte piece), 4 | 8 instructions
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int id = lane + 64 * j, row = id >> 3, pc = id & 7;
-      const k2u32x4 v = *(const k2u32x4*)(st + row * K2_SPITCH + pc * 16);
+    for (int j = 0; j < (F32 ? 8 : 4); ++j) {
+      const int id = lane + 64 * j, row = F32 ? id >> 4 : id >> 3, pc = F32 ? id & 15 : id & 7;
+      const k2u32x4 v = *(const k2u32x4*)(st + row * SP + pc * 16);
       const long m = m0 + row;
-      if (!RAGGED || m < M) *(k2u32x4*)(C + m * p.cm.ld + c * 64 + pc * 8) = v;
+      if (!RAGGED || m < M) *(k2u32x4*)(C + (m * p.cm.ld + c * 64) * (F32 ? 4 : 2) + pc * 16) = v;
     }
     __syncthreads();        // the next chunk's fragments are complete; every wave has left this chunk's buffer and its own tile
   }
 }
 
-// the launch qualifies (checked by the caller, dfold_gemm_bf16): plain row maps, one K segment of 256, N % 64 == 0, bf16 out,
+// the launch qualifies (checked by the caller, dfold_gemm_bf16): plain row maps, one K segment of 256, N % 64 == 0,
 // flags within {OUT_BF16, BIAS}, alpha == 1
-template <bool BIAS, bool RAGGED>
+template <bool BIAS, bool RAGGED, bool F32>
 static void k256_launch(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
-  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<BIAS, RAGGED>), K2_LDS);
-  DFOLD_LAUNCH((gemm_k256_kernel<BIAS, RAGGED>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS, stream, p, block0);
+  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<BIAS, RAGGED, F32>), K2_LDS(F32));
+  DFOLD_LAUNCH((gemm_k256_kernel<BIAS, RAGGED, F32>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS(F32), stream, p, block0);
+}
+template <bool RAGGED>
+static void k256_pick(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
+  const bool bias = (p.flags & DFOLD_GEMM_BIAS) != 0, f32 = !(p.flags & DFOLD_GEMM_OUT_BF16);
+  if (bias && f32) k256_launch<true, RAGGED, true>(p, block0, blocks, stream);
+  else if (bias) k256_launch<true, RAGGED, false>(p, block0, blocks, stream);
+  else if (f32) k256_launch<false, RAGGED, true>(p, block0, blocks, stream);
+  else k256_launch<false, RAGGED, false>(p, block0, blocks, stream);
 }
 int dfold_gemm_k256_launch(const GemmParams& p, hipStream_t stream) {
-  const int full = p.M / 256, bias = (p.flags & DFOLD_GEMM_BIAS) != 0;
+  const int full = p.M / 256;
   if (full > 0) {
-    if (bias) k256_launch<true, false>(p, 0, full, stream);
-    else k256_launch<false, false>(p, 0, full, stream);
+    k256_pick<false>(p, 0, full, stream);
     if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
   }
-  if (p.M % 256) {
-    if (bias) k256_launch<true, true>(p, full, 1, stream);
-    else k256_launch<false, true>(p, full, 1, stream);
-  }
+  if (p.M % 256) k256_pick<true>(p, full, 1, stream);
   return dfold_check_launch();
 }
