@@ -11,15 +11,23 @@
 //     come out of the matrix pipe with a lane holding (query, 4 + 4 channels) -- exactly a B operand of S^T = K Q^T once the
 //     K tile uses the same channel order, and exactly the layout of O^T = V^T P^T for the gate; K^T and V go to LDS in the
 //     operand layouts of the two attention products (one 16-byte write per lane and tile);
-//   * K / V^T of head h + 1 are written into the second buffer before the attention of head h: ONE barrier per head;
-//   * og_h = gate * O_h / l never touches LDS either: its accumulator layout is a B operand of out^T = W_o og^T (the same
-//     channel order applied to the columns of W_o); the four heads wait in 64 VGPRs for one product at the end of the row;
-//   * LDS = 2 x (K [keys][32] + V^T [32][keys]) + mask bias = 66 KB at N_res <= 256: TWO workgroups (rows) per CU whose
-//     phases interleave freely -- the loads of one row under the softmax of the other.
+//   * the head's weights (q | k | v | g rows of the head: 32 KB) wait in LDS as ready-made operand fragments, requested by LDS-DMA
+//     a whole attention phase ahead (W_o the same way behind the last head): a projection unit costs its 16 products, not an
+//     L2 round trip per unit (the first version loaded fragments from global memory: 17 - 27 k cycles of projections per head,
+//     7 k now);
+//   * og_h = gate * O_h / l never touches LDS either: its accumulator layout is a B operand of out^T = W_o og^T -- V and G rows
+//     are taken in the channel order pi(rho) = 8 ((rho & 15) >> 2) + 4 (rho >> 4) + (rho & 3), so that the k slots of og are
+//     eight consecutive channels and a W_o fragment is 16 contiguous bytes; the four heads wait in 64 VGPRs for one product at
+//     the end of the row;
+//   * LDS = K [keys][32] + V^T [32][keys] + 32 weight fragments + mask bias = 66 KB at N_res <= 256: TWO workgroups (rows) per CU
+//     whose phases interleave freely -- the loads of one row under the softmax of the other; two barriers per head (weights /
+//     K, V^T visible; K, V^T complete / weight buffer free).
 //
 // Softmax: exp2 domain (W_q's product is scaled by scale * log2 e before rounding, the triangle bias arrives x log2 e),
-// online over chunks of 128 keys (32 accumulator registers per 16-query tile; the register budget of two waves per SIMD is
-// 256).  Pass 0 (dfold_triatt_bias_blocked, triatt_fused.hip) writes the blocked triangle bias as before.
+// online over chunks of 64 keys (16 accumulator registers per 16-query tile + 16 that hold the bias blocks of the next chunk,
+// requested before the chunk's arithmetic; the register budget of two waves per SIMD is 256, 128 of them LayerNorm output +
+// gated O).  Pass 0 (dfold_triatt_bias_blocked, triatt_fused.hip) writes the blocked triangle bias as before.
+// What was measured on the way (serialised loads, elimination builds, phase clock, two-tile form): HISTORY.md, round 6.
 #include "dfold_common.h"
 #include "../../include/dfold_hip.h"
 #include <math.h>
