@@ -737,14 +737,15 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
   const int role = (d->a_rows.mode != 0 && d->seg_div == 5 && d->seg_div_mid == 5) ? 1 : (d->nbatch == 25 && d->nb1 == 5) ? 2 : 0;
   const long steps = (long)d->nseg * ((d->seglen + BK - 1) / BK);
   const long tiles256 = (long)((d->M + BM2 - 1) / BM2) * ((d->N + BN - 1) / BN);
-  // K = 256 projections (round 6, gemm_k256.hip; DFOLD_GEMM_K256=0: the tile kernels below, 2: only outputs of 1024 columns and more)
+  // K = 256 projections (round 6, gemm_k256.hip; DFOLD_GEMM_K256=0: the tile kernels below, 2: only outputs of 1024 columns and more, 3: K = 256 only)
   {
     static int k256_mode = -1;
     if (k256_mode < 0) {
       const char* e = getenv("DFOLD_GEMM_K256");
       k256_mode = e ? atoi(e) : 1;
     }
-    if (k256_mode && role == 0 && d->nbatch == 1 && d->nseg == 1 && d->seglen == 256 && d->a_seg0 == 0 && d->b_seg0 == 0 &&
+    if (k256_mode && role == 0 && d->nbatch == 1 && d->nseg == 1 && d->a_seg0 == 0 && d->b_seg0 == 0 &&
+        (d->seglen == 256 || (k256_mode != 3 && d->seglen >= 8 && d->seglen <= 64 && (d->seglen & 7) == 0)) &&
         d->a_rows.mode == 0 && d->c_rows.mode == 0 && (d->flags & ~(DFOLD_GEMM_OUT_BF16 | DFOLD_GEMM_BIAS)) == 0 &&
         d->alpha == 1.f && !d->C2 && d->splitk <= 1 && (d->N % 64) == 0 && d->N >= (k256_mode == 2 ? 1024 : 128) &&
         d->M >= 4096 && ((p.am.ld | p.am.base | p.cm.ld | p.cm.base | d->ldb) & 7) == 0)

@@ -22,7 +22,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned k2u32x2;
 
 // RAGGED: the (single) row block that straddles M, launched on its own -- predicated stores hide their number from the compiler's
 // wait-count pass, which then waits for them wherever it waits for a weight fragment request
-template <bool BIAS, bool RAGGED, bool F32>
+// KS = K steps of 32: 8 (K = 256 exactly) or 2 (8 <= K <= 64, K % 8 == 0: the groups of 8 past K are loaded as zeros -- the pair-side
+// product dz = [dpz | dbias] [W_dz | W_b]^T of the IPA backward, K = 40, ran at 28 TFLOP/s on the tile engine)
+template <bool BIAS, bool RAGGED, bool F32, int KS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k256_kernel(const GemmParams p, const int block0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -33,27 +35,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   char* const C = (char*)p.C + p.cm.base * (F32 ? 4 : 2);
   // ---- the wave's A panel: xa[t][ks], lane (l15, l4) = row m0 + 16 t + l15, k = 32 ks + 8 l4 .. + 8 (rows past M: the last row,
   //      computed and never stored) ----
-  bf16x8 xa[2][8];
+  const int K = p.seglen;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 xa[2][KS];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     long m = m0 + t * 16 + l15;
     if (RAGGED) m = m < M ? m : M - 1;
     const bf16_t* src = A + m * p.am.ld + l4 * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) xa[t][ks] = *(const bf16x8*)(src + ks * 32);
+    for (int ks = 0; ks < KS; ++ks) xa[t][ks] = (KS == 8 || ks * 32 + l4 * 8 < K) ? *(const bf16x8*)(src + ks * 32) : zero8;
   }
-  // ---- weights: fragment f = ct * 8 + ks of a chunk holds, in lane (l15, l4), B[n0 + 16 ct + l15][32 ks + 8 l4 .. + 8]; wave w
-  //      moves fragments 4 w .. 4 w + 3 (ct = w >> 1, ks = 4 (w & 1) + j) ----
-  const bf16_t* const wsrc = p.B + (long)((w >> 1) * 16 + l15) * p.ldb + (w & 1) * 128 + l4 * 8;
+  // ---- weights: fragment f = ct * KS + ks of a chunk holds, in lane (l15, l4), B[n0 + 16 ct + l15][32 ks + 8 l4 .. + 8]; wave w
+  //      moves fragments FPW w .. FPW w + FPW - 1 (KS = 8: four, ct = w >> 1, ks = 4 (w & 1) + j; KS = 2: one, ct = w >> 1, ks = w & 1) ----
+  constexpr int FPW = KS / 2;
+  const int ks0 = (w * FPW) % KS;
+  const bf16_t* const wsrc = p.B + (long)((w >> 1) * 16 + l15) * p.ldb + ks0 * 32 + l4 * 8;
   const long chunk_stride = 64 * p.ldb;
-  bf16x8 wst[4];
+  bool wok[FPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + j * 32);
+  for (int j = 0; j < FPW; ++j) wok[j] = KS == 8 || (ks0 + j) * 32 + l4 * 8 < K;
+  bf16x8 wst[FPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) *(bf16x8*)(smem + (w * 4 + j) * 1024 + lane * 16) = wst[j];
+  for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + j * 32) : zero8;
+#pragma unroll
+  for (int j = 0; j < FPW; ++j) *(bf16x8*)(smem + (w * FPW + j) * 1024 + lane * 16) = wst[j];
   if (NC > 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + chunk_stride + j * 32);
+    for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + chunk_stride + j * 32) : zero8;
   }
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the A panel is in (said here, the loop below would otherwise wait for it mid-chunk)
@@ -69,10 +78,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (c + 1 < NC) {
       char* const wn = smem + ((c + 1) & 1) * K2_WBUF;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(bf16x8*)(wn + (w * 4 + j) * 1024 + lane * 16) = wst[j];
+      for (int j = 0; j < FPW; ++j) *(bf16x8*)(wn + (w * FPW + j) * 1024 + lane * 16) = wst[j];
       if (c + 2 < NC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wst[j] = *(const bf16x8*)(wsrc + (long)(c + 2) * chunk_stride + j * 32);
+        for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + (long)(c + 2) * chunk_stride + j * 32) : zero8;
       }
     }
     f32x4 bv[4];            // (a compile-time switch: as a run-time one every channel tile of the epilogue got its own branch, load and
@@ -88,10 +97,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 bf[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bf[ct] = *(const bf16x8*)(wb + (ct * 8 + ks) * 1024 + lane * 16);
+      for (int ct = 0; ct < 4; ++ct) bf[ct] = *(const bf16x8*)(wb + (ct * KS + ks) * 1024 + lane * 16);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -126,25 +135,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // the launch qualifies (checked by the caller, dfold_gemm_bf16): plain row maps, one K segment of 256, N % 64 == 0,
 // flags within {OUT_BF16, BIAS}, alpha == 1
-template <bool BIAS, bool RAGGED, bool F32>
+template <bool BIAS, bool RAGGED, bool F32, int KS>
 static void k256_launch(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
-  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<BIAS, RAGGED, F32>), K2_LDS(F32));
-  DFOLD_LAUNCH((gemm_k256_kernel<BIAS, RAGGED, F32>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS(F32), stream, p, block0);
+  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<BIAS, RAGGED, F32, KS>), K2_LDS(F32));
+  DFOLD_LAUNCH((gemm_k256_kernel<BIAS, RAGGED, F32, KS>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS(F32), stream, p, block0);
 }
-template <bool RAGGED>
+template <bool RAGGED, int KS>
 static void k256_pick(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
   const bool bias = (p.flags & DFOLD_GEMM_BIAS) != 0, f32 = !(p.flags & DFOLD_GEMM_OUT_BF16);
-  if (bias && f32) k256_launch<true, RAGGED, true>(p, block0, blocks, stream);
-  else if (bias) k256_launch<true, RAGGED, false>(p, block0, blocks, stream);
-  else if (f32) k256_launch<false, RAGGED, true>(p, block0, blocks, stream);
-  else k256_launch<false, RAGGED, false>(p, block0, blocks, stream);
+  if (bias && f32) k256_launch<true, RAGGED, true, KS>(p, block0, blocks, stream);
+  else if (bias) k256_launch<true, RAGGED, false, KS>(p, block0, blocks, stream);
+  else if (f32) k256_launch<false, RAGGED, true, KS>(p, block0, blocks, stream);
+  else k256_launch<false, RAGGED, false, KS>(p, block0, blocks, stream);
 }
+// K = p.seglen: 256, or 8 ... 64 in whole groups of 8
 int dfold_gemm_k256_launch(const GemmParams& p, hipStream_t stream) {
   const int full = p.M / 256;
+  const bool k8 = p.seglen == 256;
   if (full > 0) {
-    k256_pick<false>(p, 0, full, stream);
+    if (k8) k256_pick<false, 8>(p, 0, full, stream);
+    else k256_pick<false, 2>(p, 0, full, stream);
     if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
   }
-  if (p.M % 256) k256_pick<true>(p, full, 1, stream);
+  if (p.M % 256) {
+    if (k8) k256_pick<true, 8>(p, full, 1, stream);
+    else k256_pick<true, 2>(p, full, 1, stream);
+  }
   return dfold_check_launch();
 }
