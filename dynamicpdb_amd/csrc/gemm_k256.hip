@@ -11,6 +11,7 @@
 //   workgroup = 8 waves x 32 rows; per chunk and wave 64 MFMAs (16x16x32) against 32 fragment reads: matrix pipe and LDS are
 //   both at their rate, the launch is bound by the output stream.
 #include "gemm_engine.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) unsigned k2u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned k2u32x2;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int M = p.M, NC = p.N >> 6;
+  const int M = p.M, N = p.N, NCF = N >> 6, NC = NCF + ((N >> 5) & 1);      // chunks of 64 output channels (+ one of 32)
   const long m0 = (long)(block0 + (int)blockIdx.x) * 256 + w * 32;
   const bf16_t* const A = p.A + p.am.base;
   char* const C = (char*)p.C + p.cm.base * (F32 ? 4 : 2);
@@ -50,27 +51,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   //      moves fragments FPW w .. FPW w + FPW - 1 (KS = 8: four, ct = w >> 1, ks = 4 (w & 1) + j; KS = 2: one, ct = w >> 1, ks = w & 1) ----
   constexpr int FPW = KS / 2;
   const int ks0 = (w * FPW) % KS;
-  const bf16_t* const wsrc = p.B + (long)((w >> 1) * 16 + l15) * p.ldb + ks0 * 32 + l4 * 8;
-  const long chunk_stride = 64 * p.ldb;
+  const int wrow = (w >> 1) * 16 + l15;         // row of the chunk this lane fetches (rows past N -- the tail chunk -- repeat row N - 1)
+  auto wsrc_of = [&](int c_) { return p.B + (long)min(c_ * 64 + wrow, N - 1) * p.ldb + ks0 * 32 + l4 * 8; };
   bool wok[FPW];
 #pragma unroll
   for (int j = 0; j < FPW; ++j) wok[j] = KS == 8 || (ks0 + j) * 32 + l4 * 8 < K;
   bf16x8 wst[FPW];
 #pragma unroll
-  for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + j * 32) : zero8;
+  for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc_of(0) + j * 32) : zero8;
 #pragma unroll
   for (int j = 0; j < FPW; ++j) *(bf16x8*)(smem + (w * FPW + j) * 1024 + lane * 16) = wst[j];
   if (NC > 1) {
 #pragma unroll
-    for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + chunk_stride + j * 32) : zero8;
+    for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc_of(1) + j * 32) : zero8;
   }
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the A panel is in (said here, the loop below would otherwise wait for it mid-chunk)
   constexpr int SP = K2_SPITCH(F32);
   char* const st = smem + 2 * K2_WBUF + w * K2_STAGE(F32);
 
-#pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
+  auto chunk = [&](auto tail_tag, const int c) {
+    constexpr bool TAIL = decltype(tail_tag)::value;      // the last chunk of an N that is 32 mod 64: channels 0 .. 31 exist
     const char* const wb = smem + (c & 1) * K2_WBUF;
     // the fragments of chunk c + 1 (requested a whole chunk ago) go into the other buffer -- every wave left it before the
     // barrier that ended chunk c - 1 --, those of chunk c + 2 are requested: in vmcnt order they are OLDER than this chunk's
@@ -81,14 +82,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < FPW; ++j) *(bf16x8*)(wn + (w * FPW + j) * 1024 + lane * 16) = wst[j];
       if (c + 2 < NC) {
 #pragma unroll
-        for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc + (long)(c + 2) * chunk_stride + j * 32) : zero8;
+        for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc_of(c + 2) + j * 32) : zero8;
       }
     }
     f32x4 bv[4];            // (a compile-time switch: as a run-time one every channel tile of the epilogue got its own branch, load and
                             //  s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous chunk's stores)
     if (BIAS) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bv[ct] = *(const f32x4*)(p.bias + c * 64 + ct * 16 + l4 * 4);
+      for (int ct = 0; ct < (TAIL ? 2 : 4); ++ct) bv[ct] = *(const f32x4*)(p.bias + c * 64 + ct * 16 + l4 * 4);
     }
     // acc[t][ct]: lane (l15, l4) = row 16 t + l15, output channels 64 c + 16 ct + 4 l4 .. + 4   (A operand = weight fragment)
     f32x4 acc[2][4];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // ---- epilogue of the chunk: (+ bias) -> bf16 -> the wave's LDS tile [32 rows][64 channels] -> whole 128-byte row segments ----
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < (TAIL ? 2 : 4); ++ct) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 v = acc[t][ct];
@@ -122,15 +123,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // 32 rows x 128 (bf16) | 256 (fp32) bytes: lane -> (row, 16-byte piece), 4 | 8 instructions
+    constexpr int PPR = (F32 ? 16 : 8) / (TAIL ? 2 : 1);      // 16-byte pieces per row (tail chunk: half a row)
 #pragma unroll
-    for (int j = 0; j < (F32 ? 8 : 4); ++j) {
-      const int id = lane + 64 * j, row = F32 ? id >> 4 : id >> 3, pc = F32 ? id & 15 : id & 7;
+    for (int j = 0; j < 32 * PPR / 64; ++j) {
+      const int id = lane + 64 * j, row = id / PPR, pc = id % PPR;
       const k2u32x4 v = *(const k2u32x4*)(st + row * SP + pc * 16);
       const long m = m0 + row;
       if (!RAGGED || m < M) *(k2u32x4*)(C + (m * p.cm.ld + c * 64) * (F32 ? 4 : 2) + pc * 16) = v;
     }
     __syncthreads();        // the next chunk's fragments are complete; every wave has left this chunk's buffer and its own tile
-  }
+  };
+#pragma unroll 1
+  for (int c = 0; c < NCF; ++c) chunk(std::false_type{}, c);
+  if (NC > NCF) chunk(std::true_type{}, NCF);
 }
 
 // the launch qualifies (checked by the caller, dfold_gemm_bf16): plain row maps, one K segment of 256, N % 64 == 0,

@@ -464,7 +464,8 @@ def test_conv_flagged_launch_with_device_chosen_split(dev, live, monkeypatch):
 
 
 @pytest.mark.parametrize("M,N,bias,f32", [(8192, 2048, False, False), (4096 + 37, 1024, True, False), (65536, 4096, False, False),
-                                          (65536, 256, False, True), (8192 + 5, 192, True, True), (4096, 128, False, False)])
+                                          (65536, 256, False, True), (8192 + 5, 192, True, True), (4096, 128, False, False),
+                                          (65536, 480, False, True), (4096 + 100, 160, True, False)])
 @pytest.mark.parametrize("K", [256, 40, 64, 8])
 def test_k256_projection_kernel_vs_fp64(dev, M, N, bias, f32, K, monkeypatch):
     """Round 6: dense products with K = 256 and a wide bf16 output (the q / kv / point projections of IPA) run on
