@@ -746,7 +746,9 @@ extern "C" int dfold_gemm_bf16(const dfold_gemm_desc* d, void* stream) {
     }
     if (k256_mode && role == 0 && d->nbatch == 1 && d->nseg == 1 && d->a_seg0 == 0 && d->b_seg0 == 0 &&
         (d->seglen == 256 || (k256_mode != 3 && d->seglen >= 8 && d->seglen <= 64 && (d->seglen & 7) == 0)) &&
-        d->a_rows.mode == 0 && d->c_rows.mode == 0 && (d->flags & ~(DFOLD_GEMM_OUT_BF16 | DFOLD_GEMM_BIAS)) == 0 &&
+        d->a_rows.mode == 0 && d->c_rows.mode == 0 &&
+        ((d->flags & ~(DFOLD_GEMM_OUT_BF16 | DFOLD_GEMM_BIAS)) == 0 ||
+         (d->flags == (DFOLD_GEMM_OUT_BF16 | DFOLD_GEMM_RELUMASK) && k256_mode == 1 && (!d->nz_ps || d->nz_f0 > 0))) &&
         d->alpha == 1.f && !d->C2 && d->splitk <= 1 && (d->N % 32) == 0 && d->N >= (k256_mode == 2 ? 1024 : 128) &&
         d->M >= 4096 && ((p.am.ld | p.am.base | p.cm.ld | p.cm.base | d->ldb) & 7) == 0)
       return dfold_gemm_k256_launch(p, (hipStream_t)stream);

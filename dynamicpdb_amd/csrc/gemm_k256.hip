@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned k2u32x2;
 // wait-count pass, which then waits for them wherever it waits for a weight fragment request
 // KS = K steps of 32: 8 (K = 256 exactly) or 2 (8 <= K <= 64, K % 8 == 0: the groups of 8 past K are loaded as zeros -- the pair-side
 // product dz = [dpz | dbias] [W_dz | W_b]^T of the IPA backward, K = 40, ran at 28 TFLOP/s on the tile engine)
-template <bool BIAS, bool RAGGED, bool F32, int KS>
+template <bool BIAS, bool RAGGED, bool F32, int KS, bool RMASK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_k256_kernel(const GemmParams p, const int block0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -36,6 +36,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   char* const C = (char*)p.C + p.cm.base * (F32 ? 4 : 2);
   // ---- the wave's A panel: xa[t][ks], lane (l15, l4) = row m0 + 16 t + l15, k = 32 ks + 8 l4 .. + 8 (rows past M: the last row,
   //      computed and never stored) ----
+  if (RMASK && p.nz_ps != nullptr) {
+    // row-block flags of A (dfold_row_block_flags: prefix sums over blocks of p.nz_f0 rows): a workgroup whose 256 rows of A are all
+    // zero stores the zeros its masked product would be and leaves (the angle head's backward: 31 of 32 blocks, functional.AngleResnetFn)
+    const long mb = (long)(block0 + (int)blockIdx.x) * 256;
+    const long ml = (mb + 256 < M ? mb + 256 : M) - 1;
+    if (p.nz_ps[ml / p.nz_f0 + 1] - p.nz_ps[mb / p.nz_f0] <= 0) {
+      const int n16 = N >> 3;                                   // 16-byte pieces per row
+      for (long id = tid; id < (ml - mb + 1) * n16; id += 512) {
+        const long row = id / n16, pc = id - row * n16;
+        *(k2u32x4*)(C + ((mb + row) * p.cm.ld) * 2 + pc * 16) = (k2u32x4){0u, 0u, 0u, 0u};
+      }
+      return;
+    }
+  }
   const int K = p.seglen;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   bf16x8 xa[2][KS];
@@ -85,6 +99,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < FPW; ++j) wst[j] = wok[j] ? *(const bf16x8*)(wsrc_of(c + 2) + j * 32) : zero8;
       }
     }
+    k2u32x4 rm[4];          // RMASK: the ReLU-mask rows of this chunk's stores (same cells as C), requested before the products
+    if (RMASK) {
+      constexpr int PPR_ = 8 / (TAIL ? 2 : 1);
+#pragma unroll
+      for (int j = 0; j < 32 * PPR_ / 64; ++j) {
+        const int id = lane + 64 * j, row = id / PPR_, pc = id % PPR_;
+        long m = m0 + row;
+        if (RAGGED) m = m < M ? m : M - 1;
+        rm[j] = *(const k2u32x4*)((const char*)(p.R + p.cm.base) + (m * p.cm.ld + c * 64) * 2 + pc * 16);
+      }
+    }
     f32x4 bv[4];            // (a compile-time switch: as a run-time one every channel tile of the epilogue got its own branch, load and
                             //  s_waitcnt vmcnt(0) -- which on gfx9 also waits for the previous chunk's stores)
     if (BIAS) {
@@ -127,7 +152,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int j = 0; j < 32 * PPR / 64; ++j) {
       const int id = lane + 64 * j, row = id / PPR, pc = id % PPR;
-      const k2u32x4 v = *(const k2u32x4*)(st + row * SP + pc * 16);
+      k2u32x4 v = *(const k2u32x4*)(st + row * SP + pc * 16);
+      if (RMASK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          v[q] = (bf_lo(rm[j][q]) > 0.f ? (v[q] & 0xffffu) : 0u) | (bf_hi(rm[j][q]) > 0.f ? (v[q] & 0xffff0000u) : 0u);
+      }
       const long m = m0 + row;
       if (!RAGGED || m < M) *(k2u32x4*)(C + (m * p.cm.ld + c * 64) * (F32 ? 4 : 2) + pc * 16) = v;
     }
@@ -153,10 +183,28 @@ static void k256_pick(const GemmParams& p, int block0, int blocks, hipStream_t s
   else if (f32) k256_launch<false, RAGGED, true, KS>(p, block0, blocks, stream);
   else k256_launch<false, RAGGED, false, KS>(p, block0, blocks, stream);
 }
-// K = p.seglen: 256, or 8 ... 64 in whole groups of 8
+template <bool RAGGED, int KS>
+static void k256_rmask(const GemmParams& p, int block0, int blocks, hipStream_t stream) {
+  DFOLD_MAX_LDS_ONCE((gemm_k256_kernel<false, RAGGED, false, KS, true>), K2_LDS(false));
+  DFOLD_LAUNCH((gemm_k256_kernel<false, RAGGED, false, KS, true>), dim3((unsigned)blocks), dim3(512), (size_t)K2_LDS(false), stream, p, block0);
+}
+// K = p.seglen: 256, or 8 ... 64 in whole groups of 8.  DFOLD_GEMM_RELUMASK (bf16 out, no bias): the ReLU backward in the epilogue,
+// with A's row-block flags (p.nz_ps) dead workgroups store zeros.
 int dfold_gemm_k256_launch(const GemmParams& p, hipStream_t stream) {
   const int full = p.M / 256;
   const bool k8 = p.seglen == 256;
+  if (p.flags & DFOLD_GEMM_RELUMASK) {
+    if (full > 0) {
+      if (k8) k256_rmask<false, 8>(p, 0, full, stream);
+      else k256_rmask<false, 2>(p, 0, full, stream);
+      if (dfold_check_launch() != DFOLD_OK) return DFOLD_ELAUNCH;
+    }
+    if (p.M % 256) {
+      if (k8) k256_rmask<true, 8>(p, full, 1, stream);
+      else k256_rmask<true, 2>(p, full, 1, stream);
+    }
+    return dfold_check_launch();
+  }
   if (full > 0) {
     if (k8) k256_pick<false, 8>(p, 0, full, stream);
     else k256_pick<false, 2>(p, 0, full, stream);

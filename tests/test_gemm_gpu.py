@@ -492,6 +492,38 @@ def test_k256_projection_kernel_vs_fp64(dev, M, N, bias, f32, K, monkeypatch):
         assert float((C[rows].double() - ref.to(torch.bfloat16).double()).abs().max()) <= 2 * float(ref.abs().max()) * 2 ** -8
 
 
+@pytest.mark.parametrize("M,N,K,flagged", [(65536, 1280, 16, True), (8192 + 77, 256, 16, False), (8192, 1280, 256, True)])
+def test_k256_kernel_relu_mask_and_dead_row_blocks(dev, M, N, K, flagged):
+    """gemm_k256.hip with DFOLD_GEMM_RELUMASK (the first data-gradient product of the angle head's backward: K = 16 -> 1280
+    channels, masked by the saved activation): out = (A B^T) where R > 0, else 0; with the row-block flags of A (most 256-row blocks
+    all zero, as under a last-frame loss) the dead workgroups store zeros and the result is the same bits as without flags."""
+    from dynamicpdb_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randn(M, K, generator=gen)
+    if flagged:
+        keep = torch.zeros(M, dtype=torch.bool)
+        keep[(M // 256 - 3) * 256:] = True
+        keep[512:768] = True
+        A = A * keep[:, None]
+    A = A.to(torch.bfloat16).to(dev)
+    B = (torch.randn(N, K, generator=gen) / K ** 0.5).to(torch.bfloat16).to(dev)
+    R = torch.randn(M, N, generator=gen).to(torch.bfloat16).to(dev)
+    outs = []
+    for use_flags in ((True, False) if flagged else (False,)):
+        C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+        nz = None
+        if use_flags:
+            nz = (ops.row_block_flags(A.float(), 256), 0, 256)
+        ops.gemm(A, B, C, M, N, K, a_rows=ops.rows_plain(K), c_rows=ops.rows_plain(N), ldb=K, R=R, flags=ops.GEMM_RELUMASK, nz=nz)
+        outs.append(C)
+    rows = torch.cat([torch.arange(0, 1024), torch.arange(M - 1024, M)]).to(dev)
+    ref = (A[rows].double() @ B.double().t()) * (R[rows].double() > 0)
+    assert rel_l2(outs[0][rows].double(), ref) < 4e-3
+    assert float(outs[0][1024:2048].float().abs().max()) == 0 if flagged else True
+    if flagged:
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_one_wave_per_simd_kernel_vs_fp64(dev):
     """csrc/conv_fwd_w4.hip (512 x 160 tile, one wave per SIMD, 32-channel halo groups): unsplit conv launches whose tiles are
     runs of 256 consecutive residues.  Whole outputs against fp64 conv2d on the same bf16 operands for every epilogue of the
