@@ -20,6 +20,7 @@ for f in $R/dynamicpdb_amd/csrc/*.hip; do  # the diagnostic switches live in scr
       triatt_fused) python $R/scripts/make_triatt_lab.py ;;
       conv_wgrad_tn) python $R/scripts/make_wgrad_lab.py ;;
       pair_fused) python $R/scripts/make_pairproj_lab.py ;;
+      conv_fwd_w4) python $R/scripts/make_conv_w4_lab.py ;;
     esac
     [ -f $lab ] && f=$lab
     /opt/rocm/bin/hipcc $FLAGS "$@" -I $R/include -I $R/dynamicpdb_amd/csrc -c $f -o $out/obj_$name/$b.o

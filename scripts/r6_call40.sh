@@ -1,5 +1,6 @@
 #!/bin/bash
-# what does the epilogue of the 512 x 160 conv kernel cost?  the two production launches with and without it (diagnostic library)
+# what does the epilogue of the 512 x 160 conv kernel cost?  the two production launches with and without it (diagnostic library:
+#   SRC=conv_fwd_w4 bash scripts/build_variant.sh noepi -DW4_NO_EPI   in the build container, before the gpurun call)
 set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
 cat > /tmp/tconv.py <<'PY'
