@@ -407,6 +407,7 @@ _IPA_BWD_FUSED = os.environ.get("DFOLD_IPA_BWD_FUSED", "1") != "0"   # "0": the 
 _PAIR_PROJ_FUSED = os.environ.get("DFOLD_PAIR_PROJ_FUSED", "1") != "0"   # "0": linear_b / down_z as three GEMM launches (A/B runs)
 _IPA_PAIR_STREAM = os.environ.get("DFOLD_IPA_PAIR_STREAM", "1") != "0"   # "0": the pair-value products as batched GEMMs (rounds 1-5)
 _IPA_PAIR_TN = os.environ.get("DFOLD_IPA_PAIR_TN", "1") != "0"       # "0": dz's pair product through two transposed copies (rounds 1-5)
+_IPA_PAIR_WTN = os.environ.get("DFOLD_IPA_PAIR_WTN", "1") != "0"     # "0": the pair-side weight gradients through transposed copies of z / dpz
 _IPA_KEEP_P32 = False      # diagnostic: also write the fp32 copy of the probabilities (nothing reads it)
 _IPA_WS = {}
 
@@ -702,16 +703,28 @@ class IpaCoreFn(Function):
         dz = torch.empty((B * NN, CZ), dtype=BF16, device=dev)
         gemm(dpzb, _wt_cat(w_dz, w_b), dz, B * NN, CZ, KZ, a_rows=rows_plain(KZ), c_rows=rows_plain(CZ), ldb=KZ)
         dz = dz.view(z.shape)
-        zT = _zT(z.view(B * NN, CZ))                                                                     # [CZ][B*NN]
-        dpzT = ops.transpose_bf16(dpzb, B * NN, PZ, ld_src=KZ)                                           # [PZ][B*NN]
-        dw_dz = ops.gemm_reduce_rows(dpzT, zT, PZ, CZ, B * NN)
-        dw_b = torch.zeros((H, CZ), dtype=torch.float32, device=dev)
-        S2 = max(1, min(64, 256 // B))
-        while S2 > 1 and NN % (S2 * 64):
-            S2 -= 1
-        ks = NN // S2                                    # split-K over (window, K slice): 1 output tile otherwise
-        gemm(db_hn, zT, dw_b, H, CZ, ks, a_rows=rows_plain(NN), c_rows=rows_plain(CZ), ldb=B * NN, nbatch=B * S2,
-             nb1=S2, sa=(H * NN, ks), sb=(NN, ks), sc=(0, 0), flags=ops.GEMM_ATOMIC)
+        R = B * NN
+        if _IPA_PAIR_WTN and z.dtype == BF16 and z.is_contiguous() and ops.gemm_tn_ok(KZ, CZ, R, ragged=True):
+            # dW_dz | dW_b = [dpz | dbias]^T z as ONE reduction-major product straight from the operands as they lie (round 6,
+            # second session): dpzb [R, PZ + 8] and z [R, CZ] both have the reduction index as their row.  Before: a transposed copy
+            # of z per block (134 MB), one of dpz, and two products with the transposed operands (0.18 + 0.07 + 0.08 + 0.17 ms).
+            S = 512
+            while S > 1 and R % (S * 64):
+                S //= 2
+            dw_cat = torch.zeros((KZ, CZ), dtype=torch.float32, device=dev)
+            ops.gemm_tn(dpzb, z.view(R, CZ), dw_cat, KZ, CZ, R, KZ, CZ, CZ, splitk=S, flags=ops.GEMM_ATOMIC)
+            dw_dz, dw_b = dw_cat[:PZ], dw_cat[PZ:PZ + H]
+        else:
+            zT = _zT(z.view(R, CZ))                                                                      # [CZ][B*NN]
+            dpzT = ops.transpose_bf16(dpzb, R, PZ, ld_src=KZ)                                            # [PZ][B*NN]
+            dw_dz = ops.gemm_reduce_rows(dpzT, zT, PZ, CZ, R)
+            dw_b = torch.zeros((H, CZ), dtype=torch.float32, device=dev)
+            S2 = max(1, min(64, 256 // B))
+            while S2 > 1 and NN % (S2 * 64):
+                S2 -= 1
+            ks = NN // S2                                    # split-K over (window, K slice): 1 output tile otherwise
+            gemm(db_hn, zT, dw_b, H, CZ, ks, a_rows=rows_plain(NN), c_rows=rows_plain(CZ), ldb=R, nbatch=B * S2,
+                 nb1=S2, sa=(H * NN, ks), sb=(NN, ks), sc=(0, 0), flags=ops.GEMM_ATOMIC)
         db_dz = torch.zeros(PZ, dtype=torch.float32, device=dev)
         ops.colsum_bf16(do_pair, db_dz, do_pair.numel() // PZ, PZ, PZ)
         return dq, dkv, dq_pts, dk_pts, dv_pts, dz, dw_b, dw_dz, db_dz, None, dhw
